@@ -1,0 +1,160 @@
+"""Host-side mirror of the reference's BakeEngine namespace over the C ABI.
+
+`BakeEngine.Init() / Dispose() / Bake(scene)` keep the names, argument meaning and
+(absent) return values of the reference (BakeEngine.h:5-10); failures raise
+`capi.AobError` where the reference silently ignored HRESULTs.  `Baker` wraps the
+staged API (`aob_bake_*`) for tests, the benchmark and the multi-GPU driver.
+
+Everything here calls the HIP library; nothing falls back to a CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .scene import BakeTexture, FlatScene, Scene
+
+
+class Baker:
+    """Staged bake of one flattened scene resident in HBM (aob_bake_* entry points)."""
+
+    def __init__(self, flat: FlatScene, options: capi.AobOptions):
+        self.lib = capi.load()
+        self.flat = flat
+        self.options = options
+        h = C.c_void_p()
+        capi.check(self.lib.aob_bake_create(C.byref(flat.desc), C.byref(options), C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if self.handle:
+            self.lib.aob_bake_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self): return self
+    def __exit__(self, *a): self.close()
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # stages -------------------------------------------------------------------
+    def build_bvh(self): capi.check(self.lib.aob_bake_build_bvh(self.handle))
+    def rasterize(self, material=0): capi.check(self.lib.aob_bake_rasterize(self.handle, material))
+    def trace(self, material=0, begin=0, end=capi.UINT64_MAX):
+        capi.check(self.lib.aob_bake_trace(self.handle, material, begin, end))
+    def resolve(self, material=0): capi.check(self.lib.aob_bake_resolve(self.handle, material))
+    def clear_results(self, material=0): capi.check(self.lib.aob_bake_clear_results(self.handle, material))
+    def run_device(self): capi.check(self.lib.aob_bake_run_device(self.handle))
+    def sync(self): capi.check(self.lib.aob_bake_sync(self.handle))
+
+    def download(self, material=0, dst: np.ndarray | None = None):
+        if dst is None:
+            capi.check(self.lib.aob_bake_download(self.handle, material, None, 0))
+            return None
+        capi.check(self.lib.aob_bake_download(self.handle, material, dst.ctypes.data, dst.nbytes))
+        return dst
+
+    # introspection --------------------------------------------------------------
+    def stats(self) -> capi.AobStats:
+        s = capi.AobStats()
+        capi.check(self.lib.aob_bake_get_stats(self.handle, C.byref(s)))
+        return s
+
+    def node_count(self) -> int:
+        n = C.c_uint64()
+        capi.check(self.lib.aob_bake_node_count(self.handle, C.byref(n)))
+        return n.value
+
+    def nodes(self) -> np.ndarray:
+        n = self.node_count()
+        out = np.zeros(max(n, 1), dtype=capi.node_dtype())
+        capi.check(self.lib.aob_bake_copy_nodes(self.handle, out.ctypes.data, n))
+        return out[:n]
+
+    def surfel_count(self, material=0) -> int:
+        n = C.c_uint64()
+        capi.check(self.lib.aob_bake_surfel_count(self.handle, material, C.byref(n)))
+        return n.value
+
+    def surfels(self, material=0) -> np.ndarray:
+        n = self.surfel_count(material)
+        out = np.zeros(max(n, 1), dtype=capi.surfel_dtype())
+        capi.check(self.lib.aob_bake_copy_surfels(self.handle, material, out.ctypes.data, n))
+        return out[:n]
+
+    def results(self, material=0) -> np.ndarray:
+        m = self.flat.material_array[material]
+        cells = m.width * m.height
+        out = np.zeros(cells, dtype=capi.result_dtype())
+        capi.check(self.lib.aob_bake_copy_results(self.handle, material, out.ctypes.data, cells))
+        return out
+
+    def results_device_ptr(self, material=0):
+        p, n = C.c_void_p(), C.c_uint64()
+        capi.check(self.lib.aob_bake_results_device_ptr(self.handle, material, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def image_device_ptr(self, material=0):
+        p, n = C.c_void_p(), C.c_uint64()
+        capi.check(self.lib.aob_bake_image_device_ptr(self.handle, material, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def stream(self):
+        p = C.c_void_p()
+        capi.check(self.lib.aob_bake_stream(self.handle, C.byref(p)))
+        return p.value
+
+    def last_trace_ms(self) -> float:
+        ms = C.c_float()
+        capi.check(self.lib.aob_bake_last_trace_ms(self.handle, C.byref(ms)))
+        return ms.value
+
+
+class BakeEngine:
+    """namespace BakeEngine { void Init(); void Dispose(); void Bake(Scene*); } (BakeEngine.h:5-10)"""
+
+    Options: capi.AobOptions | None = None     # the reference's constants unless overridden
+    LastStats: capi.AobStats | None = None
+
+    @staticmethod
+    def Init(device: int = -1):
+        cfg = capi.AobDeviceConfig()
+        cfg.device = device
+        capi.check(capi.load().aob_init(C.byref(cfg)))
+        if BakeEngine.Options is None:
+            BakeEngine.Options = capi.default_options()
+
+    @staticmethod
+    def Dispose():
+        capi.load().aob_shutdown()
+
+    @staticmethod
+    def Bake(scene: Scene, texture: BakeTexture | None = None):
+        """Bake(Scene*) writes every material's AO texture (BakeEngine.cpp:404-734).
+        Bake(Scene*, BakeTexture*) — the overload BASELINE.json's north star names — bakes only the
+        material whose GetAOTexture() is `texture`."""
+        opts = BakeEngine.Options or capi.default_options()
+        flat = FlatScene(scene)
+        if texture is None:
+            stats = capi.AobStats()
+            capi.check(capi.load().aob_bake(C.byref(flat.desc), C.byref(opts), C.byref(stats)))
+            BakeEngine.LastStats = stats
+            for i in range(scene.GetMaterialCount()):
+                scene.GetMaterial(i).GetAOTexture().RefreshPreview()     # BakeEngine.cpp:734
+            return
+        which = [i for i in range(scene.GetMaterialCount()) if scene.GetMaterial(i).GetAOTexture() is texture]
+        if not which:
+            raise ValueError("texture does not belong to any material of the scene")
+        with Baker(flat, opts) as b:
+            b.build_bvh()
+            for i in which:
+                b.rasterize(i)
+                b.trace(i)
+                b.resolve(i)
+                b.download(i)
+            BakeEngine.LastStats = b.stats()
+        texture.RefreshPreview()

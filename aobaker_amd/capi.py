@@ -1,0 +1,215 @@
+"""ctypes mirror of include/aobaker.h and loader of the HIP library.
+
+The library is the product: there is no CPU fallback.  `load()` raises if
+`libaobaker_hip.so` has not been built (`python __graft_entry__.py` or
+`make -C aobaker_amd/csrc`), and every wrapper raises `AobError` with the
+library's own `aob_last_error()` text when a call fails.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+ABI_VERSION = 1
+
+# ---- enums (include/aobaker.h) ------------------------------------------------
+AOB_OK = 0
+SAMPLER_REFERENCE_COMPAT = 0
+SAMPLER_COSINE = 1
+ACCUMULATE_QUANTISED = 0
+ACCUMULATE_FLOAT = 1
+FP16_OFF = 0
+FP16_RTZ = 1
+FP16_RNE = 2
+INVALID_ADDR = 0xFFFFFFFF
+UINT64_MAX = 0xFFFFFFFFFFFFFFFF
+
+
+class AobOptions(C.Structure):
+    _fields_ = [
+        ("sample_count", C.c_int32),
+        ("sampler", C.c_int32),
+        ("seed", C.c_uint32),
+        ("use_any_hit", C.c_int32),
+        ("falloff_distance", C.c_float),
+        ("ray_tmax", C.c_float),
+        ("ray_bias", C.c_float),
+        ("bleed_distance", C.c_int32),
+        ("accumulate", C.c_int32),
+        ("normal_fp16", C.c_int32),
+        ("ray_chunk_size", C.c_int32),
+        ("clamp_tmax_to_falloff", C.c_int32),
+        ("reserved", C.c_int32 * 4),
+    ]
+
+
+class AobMeshDesc(C.Structure):
+    _fields_ = [
+        ("positions", C.c_void_p),
+        ("normals", C.c_void_p),
+        ("uvs", C.c_void_p),
+        ("position_stride", C.c_uint32),
+        ("normal_stride", C.c_uint32),
+        ("uv_stride", C.c_uint32),
+        ("vertex_count", C.c_uint32),
+        ("indices", C.c_void_p),
+        ("index_count", C.c_uint32),
+        ("material", C.c_int32),
+        ("model", C.c_float * 16),
+    ]
+
+
+class AobMaterialDesc(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32),
+        ("height", C.c_int32),
+        ("channels", C.c_int32),
+        ("bytes_per_channel", C.c_int32),
+        ("data", C.c_void_p),
+    ]
+
+
+class AobSceneDesc(C.Structure):
+    _fields_ = [
+        ("meshes", C.POINTER(AobMeshDesc)),
+        ("mesh_count", C.c_uint32),
+        ("materials", C.POINTER(AobMaterialDesc)),
+        ("material_count", C.c_uint32),
+    ]
+
+
+class AobDeviceConfig(C.Structure):
+    _fields_ = [("device", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+class AobStats(C.Structure):
+    _fields_ = [
+        ("triangle_count", C.c_uint64),
+        ("node_count", C.c_uint64),
+        ("surfel_count", C.c_uint64),
+        ("ray_count", C.c_uint64),
+        ("bvh_depth", C.c_uint32),
+        ("reserved0", C.c_uint32),
+        ("ms_upload", C.c_float),
+        ("ms_bvh_build", C.c_float),
+        ("ms_rasterize", C.c_float),
+        ("ms_trace", C.c_float),
+        ("ms_resolve", C.c_float),
+        ("ms_download", C.c_float),
+        ("ms_total_device", C.c_float),
+        ("reserved1", C.c_float),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if not n.startswith("reserved")}
+
+
+# numpy dtypes of the device records (AobSurfel 40 B, AobBvhNode 64 B, AobResult 8 B)
+def surfel_dtype():
+    import numpy as np
+    return np.dtype([("texel_x", "<i4"), ("texel_y", "<i4"), ("position", "<f4", 3),
+                     ("texcoord", "<f4", 2), ("normal", "<f4", 3)])
+
+
+def node_dtype():
+    import numpy as np
+    return np.dtype([("lmin_or_v0", "<f4", 3), ("addr_left", "<u4"),
+                     ("lmax_or_v1", "<f4", 3), ("shape_id", "<u4"),
+                     ("rmin_or_v2", "<f4", 3), ("addr_right", "<u4"),
+                     ("rmax", "<f4", 3), ("prim_id", "<u4")])
+
+
+def result_dtype():
+    import numpy as np
+    return np.dtype([("total_bits", "<u4"), ("weight_bits", "<u4")])
+
+
+# every symbol include/aobaker.h declares; tests/test_capi_symbols.py checks the
+# built library exports exactly these
+EXPORTED_SYMBOLS = [
+    "aob_init", "aob_shutdown", "aob_default_options", "aob_bake", "aob_last_error",
+    "aob_abi_version",
+    "aob_bake_create", "aob_bake_destroy", "aob_bake_build_bvh", "aob_bake_rasterize",
+    "aob_bake_trace", "aob_bake_resolve", "aob_bake_download", "aob_bake_run_device",
+    "aob_bake_sync", "aob_bake_get_stats", "aob_bake_clear_results",
+    "aob_bake_node_count", "aob_bake_copy_nodes", "aob_bake_surfel_count",
+    "aob_bake_copy_surfels", "aob_bake_copy_results", "aob_bake_results_device_ptr",
+    "aob_bake_image_device_ptr", "aob_bake_stream", "aob_bake_last_trace_ms",
+]
+
+
+class AobError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"aobaker HIP library error {code}: {text}")
+        self.code = code
+
+
+_LIB = None
+
+
+def library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaobaker_hip.so")
+
+
+def load() -> C.CDLL:
+    """dlopen the HIP library (no GPU needed for the dlopen itself)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: the HIP extension is the product and there is no fallback. "
+            "Build it with `python __graft_entry__.py` (or `make -C aobaker_amd/csrc`).")
+    lib = C.CDLL(path)
+    vp, i32, u64 = C.c_void_p, C.c_int32, C.c_uint64
+    P = C.POINTER
+    sig = {
+        "aob_init": (C.c_int, [P(AobDeviceConfig)]),
+        "aob_shutdown": (None, []),
+        "aob_default_options": (None, [P(AobOptions)]),
+        "aob_bake": (C.c_int, [P(AobSceneDesc), P(AobOptions), P(AobStats)]),
+        "aob_last_error": (C.c_char_p, []),
+        "aob_abi_version": (C.c_int, []),
+        "aob_bake_create": (C.c_int, [P(AobSceneDesc), P(AobOptions), P(vp)]),
+        "aob_bake_destroy": (None, [vp]),
+        "aob_bake_build_bvh": (C.c_int, [vp]),
+        "aob_bake_rasterize": (C.c_int, [vp, i32]),
+        "aob_bake_trace": (C.c_int, [vp, i32, u64, u64]),
+        "aob_bake_resolve": (C.c_int, [vp, i32]),
+        "aob_bake_download": (C.c_int, [vp, i32, vp, C.c_size_t]),
+        "aob_bake_run_device": (C.c_int, [vp]),
+        "aob_bake_sync": (C.c_int, [vp]),
+        "aob_bake_get_stats": (C.c_int, [vp, P(AobStats)]),
+        "aob_bake_clear_results": (C.c_int, [vp, i32]),
+        "aob_bake_node_count": (C.c_int, [vp, P(u64)]),
+        "aob_bake_copy_nodes": (C.c_int, [vp, vp, u64]),
+        "aob_bake_surfel_count": (C.c_int, [vp, i32, P(u64)]),
+        "aob_bake_copy_surfels": (C.c_int, [vp, i32, vp, u64]),
+        "aob_bake_copy_results": (C.c_int, [vp, i32, vp, u64]),
+        "aob_bake_results_device_ptr": (C.c_int, [vp, i32, P(vp), P(u64)]),
+        "aob_bake_image_device_ptr": (C.c_int, [vp, i32, P(vp), P(u64)]),
+        "aob_bake_stream": (C.c_int, [vp, P(vp)]),
+        "aob_bake_last_trace_ms": (C.c_int, [vp, P(C.c_float)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.aob_abi_version() != ABI_VERSION:
+        raise ImportError(f"{path}: ABI version {lib.aob_abi_version()} != {ABI_VERSION}")
+    _LIB = lib
+    return lib
+
+
+def check(code: int) -> None:
+    if code != AOB_OK:
+        text = load().aob_last_error()
+        raise AobError(code, text.decode("utf-8", "replace") if text else "")
+
+
+def default_options() -> AobOptions:
+    """The reference's compile-time constants (BakeEngine.cpp:13-18), from the library."""
+    o = AobOptions()
+    load().aob_default_options(C.byref(o))
+    return o

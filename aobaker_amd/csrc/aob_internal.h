@@ -1,0 +1,101 @@
+// aob_internal.h — internal state of the HIP bake library (not part of the ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/aobaker.h"
+
+namespace aob {
+
+void set_error(const char* fmt, ...);
+
+#define AOB_HIP(call)                                                                         \
+    do {                                                                                      \
+        hipError_t e__ = (call);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            aob::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__,  \
+                           __LINE__);                                                         \
+            return e__ == hipErrorOutOfMemory ? AOB_ERR_OUT_OF_MEMORY : AOB_ERR_DEVICE;       \
+        }                                                                                     \
+    } while (0)
+
+#define AOB_TRY(expr)                       \
+    do {                                    \
+        int rc__ = (expr);                  \
+        if (rc__ != AOB_OK) return rc__;    \
+    } while (0)
+
+struct Box { float pmin[3], pmax[3]; };
+
+struct DeviceMesh {
+    float*    positions = nullptr;   // packed float3
+    float*    normals = nullptr;     // packed float3
+    float*    uvs = nullptr;         // packed float2
+    uint32_t* indices = nullptr;
+    uint32_t  vertex_count = 0, triangle_count = 0;
+    uint64_t  triangle_offset = 0;   // first global triangle
+    int32_t   material = -1;
+    float     model[16];
+};
+
+struct DeviceMaterial {
+    int32_t width = 0, height = 0, channels = 0, bytes_per_channel = 0;
+    uint8_t* host_data = nullptr;
+    uint32_t* cover = nullptr;            // W*H: winning triangle index + 1, per section pass
+    uint32_t* block_sums = nullptr;       // scan partials
+    uint32_t  scan_blocks = 0;
+    AobSurfel* surfels = nullptr;         // concatenated, row-major per section
+    uint32_t* section_index = nullptr;    // surfel -> index inside its section's list
+    uint64_t  surfel_capacity = 0, surfel_count = 0;
+    std::vector<uint64_t> section_offsets; // prefix offsets per contributing mesh (+ total)
+    std::vector<uint32_t> section_mesh;
+    AobResult* results = nullptr;         // W*H
+    uint8_t* image = nullptr;             // W*H*channels*bpc
+    bool rasterized = false;
+};
+
+} // namespace aob
+
+struct AobBake {
+    AobOptions opt;
+    hipStream_t stream = nullptr;
+    std::vector<aob::DeviceMesh> meshes;
+    std::vector<aob::DeviceMaterial> materials;
+    uint64_t triangle_count = 0;
+
+    // BVH build workspace and result
+    float4*   tri_verts = nullptr;      // 3 x float4 per triangle: (v0,shape) (v1,prim) (v2,0)
+    aob::Box* prim_bounds = nullptr;
+    uint32_t* scene_bounds_enc = nullptr; // 6 ordered-uint encoded floats
+    uint64_t* codes[2] = { nullptr, nullptr };
+    uint32_t* prim_idx[2] = { nullptr, nullptr };
+    void*     sort_temp = nullptr; size_t sort_temp_bytes = 0;
+    uint32_t* child_left = nullptr; uint32_t* child_right = nullptr; uint32_t* parent = nullptr;
+    aob::Box* node_bounds = nullptr;
+    uint32_t* refit_flags = nullptr;
+    uint32_t* depth_dev = nullptr;
+    AobBvhNode* nodes = nullptr;
+    uint64_t node_count = 0;
+    uint32_t bvh_depth = 0;
+    bool bvh_built = false, depth_known = false, bvh_timed = false;
+    uint32_t* pinned = nullptr;         // 64 B of pinned host memory for small read-backs
+
+    float* hemisphere = nullptr;        // compat sampler table (float3 packed)
+    uint64_t hemisphere_entries = 0;
+
+    hipEvent_t ev[8] = {};
+    hipEvent_t ev_trace[2] = {};
+    bool trace_timed = false;
+    AobStats stats = {};
+};
+
+namespace aob {
+// stage launchers (each enqueues on bake->stream; only the ones that say so synchronise)
+int build_bvh(AobBake* b);                                   // bvh_build.hip
+int rasterize_material(AobBake* b, int32_t material);        // raster.hip (syncs once per section)
+int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end);   // trace.hip
+int resolve_material(AobBake* b, int32_t material);          // resolve.hip
+}

@@ -1,0 +1,521 @@
+// api.hip — the C ABI of include/aobaker.h: device/stream setup, scene upload,
+// stage orchestration and read-back.  Host logic only; the kernels live in
+// bvh_build.hip, raster.hip, trace.hip and resolve.hip.
+#include "aob_internal.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include <rocprim/rocprim.hpp>
+
+namespace aob {
+
+static thread_local char g_error[512] = "";
+static bool g_initialised = false;
+static int g_device = 0;
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof g_error, fmt, ap);
+    va_end(ap);
+}
+
+uint64_t chunk_texel_max(const AobOptions& opt);   // trace.hip
+
+// BakeEngine.cpp:312-333 with the MSVC CRT rand() the reference draws from (never seeded, so
+// the state starts at 1): x = sin(theta)cos(phi), z = sin(theta)sin(phi), y = 1 - sin(theta).
+static void hemisphere_table(float* out, uint64_t count)
+{
+    uint32_t state = 1u;
+    auto msvc_rand = [&]() { state = state * 214013u + 2531011u; return (state >> 16) & 0x7fffu; };
+    const float two_pi = 2.0f * 3.14159265358979323846f;
+    for (uint64_t i = 0; i < count; i++) {
+        float u = (float)msvc_rand() / 32767.0f;
+        float v = (float)msvc_rand() / 32767.0f;
+        float sintheta = std::sqrt(-u * (u - 2.0f));
+        float phi = two_pi * v;
+        float x = sintheta * std::cos(phi);
+        float z = sintheta * std::sin(phi);
+        float len = std::sqrt(x * x + z * z);
+        out[3 * i + 0] = x; out[3 * i + 1] = 1.0f - len; out[3 * i + 2] = z;
+    }
+}
+
+static int validate_options(const AobOptions* o)
+{
+    if (!o) { set_error("options is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
+    if (o->sample_count <= 0 || o->sample_count > (1 << 20)) { set_error("sample_count %d out of range", o->sample_count); return AOB_ERR_INVALID_ARGUMENT; }
+    if (o->sampler != AOB_SAMPLER_REFERENCE_COMPAT && o->sampler != AOB_SAMPLER_COSINE) { set_error("unknown sampler %d", o->sampler); return AOB_ERR_INVALID_ARGUMENT; }
+    if (o->accumulate != AOB_ACCUMULATE_QUANTISED && o->accumulate != AOB_ACCUMULATE_FLOAT) { set_error("unknown accumulate mode %d", o->accumulate); return AOB_ERR_INVALID_ARGUMENT; }
+    if (o->normal_fp16 < AOB_FP16_OFF || o->normal_fp16 > AOB_FP16_RNE) { set_error("unknown normal_fp16 mode %d", o->normal_fp16); return AOB_ERR_INVALID_ARGUMENT; }
+    if (o->bleed_distance < 0 || o->bleed_distance > 64) { set_error("bleed_distance %d out of range", o->bleed_distance); return AOB_ERR_INVALID_ARGUMENT; }
+    if (!(o->falloff_distance > 0.0f)) { set_error("falloff_distance must be positive"); return AOB_ERR_INVALID_ARGUMENT; }
+    return AOB_OK;
+}
+
+static bool valid_format(int channels, int bpc)
+{
+    // Scene/BakeTexture.cpp:9-49
+    if (bpc == 1 || bpc == 2) return channels == 1 || channels == 2 || channels == 4;
+    if (bpc == 4) return channels >= 1 && channels <= 4;
+    return false;
+}
+
+template <class T>
+static int dev_alloc(T** p, uint64_t count)
+{
+    *p = nullptr;
+    if (!count) count = 1;
+    AOB_HIP(hipMalloc((void**)p, sizeof(T) * count));
+    return AOB_OK;
+}
+
+static void free_bake(AobBake* b)
+{
+    if (!b) return;
+    for (auto& m : b->meshes) { hipFree(m.positions); hipFree(m.normals); hipFree(m.uvs); hipFree(m.indices); }
+    for (auto& m : b->materials) {
+        hipFree(m.cover); hipFree(m.block_sums); hipFree(m.surfels); hipFree(m.section_index);
+        hipFree(m.results); hipFree(m.image);
+    }
+    hipFree(b->tri_verts); hipFree(b->prim_bounds); hipFree(b->scene_bounds_enc);
+    hipFree(b->codes[0]); hipFree(b->codes[1]); hipFree(b->prim_idx[0]); hipFree(b->prim_idx[1]);
+    hipFree(b->sort_temp); hipFree(b->child_left); hipFree(b->child_right); hipFree(b->parent);
+    hipFree(b->node_bounds); hipFree(b->refit_flags); hipFree(b->depth_dev); hipFree(b->nodes);
+    hipFree(b->hemisphere);
+    if (b->pinned) hipHostFree(b->pinned);
+    for (auto& e : b->ev) if (e) hipEventDestroy(e);
+    for (auto& e : b->ev_trace) if (e) hipEventDestroy(e);
+    if (b->stream) hipStreamDestroy(b->stream);
+    delete b;
+}
+
+static int check_bake(AobBake* b, int32_t material, bool need_material)
+{
+    if (!b) { set_error("bake handle is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
+    if (need_material && (material < 0 || (size_t)material >= b->materials.size())) {
+        set_error("material %d out of range (%zu)", material, b->materials.size());
+        return AOB_ERR_INVALID_ARGUMENT;
+    }
+    return AOB_OK;
+}
+
+static int ensure_depth(AobBake* b)
+{
+    if (b->depth_known) return AOB_OK;
+    AOB_HIP(hipStreamSynchronize(b->stream));
+    b->bvh_depth = b->node_count > 1 ? b->pinned[1] : 0;
+    b->depth_known = true;
+    return AOB_OK;
+}
+
+} // namespace aob
+
+using namespace aob;
+
+extern "C" {
+
+int aob_abi_version(void) { return AOB_ABI_VERSION; }
+
+const char* aob_last_error(void) { return g_error; }
+
+void aob_default_options(AobOptions* o)
+{
+    if (!o) return;
+    memset(o, 0, sizeof *o);
+    // BakeEngine.cpp:13-18 and GenerateRaysComputeShader.hlsl:47,49
+    o->sample_count = 100;
+    o->sampler = AOB_SAMPLER_REFERENCE_COMPAT;
+    o->seed = 0;
+    o->use_any_hit = 1;
+    o->falloff_distance = 1.25f;
+    o->ray_tmax = 1000000.0f;
+    o->ray_bias = 0.001f;
+    o->bleed_distance = 5;
+    o->accumulate = AOB_ACCUMULATE_QUANTISED;
+    o->normal_fp16 = AOB_FP16_RTZ;
+    o->ray_chunk_size = 0xFFFFFF;
+    o->clamp_tmax_to_falloff = 0;
+}
+
+int aob_init(const AobDeviceConfig* config)
+{
+    int count = 0;
+    AOB_HIP(hipGetDeviceCount(&count));
+    if (count <= 0) { set_error("no HIP device visible"); return AOB_ERR_DEVICE; }
+    int dev = config ? config->device : -1;
+    if (dev < 0) AOB_HIP(hipGetDevice(&dev));
+    if (dev >= count) { set_error("device %d out of range (%d visible)", dev, count); return AOB_ERR_INVALID_ARGUMENT; }
+    AOB_HIP(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    AOB_HIP(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; this library is built for gfx950 (MI355X) only", dev, prop.gcnArchName);
+        return AOB_ERR_UNSUPPORTED;
+    }
+    g_device = dev;
+    g_initialised = true;
+    return AOB_OK;
+}
+
+void aob_shutdown(void) { g_initialised = false; }
+
+int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBake** out)
+{
+    if (!out) { set_error("out is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
+    *out = nullptr;
+    if (!g_initialised) { set_error("aob_init has not been called"); return AOB_ERR_NOT_INITIALISED; }
+    if (!scene) { set_error("scene is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
+    AOB_TRY(validate_options(options));
+    if ((scene->mesh_count && !scene->meshes) || (scene->material_count && !scene->materials)) {
+        set_error("scene arrays are NULL"); return AOB_ERR_INVALID_ARGUMENT;
+    }
+    for (uint32_t i = 0; i < scene->material_count; i++) {
+        const AobMaterialDesc& m = scene->materials[i];
+        if (m.width <= 0 || m.height <= 0 || m.width > 32768 || m.height > 32768) { set_error("material %u: bad size %dx%d", i, m.width, m.height); return AOB_ERR_INVALID_ARGUMENT; }
+        if (!valid_format(m.channels, m.bytes_per_channel)) { set_error("material %u: invalid combination of channelCount %d and bytesPerChannel %d", i, m.channels, m.bytes_per_channel); return AOB_ERR_INVALID_ARGUMENT; }
+    }
+    for (uint32_t i = 0; i < scene->mesh_count; i++) {
+        const AobMeshDesc& m = scene->meshes[i];
+        if (m.vertex_count && (!m.positions || !m.normals || !m.uvs)) { set_error("mesh %u: NULL vertex attribute", i); return AOB_ERR_INVALID_ARGUMENT; }
+        if (m.index_count && !m.indices) { set_error("mesh %u: NULL indices", i); return AOB_ERR_INVALID_ARGUMENT; }
+        if (m.material >= (int32_t)scene->material_count) { set_error("mesh %u: material %d out of range", i, m.material); return AOB_ERR_INVALID_ARGUMENT; }
+        if (m.vertex_count && (m.position_stride < 12 || m.normal_stride < 12 || m.uv_stride < 8)) { set_error("mesh %u: attribute stride too small", i); return AOB_ERR_INVALID_ARGUMENT; }
+        for (uint32_t k = 0; k < 3 * (m.index_count / 3); k++) {
+            if (m.indices[k] >= m.vertex_count) { set_error("mesh %u: index %u out of range (%u vertices)", i, m.indices[k], m.vertex_count); return AOB_ERR_INVALID_ARGUMENT; }
+        }
+    }
+
+    AOB_HIP(hipSetDevice(g_device));
+    AobBake* b = new (std::nothrow) AobBake();
+    if (!b) { set_error("out of host memory"); return AOB_ERR_OUT_OF_MEMORY; }
+    b->opt = *options;
+    int rc = AOB_OK;
+    auto fail = [&](int code) { free_bake(b); return code; };
+#define AOB_C(expr) do { rc = (expr); if (rc != AOB_OK) return fail(rc); } while (0)
+#define AOB_CH(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { set_error("%s failed: %s", #call, hipGetErrorString(e__)); return fail(e__ == hipErrorOutOfMemory ? AOB_ERR_OUT_OF_MEMORY : AOB_ERR_DEVICE); } } while (0)
+
+    AOB_CH(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    for (auto& e : b->ev) AOB_CH(hipEventCreate(&e));
+    for (auto& e : b->ev_trace) AOB_CH(hipEventCreate(&e));
+    AOB_CH(hipHostMalloc((void**)&b->pinned, 64));
+    AOB_CH(hipEventRecord(b->ev[0], b->stream));
+
+    // S1 upload (BakeEngine.cpp:370-398): de-interleave the strided vertex attributes
+    std::vector<float> staging;
+    b->meshes.resize(scene->mesh_count);
+    uint64_t tri_total = 0;
+    for (uint32_t i = 0; i < scene->mesh_count; i++) {
+        const AobMeshDesc& src = scene->meshes[i];
+        DeviceMesh& d = b->meshes[i];
+        d.vertex_count = src.vertex_count;
+        d.triangle_count = src.index_count / 3;
+        d.triangle_offset = tri_total;
+        d.material = src.material;
+        memcpy(d.model, src.model, sizeof d.model);
+        tri_total += d.triangle_count;
+        AOB_C(dev_alloc(&d.positions, 3ull * src.vertex_count));
+        AOB_C(dev_alloc(&d.normals, 3ull * src.vertex_count));
+        AOB_C(dev_alloc(&d.uvs, 2ull * src.vertex_count));
+        AOB_C(dev_alloc(&d.indices, 3ull * d.triangle_count));
+        if (src.vertex_count) {
+            staging.resize(8ull * src.vertex_count);
+            float* sp = staging.data(); float* sn = sp + 3ull * src.vertex_count; float* su = sn + 3ull * src.vertex_count;
+            for (uint32_t v = 0; v < src.vertex_count; v++) {
+                memcpy(sp + 3ull * v, (const uint8_t*)src.positions + (size_t)src.position_stride * v, 12);
+                memcpy(sn + 3ull * v, (const uint8_t*)src.normals + (size_t)src.normal_stride * v, 12);
+                memcpy(su + 2ull * v, (const uint8_t*)src.uvs + (size_t)src.uv_stride * v, 8);
+            }
+            AOB_CH(hipMemcpyAsync(d.positions, sp, 12ull * src.vertex_count, hipMemcpyHostToDevice, b->stream));
+            AOB_CH(hipMemcpyAsync(d.normals, sn, 12ull * src.vertex_count, hipMemcpyHostToDevice, b->stream));
+            AOB_CH(hipMemcpyAsync(d.uvs, su, 8ull * src.vertex_count, hipMemcpyHostToDevice, b->stream));
+            AOB_CH(hipStreamSynchronize(b->stream));     // staging is reused by the next mesh
+        }
+        if (d.triangle_count)
+            AOB_CH(hipMemcpyAsync(d.indices, src.indices, 12ull * d.triangle_count, hipMemcpyHostToDevice, b->stream));
+    }
+    b->triangle_count = tri_total;
+    const uint64_t n = tri_total;
+
+    // BVH workspace, sized once
+    AOB_C(dev_alloc(&b->tri_verts, 3 * n));
+    AOB_C(dev_alloc(&b->prim_bounds, n));
+    AOB_C(dev_alloc(&b->scene_bounds_enc, 8));
+    AOB_C(dev_alloc(&b->codes[0], n)); AOB_C(dev_alloc(&b->codes[1], n));
+    AOB_C(dev_alloc(&b->prim_idx[0], n)); AOB_C(dev_alloc(&b->prim_idx[1], n));
+    AOB_C(dev_alloc(&b->child_left, n)); AOB_C(dev_alloc(&b->child_right, n));
+    AOB_C(dev_alloc(&b->parent, 2 * n));
+    AOB_C(dev_alloc(&b->node_bounds, 2 * n));
+    AOB_C(dev_alloc(&b->refit_flags, n));
+    AOB_C(dev_alloc(&b->depth_dev, 1));
+    AOB_C(dev_alloc(&b->nodes, 2 * n));
+    if (n) {
+        size_t temp = 0;
+        AOB_CH(rocprim::radix_sort_pairs(nullptr, temp, b->codes[0], b->codes[1], b->prim_idx[0], b->prim_idx[1],
+                                         (size_t)n, 0u, 63u, b->stream));
+        b->sort_temp_bytes = temp;
+        AOB_CH(hipMalloc(&b->sort_temp, temp ? temp : 1));
+    }
+
+    b->materials.resize(scene->material_count);
+    for (uint32_t i = 0; i < scene->material_count; i++) {
+        const AobMaterialDesc& src = scene->materials[i];
+        DeviceMaterial& d = b->materials[i];
+        d.width = src.width; d.height = src.height; d.channels = src.channels; d.bytes_per_channel = src.bytes_per_channel;
+        d.host_data = src.data;
+        const uint64_t cells = (uint64_t)d.width * d.height;
+        d.scan_blocks = (uint32_t)((cells + 2047) / 2048);
+        AOB_C(dev_alloc(&d.cover, cells));
+        AOB_C(dev_alloc(&d.block_sums, (uint64_t)d.scan_blocks + 1));
+        AOB_C(dev_alloc(&d.results, cells));
+        AOB_C(dev_alloc(&d.image, cells * d.channels * d.bytes_per_channel));
+        AOB_C(dev_alloc(&d.surfels, cells));
+        AOB_C(dev_alloc(&d.section_index, cells));
+        d.surfel_capacity = cells;
+        AOB_CH(hipMemsetAsync(d.results, 0, sizeof(AobResult) * cells, b->stream));
+        d.section_offsets.push_back(0);
+    }
+
+    if (options->sampler == AOB_SAMPLER_REFERENCE_COMPAT) {
+        // S0 (BakeEngine.cpp:348-356): only the entries a chunk can index are generated
+        b->hemisphere_entries = chunk_texel_max(*options) * (uint64_t)options->sample_count;
+        std::vector<float> table(3 * b->hemisphere_entries);
+        hemisphere_table(table.data(), b->hemisphere_entries);
+        AOB_C(dev_alloc(&b->hemisphere, 3 * b->hemisphere_entries));
+        AOB_CH(hipMemcpyAsync(b->hemisphere, table.data(), sizeof(float) * table.size(), hipMemcpyHostToDevice, b->stream));
+        AOB_CH(hipStreamSynchronize(b->stream));
+    }
+    AOB_CH(hipEventRecord(b->ev[1], b->stream));
+    AOB_CH(hipStreamSynchronize(b->stream));
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, b->ev[0], b->ev[1]);
+    b->stats.ms_upload = ms;
+    b->stats.triangle_count = n;
+#undef AOB_C
+#undef AOB_CH
+    *out = b;
+    return AOB_OK;
+}
+
+void aob_bake_destroy(AobBake* bake)
+{
+    if (!bake) return;
+    if (bake->stream) hipStreamSynchronize(bake->stream);
+    free_bake(bake);
+}
+
+int aob_bake_build_bvh(AobBake* b)
+{
+    AOB_TRY(check_bake(b, 0, false));
+    AOB_HIP(hipEventRecord(b->ev[2], b->stream));
+    AOB_TRY(build_bvh(b));
+    b->depth_known = false;
+    if (b->node_count > 1)
+        AOB_HIP(hipMemcpyAsync(&b->pinned[1], b->depth_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+    AOB_HIP(hipEventRecord(b->ev[3], b->stream));
+    b->bvh_timed = true;
+    return AOB_OK;
+}
+
+int aob_bake_rasterize(AobBake* b, int32_t material)
+{
+    AOB_TRY(check_bake(b, material, true));
+    return rasterize_material(b, material);
+}
+
+int aob_bake_trace(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
+{
+    AOB_TRY(check_bake(b, material, true));
+    if (!b->bvh_built) { set_error("aob_bake_build_bvh has not run"); return AOB_ERR_INVALID_ARGUMENT; }
+    if (!b->materials[material].rasterized) { set_error("material %d has not been rasterised", material); return AOB_ERR_INVALID_ARGUMENT; }
+    AOB_TRY(ensure_depth(b));
+    return trace_range(b, material, begin, end);
+}
+
+int aob_bake_resolve(AobBake* b, int32_t material)
+{
+    AOB_TRY(check_bake(b, material, true));
+    return resolve_material(b, material);
+}
+
+int aob_bake_clear_results(AobBake* b, int32_t material)
+{
+    AOB_TRY(check_bake(b, material, true));
+    DeviceMaterial& m = b->materials[material];
+    AOB_HIP(hipMemsetAsync(m.results, 0, sizeof(AobResult) * (uint64_t)m.width * m.height, b->stream));
+    return AOB_OK;
+}
+
+int aob_bake_download(AobBake* b, int32_t material, void* dst, size_t dst_bytes)
+{
+    AOB_TRY(check_bake(b, material, true));
+    DeviceMaterial& m = b->materials[material];
+    const size_t bytes = (size_t)m.width * m.height * m.channels * m.bytes_per_channel;
+    if (!dst) { dst = m.host_data; dst_bytes = bytes; }
+    if (!dst) { set_error("material %d has no host buffer", material); return AOB_ERR_INVALID_ARGUMENT; }
+    if (dst_bytes < bytes) { set_error("destination too small (%zu < %zu)", dst_bytes, bytes); return AOB_ERR_INVALID_ARGUMENT; }
+    // BakeEngine.cpp:705-709: tightly packed W*H*channels*bytes, no row pitch
+    AOB_HIP(hipMemcpyAsync(dst, m.image, bytes, hipMemcpyDeviceToHost, b->stream));
+    AOB_HIP(hipStreamSynchronize(b->stream));
+    return AOB_OK;
+}
+
+int aob_bake_run_device(AobBake* b)
+{
+    AOB_TRY(check_bake(b, 0, false));
+    hipStream_t s = b->stream;
+    AOB_TRY(aob_bake_build_bvh(b));
+    float ms_r = 0.f, ms_t = 0.f, ms_p = 0.f;
+    for (size_t i = 0; i < b->materials.size(); i++) {
+        AOB_HIP(hipEventRecord(b->ev[4], s));
+        AOB_TRY(rasterize_material(b, (int32_t)i));
+        AOB_HIP(hipEventRecord(b->ev[5], s));
+        AOB_TRY(ensure_depth(b));
+        AOB_TRY(trace_range(b, (int32_t)i, 0, UINT64_MAX));
+        AOB_HIP(hipEventRecord(b->ev[6], s));
+        AOB_TRY(resolve_material(b, (int32_t)i));
+        AOB_HIP(hipEventRecord(b->ev[7], s));
+        AOB_HIP(hipStreamSynchronize(s));
+        float a = 0.f, c = 0.f, d = 0.f;
+        hipEventElapsedTime(&a, b->ev[4], b->ev[5]);
+        hipEventElapsedTime(&c, b->ev_trace[0], b->ev_trace[1]);
+        hipEventElapsedTime(&d, b->ev[6], b->ev[7]);
+        ms_r += a; ms_t += c; ms_p += d;
+    }
+    AOB_HIP(hipStreamSynchronize(s));
+    b->stats.ms_rasterize = ms_r; b->stats.ms_trace = ms_t; b->stats.ms_resolve = ms_p;
+    return AOB_OK;
+}
+
+int aob_bake_sync(AobBake* b)
+{
+    AOB_TRY(check_bake(b, 0, false));
+    AOB_HIP(hipStreamSynchronize(b->stream));
+    return AOB_OK;
+}
+
+int aob_bake_get_stats(AobBake* b, AobStats* stats)
+{
+    AOB_TRY(check_bake(b, 0, false));
+    if (!stats) { set_error("stats is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
+    AOB_TRY(ensure_depth(b));
+    if (b->bvh_timed) { float ms = 0.f; hipEventElapsedTime(&ms, b->ev[2], b->ev[3]); b->stats.ms_bvh_build = ms; }
+    b->stats.triangle_count = b->triangle_count;
+    b->stats.node_count = b->node_count;
+    b->stats.bvh_depth = b->bvh_depth;
+    uint64_t surfels = 0;
+    for (auto& m : b->materials) surfels += m.surfel_count;
+    b->stats.surfel_count = surfels;
+    b->stats.ray_count = surfels * (uint64_t)b->opt.sample_count;
+    b->stats.ms_total_device = b->stats.ms_bvh_build + b->stats.ms_rasterize + b->stats.ms_trace + b->stats.ms_resolve;
+    *stats = b->stats;
+    return AOB_OK;
+}
+
+int aob_bake_node_count(AobBake* b, uint64_t* count)
+{
+    AOB_TRY(check_bake(b, 0, false));
+    if (!count) { set_error("count is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
+    *count = b->node_count;
+    return AOB_OK;
+}
+
+int aob_bake_copy_nodes(AobBake* b, AobBvhNode* dst, uint64_t capacity)
+{
+    AOB_TRY(check_bake(b, 0, false));
+    if (capacity < b->node_count || (!dst && b->node_count)) { set_error("node buffer too small"); return AOB_ERR_INVALID_ARGUMENT; }
+    if (b->node_count) AOB_HIP(hipMemcpyAsync(dst, b->nodes, sizeof(AobBvhNode) * b->node_count, hipMemcpyDeviceToHost, b->stream));
+    AOB_HIP(hipStreamSynchronize(b->stream));
+    return AOB_OK;
+}
+
+int aob_bake_surfel_count(AobBake* b, int32_t material, uint64_t* count)
+{
+    AOB_TRY(check_bake(b, material, true));
+    if (!count) { set_error("count is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
+    *count = b->materials[material].surfel_count;
+    return AOB_OK;
+}
+
+int aob_bake_copy_surfels(AobBake* b, int32_t material, AobSurfel* dst, uint64_t capacity)
+{
+    AOB_TRY(check_bake(b, material, true));
+    DeviceMaterial& m = b->materials[material];
+    if (capacity < m.surfel_count || (!dst && m.surfel_count)) { set_error("surfel buffer too small"); return AOB_ERR_INVALID_ARGUMENT; }
+    if (m.surfel_count) AOB_HIP(hipMemcpyAsync(dst, m.surfels, sizeof(AobSurfel) * m.surfel_count, hipMemcpyDeviceToHost, b->stream));
+    AOB_HIP(hipStreamSynchronize(b->stream));
+    return AOB_OK;
+}
+
+int aob_bake_copy_results(AobBake* b, int32_t material, AobResult* dst, uint64_t capacity)
+{
+    AOB_TRY(check_bake(b, material, true));
+    DeviceMaterial& m = b->materials[material];
+    const uint64_t cells = (uint64_t)m.width * m.height;
+    if (capacity < cells || !dst) { set_error("result buffer too small"); return AOB_ERR_INVALID_ARGUMENT; }
+    AOB_HIP(hipMemcpyAsync(dst, m.results, sizeof(AobResult) * cells, hipMemcpyDeviceToHost, b->stream));
+    AOB_HIP(hipStreamSynchronize(b->stream));
+    return AOB_OK;
+}
+
+int aob_bake_results_device_ptr(AobBake* b, int32_t material, void** ptr, uint64_t* bytes)
+{
+    AOB_TRY(check_bake(b, material, true));
+    DeviceMaterial& m = b->materials[material];
+    if (ptr) *ptr = m.results;
+    if (bytes) *bytes = sizeof(AobResult) * (uint64_t)m.width * m.height;
+    return AOB_OK;
+}
+
+int aob_bake_image_device_ptr(AobBake* b, int32_t material, void** ptr, uint64_t* bytes)
+{
+    AOB_TRY(check_bake(b, material, true));
+    DeviceMaterial& m = b->materials[material];
+    if (ptr) *ptr = m.image;
+    if (bytes) *bytes = (uint64_t)m.width * m.height * m.channels * m.bytes_per_channel;
+    return AOB_OK;
+}
+
+int aob_bake_stream(AobBake* b, void** stream)
+{
+    AOB_TRY(check_bake(b, 0, false));
+    if (stream) *stream = (void*)b->stream;
+    return AOB_OK;
+}
+
+int aob_bake_last_trace_ms(AobBake* b, float* ms)
+{
+    AOB_TRY(check_bake(b, 0, false));
+    if (!ms) { set_error("ms is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
+    if (!b->trace_timed) { set_error("no trace has been launched"); return AOB_ERR_INVALID_ARGUMENT; }
+    AOB_HIP(hipEventSynchronize(b->ev_trace[1]));
+    AOB_HIP(hipEventElapsedTime(ms, b->ev_trace[0], b->ev_trace[1]));
+    return AOB_OK;
+}
+
+// BakeEngine::Bake (BakeEngine.cpp:335-751) end to end
+int aob_bake(const AobSceneDesc* scene, const AobOptions* options, AobStats* stats)
+{
+    AobBake* b = nullptr;
+    AOB_TRY(aob_bake_create(scene, options, &b));
+    int rc = aob_bake_run_device(b);
+    if (rc == AOB_OK) {
+        hipEventRecord(b->ev[0], b->stream);
+        for (size_t i = 0; i < b->materials.size() && rc == AOB_OK; i++)
+            if (b->materials[i].host_data) rc = aob_bake_download(b, (int32_t)i, nullptr, 0);
+        hipEventRecord(b->ev[1], b->stream);
+        hipStreamSynchronize(b->stream);
+        float ms = 0.f; hipEventElapsedTime(&ms, b->ev[0], b->ev[1]);
+        b->stats.ms_download = ms;
+    }
+    if (rc == AOB_OK && stats) rc = aob_bake_get_stats(b, stats);
+    aob_bake_destroy(b);
+    return rc;
+}
+
+} // extern "C"

@@ -1,0 +1,307 @@
+// bvh_build.hip — world-space triangles + LBVH build on the GPU (gfx950).
+//
+// Replaces what RadeonRays does inside CreateMesh/SetTransform/AttachShape/
+// Commit (reference BakeEngine.cpp:370-400).  The algorithm is the one of the
+// reference stack's own GPU builder, kernels/CL/build_hlbvh.cl (Morton codes
+// :69-125, Karras span/split with index tie-break :131-261, bottom-up refit
+// with atomic flags :264-314), with 63-bit instead of 30-bit codes, emitted
+// into the 64-byte node layout of kernels/CL/intersect_bvh2_lds.cl:40-52
+// (inner: two child boxes + child addresses; leaf: the triangle, inlined).
+//
+// All kernels are HBM-streaming: one thread per primitive / node, 16-byte
+// coalesced loads and stores where the record allows it.
+#include "aob_internal.h"
+#include "aob_math.h"
+
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+namespace aob {
+
+static constexpr int kBlock = 256;
+
+// ---- order-preserving float <-> uint encoding for atomicMin/Max on bounds ----
+__device__ __forceinline__ uint32_t enc_float(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dec_float(uint32_t e)
+{
+    uint32_t u = (e & 0x80000000u) ? (e & 0x7fffffffu) : ~e;
+    return __uint_as_float(u);
+}
+
+__global__ void k_init_scene_bounds(uint32_t* enc)
+{
+    if (threadIdx.x < 3) enc[threadIdx.x] = 0xffffffffu;        // min slots
+    else if (threadIdx.x < 6) enc[threadIdx.x] = 0u;            // max slots
+}
+
+struct MeshXform { float m[16]; };
+
+// RasterizeVertexShader.hlsl:32 worldpos = mul(float4(pos,1), model), row vector.
+__device__ __forceinline__ f3 transform_point(const MeshXform& x, const float* p)
+{
+    f3 r;
+    float t;
+    t = p[0] * x.m[0]; t = fmaf(p[1], x.m[4], t); t = fmaf(p[2], x.m[8], t);  r.x = t + x.m[12];
+    t = p[0] * x.m[1]; t = fmaf(p[1], x.m[5], t); t = fmaf(p[2], x.m[9], t);  r.y = t + x.m[13];
+    t = p[0] * x.m[2]; t = fmaf(p[1], x.m[6], t); t = fmaf(p[2], x.m[10], t); r.z = t + x.m[14];
+    return r;
+}
+
+// One thread per triangle of one mesh: world-space vertices (what RadeonRays holds
+// after SetTransform), primitive box, and a block-reduced scene box.
+__global__ __launch_bounds__(kBlock)
+void k_world_triangles(const float* __restrict__ positions, const uint32_t* __restrict__ indices,
+                       uint32_t ntri, MeshXform xf, uint32_t shape_id,
+                       float4* __restrict__ tri_verts, Box* __restrict__ prim_bounds,
+                       uint32_t* __restrict__ scene_enc)
+{
+    __shared__ float red[6][kBlock / 64];
+    uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+    if (t < ntri) {
+        f3 v[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) v[c] = transform_point(xf, positions + 3ull * indices[3ull * t + c]);
+        tri_verts[3ull * t + 0] = make_float4(v[0].x, v[0].y, v[0].z, __uint_as_float(shape_id));
+        tri_verts[3ull * t + 1] = make_float4(v[1].x, v[1].y, v[1].z, __uint_as_float(t));
+        tri_verts[3ull * t + 2] = make_float4(v[2].x, v[2].y, v[2].z, 0.0f);
+        mn[0] = fminf(fminf(v[0].x, v[1].x), v[2].x); mx[0] = fmaxf(fmaxf(v[0].x, v[1].x), v[2].x);
+        mn[1] = fminf(fminf(v[0].y, v[1].y), v[2].y); mx[1] = fmaxf(fmaxf(v[0].y, v[1].y), v[2].y);
+        mn[2] = fminf(fminf(v[0].z, v[1].z), v[2].z); mx[2] = fmaxf(fmaxf(v[0].z, v[1].z), v[2].z);
+        Box b;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { b.pmin[k] = mn[k]; b.pmax[k] = mx[k]; }
+        prim_bounds[t] = b;
+    }
+    // wave reduce, then one set of atomics per block
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[k] = fminf(mn[k], __shfl_xor(mn[k], off));
+            mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off));
+        }
+    }
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { red[k][wave] = mn[k]; red[3 + k][wave] = mx[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        int k = threadIdx.x;
+        float v = red[k][0];
+        for (int w = 1; w < kBlock / 64; w++) v = k < 3 ? fminf(v, red[k][w]) : fmaxf(v, red[k][w]);
+        if (k < 3) atomicMin(&scene_enc[k], enc_float(v));
+        else atomicMax(&scene_enc[k], enc_float(v));
+    }
+}
+
+__device__ __forceinline__ uint64_t expand21(uint32_t v)
+{
+    uint64_t x = v & 0x1fffffu;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+__device__ __forceinline__ uint32_t morton_axis(float c, float smin, float extent)
+{
+    // build_hlbvh.cl:122 then :71-73, at 21 bits per axis
+    float n = extent > 0.0f ? (c - smin) / extent : 0.0f;
+    float q = fminf(fmaxf(n * 2097152.0f, 0.0f), 2097151.0f);
+    return (uint32_t)q;
+}
+
+__global__ __launch_bounds__(kBlock)
+void k_morton(const Box* __restrict__ prim_bounds, uint32_t n, const uint32_t* __restrict__ scene_enc,
+              uint64_t* __restrict__ codes, uint32_t* __restrict__ idx)
+{
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    Box b = prim_bounds[i];
+    uint32_t q[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float smin = dec_float(scene_enc[k]), smax = dec_float(scene_enc[3 + k]);
+        float c = (b.pmax[k] + b.pmin[k]) * 0.5f;                 // build_hlbvh.cl:118
+        q[k] = morton_axis(c, smin, smax - smin);
+    }
+    codes[i] = (expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]);
+    idx[i] = i;
+}
+
+// build_hlbvh.cl:131-150 with 64-bit codes
+__device__ __forceinline__ int lbvh_delta(const uint64_t* __restrict__ codes, int64_t n, int64_t i1, int64_t i2)
+{
+    int64_t left = i1 < i2 ? i1 : i2, right = i1 < i2 ? i2 : i1;
+    if (left < 0 || right >= n) return -1;
+    uint64_t lc = codes[left], rc = codes[right];
+    if (lc != rc) return __clzll((long long)(lc ^ rc));
+    return 64 + __clz((int)((uint32_t)left ^ (uint32_t)right));
+}
+
+// build_hlbvh.cl:152-261: one thread per internal node
+__global__ __launch_bounds__(kBlock)
+void k_hierarchy(const uint64_t* __restrict__ codes, uint32_t n,
+                 uint32_t* __restrict__ child_left, uint32_t* __restrict__ child_right,
+                 uint32_t* __restrict__ parent)
+{
+    int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    int64_t N = n;
+    if (idx >= N - 1) return;
+    if (idx == 0) parent[0] = 0xffffffffu;
+    int dnext = lbvh_delta(codes, N, idx, idx + 1), dprev = lbvh_delta(codes, N, idx, idx - 1);
+    int d = dnext >= dprev ? 1 : -1;
+    int delta_min = lbvh_delta(codes, N, idx, idx - d);
+    int64_t lmax = 2;
+    while (lbvh_delta(codes, N, idx, idx + lmax * d) > delta_min) lmax *= 2;
+    int64_t l = 0, t = lmax;
+    do {
+        t /= 2;
+        if (lbvh_delta(codes, N, idx, idx + (l + t) * d) > delta_min) l += t;
+    } while (t > 1);
+    int64_t other = idx + l * d;
+    int64_t sx = idx < other ? idx : other, sy = idx < other ? other : idx;
+    int64_t lo = sx, hi = sy;
+    int num_identical = lbvh_delta(codes, N, lo, hi);
+    do {
+        int64_t ns = (hi + lo) / 2;
+        if (lbvh_delta(codes, N, lo, ns) > num_identical) lo = ns; else hi = ns;
+    } while (hi > lo + 1);
+    int64_t split = lo;
+    uint32_t c1 = (split == sx) ? (uint32_t)(N - 1 + split) : (uint32_t)split;
+    uint32_t c2 = (split + 1 == sy) ? (uint32_t)(N - 1 + split + 1) : (uint32_t)(split + 1);
+    child_left[idx] = c1; child_right[idx] = c2;
+    parent[c1] = (uint32_t)idx; parent[c2] = (uint32_t)idx;
+}
+
+__global__ __launch_bounds__(kBlock)
+void k_leaf_bounds(const Box* __restrict__ prim_bounds, const uint32_t* __restrict__ sorted_idx, uint32_t n,
+                   Box* __restrict__ node_bounds)
+{
+    uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p < n) node_bounds[(uint64_t)n - 1 + p] = prim_bounds[sorted_idx[p]];
+}
+
+// build_hlbvh.cl:264-314.  The second thread to arrive at a node reads both child boxes,
+// one of which another CU wrote: the writer's stores are released and this reader's L1
+// invalidated by the agent-scope fences (__threadfence = buffer_wbl2 sc1 + buffer_inv sc1)
+// around the flag atomic, as MI355X_MICROARCH.md §inter-workgroup visibility requires.
+__global__ __launch_bounds__(kBlock)
+void k_refit(uint32_t n, const uint32_t* __restrict__ parent, const uint32_t* __restrict__ child_left,
+             const uint32_t* __restrict__ child_right, Box* node_bounds, uint32_t* flags,
+             uint32_t* __restrict__ depth_max)
+{
+    uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t depth = 0;
+    if (p < n) {
+        uint32_t idx = n - 1 + p;
+        // depth of this leaf (root = 0)
+        for (uint32_t a = idx; parent[a] != 0xffffffffu; a = parent[a]) depth++;
+        do {
+            idx = parent[idx];
+            __threadfence();
+            if (atomicAdd(&flags[idx], 1u) == 0u) break;
+            __threadfence();
+            const volatile Box* bl = &node_bounds[child_left[idx]];
+            const volatile Box* br = &node_bounds[child_right[idx]];
+            Box u;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                u.pmin[k] = fminf(bl->pmin[k], br->pmin[k]);
+                u.pmax[k] = fmaxf(bl->pmax[k], br->pmax[k]);
+            }
+            node_bounds[idx] = u;
+        } while (idx != 0);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) depth = max(depth, (uint32_t)__shfl_xor((int)depth, off));
+    if ((threadIdx.x & 63) == 0 && depth) atomicMax(depth_max, depth);
+}
+
+// One thread per node: inner nodes [0, n-1), leaves [n-1, 2n-1).  64-byte records,
+// written as four float4 stores.
+__global__ __launch_bounds__(kBlock)
+void k_emit_nodes(uint32_t n, const uint32_t* __restrict__ child_left, const uint32_t* __restrict__ child_right,
+                  const Box* __restrict__ node_bounds, const uint32_t* __restrict__ sorted_idx,
+                  const float4* __restrict__ tri_verts, float4* __restrict__ nodes)
+{
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t total = n == 1 ? 1 : 2 * n - 1;
+    if (i >= total) return;
+    float4* out = nodes + 4ull * i;
+    if (n > 1 && i < n - 1) {
+        uint32_t l = child_left[i], r = child_right[i];
+        Box bl = node_bounds[l], br = node_bounds[r];
+        out[0] = make_float4(bl.pmin[0], bl.pmin[1], bl.pmin[2], __uint_as_float(l));
+        out[1] = make_float4(bl.pmax[0], bl.pmax[1], bl.pmax[2], __uint_as_float(0u));
+        out[2] = make_float4(br.pmin[0], br.pmin[1], br.pmin[2], __uint_as_float(r));
+        out[3] = make_float4(br.pmax[0], br.pmax[1], br.pmax[2], __uint_as_float(0u));
+    } else {
+        uint32_t p = n == 1 ? 0 : i - (n - 1);
+        uint32_t t = sorted_idx[p];
+        float4 v0 = tri_verts[3ull * t], v1 = tri_verts[3ull * t + 1], v2 = tri_verts[3ull * t + 2];
+        out[0] = make_float4(v0.x, v0.y, v0.z, __uint_as_float(0xffffffffu));   // addr_left = INVALID
+        out[1] = make_float4(v1.x, v1.y, v1.z, v0.w);                            // shape id
+        out[2] = make_float4(v2.x, v2.y, v2.z, __uint_as_float(0u));
+        out[3] = make_float4(0.0f, 0.0f, 0.0f, v1.w);                            // prim id
+    }
+}
+
+// prim ids written by k_world_triangles are mesh-local already (t), shape ids start at 1
+// (RadeonRays/radeon_rays.h:238).
+
+static inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
+
+int build_bvh(AobBake* b)
+{
+    hipStream_t s = b->stream;
+    const uint64_t n = b->triangle_count;
+    b->node_count = 0; b->bvh_depth = 0;
+    if (n == 0) { b->bvh_built = true; return AOB_OK; }
+    if (n > 0x7fffffffull) { set_error("too many triangles (%llu)", (unsigned long long)n); return AOB_ERR_UNSUPPORTED; }
+
+    hipLaunchKernelGGL(k_init_scene_bounds, dim3(1), dim3(64), 0, s, b->scene_bounds_enc);
+    for (size_t mi = 0; mi < b->meshes.size(); mi++) {
+        const DeviceMesh& m = b->meshes[mi];
+        if (!m.triangle_count) continue;
+        MeshXform xf;
+        for (int k = 0; k < 16; k++) xf.m[k] = m.model[k];
+        hipLaunchKernelGGL(k_world_triangles, dim3(blocks_for(m.triangle_count)), dim3(kBlock), 0, s,
+                           m.positions, m.indices, m.triangle_count, xf, (uint32_t)mi + 1,
+                           b->tri_verts + 3ull * m.triangle_offset, b->prim_bounds + m.triangle_offset,
+                           b->scene_bounds_enc);
+    }
+    hipLaunchKernelGGL(k_morton, dim3(blocks_for(n)), dim3(kBlock), 0, s, b->prim_bounds, (uint32_t)n,
+                       b->scene_bounds_enc, b->codes[0], b->prim_idx[0]);
+    // stable LSD radix sort of (code, index) pairs: equal codes stay in index order
+    size_t temp = b->sort_temp_bytes;
+    AOB_HIP(rocprim::radix_sort_pairs(b->sort_temp, temp, b->codes[0], b->codes[1], b->prim_idx[0], b->prim_idx[1],
+                                      (size_t)n, 0u, 63u, s));
+    if (n > 1) {
+        AOB_HIP(hipMemsetAsync(b->refit_flags, 0, sizeof(uint32_t) * (n - 1), s));
+        AOB_HIP(hipMemsetAsync(b->depth_dev, 0, sizeof(uint32_t), s));
+        hipLaunchKernelGGL(k_hierarchy, dim3(blocks_for(n - 1)), dim3(kBlock), 0, s, b->codes[1], (uint32_t)n,
+                           b->child_left, b->child_right, b->parent);
+        hipLaunchKernelGGL(k_leaf_bounds, dim3(blocks_for(n)), dim3(kBlock), 0, s, b->prim_bounds, b->prim_idx[1],
+                           (uint32_t)n, b->node_bounds);
+        hipLaunchKernelGGL(k_refit, dim3(blocks_for(n)), dim3(kBlock), 0, s, (uint32_t)n, b->parent, b->child_left,
+                           b->child_right, b->node_bounds, b->refit_flags, b->depth_dev);
+    }
+    b->node_count = n == 1 ? 1 : 2 * n - 1;
+    hipLaunchKernelGGL(k_emit_nodes, dim3(blocks_for(b->node_count)), dim3(kBlock), 0, s, (uint32_t)n, b->child_left,
+                       b->child_right, b->node_bounds, b->prim_idx[1], b->tri_verts, (float4*)b->nodes);
+    AOB_HIP(hipGetLastError());
+    b->bvh_built = true;
+    return AOB_OK;
+}
+
+} // namespace aob

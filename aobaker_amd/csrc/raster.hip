@@ -1,0 +1,274 @@
+// raster.hip — UV-space surfel rasterisation + texel extraction on the GPU (gfx950).
+//
+// Replaces, per material and per section (reference BakeEngine.cpp:509-588):
+//   * RasterizeVertexShader.hlsl:26-35 / RasterizePixelShader.hlsl:17-23 drawn
+//     once per stencil layer (LayerDSS, BakeEngine.cpp:130-140,539-545),
+//   * three full-surface read-backs per layer (:548-564), and
+//   * the single-threaded CPU extraction loop (:566-588).
+// The layer peel keeps, for every covered texel, exactly the LAST fragment
+// drawn, so one pass suffices here: k_cover takes the
+// atomicMax of (triangle index + 1) per texel, an exclusive scan compacts the
+// covered texels in the reference's row-major order, and k_emit_surfels
+// interpolates the winner's attributes straight into the 40-byte
+// TexelRasterization record (BakeEngine.cpp:98-116).
+//
+// Coverage is exact integer arithmetic on 24.8 fixed-point coordinates with
+// the D3D11 top-left rule, so GPU and oracle agree texel for texel.
+#include "aob_internal.h"
+#include "aob_math.h"
+
+namespace aob {
+
+static constexpr int kBlock = 256;
+static constexpr int kScanItems = 8;                       // texels per thread in the scan kernels
+static constexpr int kScanTile = kBlock * kScanItems;      // 2048 texels per block
+static constexpr float kCoordLimit = 67108864.0f;          // 2^26 sub-pixels
+
+struct MeshXform { float m[16]; };
+
+__device__ __forceinline__ int64_t edge_fn(int64_t ax, int64_t ay, int64_t bx, int64_t by, int64_t px, int64_t py)
+{
+    return (bx - ax) * (py - ay) - (by - ay) * (px - ax);
+}
+__device__ __forceinline__ bool edge_top_left(int64_t ax, int64_t ay, int64_t bx, int64_t by)
+{
+    int64_t dx = bx - ax, dy = by - ay;
+    return dy < 0 || (dy == 0 && dx > 0);
+}
+
+// RasterizeVertexShader.hlsl:29 + viewport transform: pixel = (u*W, v*H); 8 sub-pixel bits.
+__device__ __forceinline__ bool snap_uv(const float* uv, int32_t W, int32_t H, int64_t& X, int64_t& Y)
+{
+    float sx = uv[0] * (float)W * 256.0f, sy = uv[1] * (float)H * 256.0f;
+    if (!(fabsf(sx) < kCoordLimit) || !(fabsf(sy) < kCoordLimit)) return false;
+    X = (int64_t)rintf(sx); Y = (int64_t)rintf(sy);
+    return true;
+}
+
+// One wavefront per triangle; the 64 lanes stride over the texels of its bounding box.
+__global__ __launch_bounds__(kBlock)
+void k_cover(const float* __restrict__ uvs, const uint32_t* __restrict__ indices, uint32_t ntri,
+             int32_t W, int32_t H, uint32_t* __restrict__ cover)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t t = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (t >= ntri) return;
+    int64_t X[3], Y[3];
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < 3; c++) ok = snap_uv(uvs + 2ull * indices[3ull * t + c], W, H, X[c], Y[c]) && ok;
+    if (!ok) return;
+    int64_t area = edge_fn(X[0], Y[0], X[1], Y[1], X[2], Y[2]);
+    if (area == 0) return;
+    if (area < 0) { int64_t tx = X[1], ty = Y[1]; X[1] = X[2]; Y[1] = Y[2]; X[2] = tx; Y[2] = ty; }
+    int64_t minx = min(min(X[0], X[1]), X[2]), maxx = max(max(X[0], X[1]), X[2]);
+    int64_t miny = min(min(Y[0], Y[1]), Y[2]), maxy = max(max(Y[0], Y[1]), Y[2]);
+    int64_t px0 = max((minx - 128 + 255) >> 8, (int64_t)0), px1 = min((maxx - 128) >> 8, (int64_t)W - 1);
+    int64_t py0 = max((miny - 128 + 255) >> 8, (int64_t)0), py1 = min((maxy - 128) >> 8, (int64_t)H - 1);
+    if (px1 < px0 || py1 < py0) return;
+    const int64_t b0 = edge_top_left(X[0], Y[0], X[1], Y[1]) ? 0 : -1;
+    const int64_t b1 = edge_top_left(X[1], Y[1], X[2], Y[2]) ? 0 : -1;
+    const int64_t b2 = edge_top_left(X[2], Y[2], X[0], Y[0]) ? 0 : -1;
+    const uint64_t bw = (uint64_t)(px1 - px0 + 1), bh = (uint64_t)(py1 - py0 + 1);
+    const uint64_t npix = bw * bh;
+    for (uint64_t p = lane; p < npix; p += 64) {
+        int64_t py = py0 + (int64_t)(p / bw), px = px0 + (int64_t)(p % bw);
+        int64_t cx = px * 256 + 128, cy = py * 256 + 128;
+        if (edge_fn(X[0], Y[0], X[1], Y[1], cx, cy) + b0 < 0) continue;
+        if (edge_fn(X[1], Y[1], X[2], Y[2], cx, cy) + b1 < 0) continue;
+        if (edge_fn(X[2], Y[2], X[0], Y[0], cx, cy) + b2 < 0) continue;
+        atomicMax(&cover[(uint64_t)py * W + px], t + 1);       // last fragment drawn wins
+    }
+}
+
+// ---- row-major exclusive scan of (cover != 0) -----------------------------------
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total_out)
+{
+    __shared__ uint32_t wave_sums[kBlock / 64];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t y = __shfl_up(inc, off);
+        if (lane >= (uint32_t)off) inc += y;
+    }
+    if (lane == 63) wave_sums[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; w++) { if ((uint32_t)w < wave) base += wave_sums[w]; total += wave_sums[w]; }
+    __syncthreads();
+    *total_out = total;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(kBlock)
+void k_scan_count(const uint32_t* __restrict__ cover, uint64_t cells, uint32_t* __restrict__ block_sums)
+{
+    uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; k++) if (base + k < cells) c += cover[base + k] != 0u;
+    uint32_t total;
+    block_exclusive_scan(c, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// single block: exclusive scan of the per-tile counts, total into block_sums[nblocks]
+__global__ __launch_bounds__(kBlock)
+void k_scan_partials(uint32_t* block_sums, uint32_t nblocks)
+{
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nblocks; base += kBlock) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = i < nblocks ? block_sums[i] : 0u;
+        uint32_t total;
+        uint32_t ex = block_exclusive_scan(v, &total);
+        uint32_t carry = carry_s;
+        if (i < nblocks) block_sums[i] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_sums[nblocks] = carry_s;
+}
+
+// RasterizeVertexShader.hlsl:30-32 (row vector times model matrix; the normal uses the model
+// matrix itself and is normalised per vertex, not per fragment)
+__device__ __forceinline__ f3 xform(const MeshXform& x, const float* p, bool point)
+{
+    f3 r; float t;
+    t = p[0] * x.m[0]; t = fmaf(p[1], x.m[4], t); t = fmaf(p[2], x.m[8], t);  r.x = point ? t + x.m[12] : t;
+    t = p[0] * x.m[1]; t = fmaf(p[1], x.m[5], t); t = fmaf(p[2], x.m[9], t);  r.y = point ? t + x.m[13] : t;
+    t = p[0] * x.m[2]; t = fmaf(p[1], x.m[6], t); t = fmaf(p[2], x.m[10], t); r.z = point ? t + x.m[14] : t;
+    return r;
+}
+
+struct RasterVertex { f3 wpos, wnrm; float u, v; };
+
+__global__ __launch_bounds__(kBlock)
+void k_emit_surfels(const uint32_t* __restrict__ cover, uint64_t cells, const uint32_t* __restrict__ block_offsets,
+                    const float* __restrict__ positions, const float* __restrict__ normals,
+                    const float* __restrict__ uvs, const uint32_t* __restrict__ indices,
+                    MeshXform xf, int32_t W, int32_t H, int fp16_mode,
+                    AobSurfel* __restrict__ surfels, uint32_t* __restrict__ section_index)
+{
+    uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+    uint32_t cv[kScanItems];
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; k++) { cv[k] = base + k < cells ? cover[base + k] : 0u; c += cv[k] != 0u; }
+    uint32_t total;
+    uint32_t local = block_exclusive_scan(c, &total) + block_offsets[blockIdx.x];
+    if (!c) return;
+#pragma unroll 1
+    for (int k = 0; k < kScanItems; k++) {
+        if (!cv[k]) continue;
+        const uint32_t t = cv[k] - 1;
+        const uint64_t cell = base + k;
+        const int32_t py = (int32_t)(cell / (uint64_t)W), px = (int32_t)(cell % (uint64_t)W);
+        RasterVertex rv[3];
+        int64_t X[3], Y[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            uint32_t vi = indices[3ull * t + j];
+            const float* uv = uvs + 2ull * vi;
+            snap_uv(uv, W, H, X[j], Y[j]);
+            rv[j].wpos = xform(xf, positions + 3ull * vi, true);
+            rv[j].wnrm = normalize(xform(xf, normals + 3ull * vi, false));
+            rv[j].u = uv[0]; rv[j].v = uv[1];
+        }
+        int64_t area = edge_fn(X[0], Y[0], X[1], Y[1], X[2], Y[2]);
+        if (area < 0) {
+            int64_t tx = X[1], ty = Y[1]; X[1] = X[2]; Y[1] = Y[2]; X[2] = tx; Y[2] = ty;
+            RasterVertex tv = rv[1]; rv[1] = rv[2]; rv[2] = tv;
+            area = -area;
+        }
+        const int64_t cx = (int64_t)px * 256 + 128, cy = (int64_t)py * 256 + 128;
+        const float fa = (float)area;
+        const float l0 = (float)edge_fn(X[1], Y[1], X[2], Y[2], cx, cy) / fa;
+        const float l1 = (float)edge_fn(X[2], Y[2], X[0], Y[0], cx, cy) / fa;
+        const float l2 = (float)edge_fn(X[0], Y[0], X[1], Y[1], cx, cy) / fa;
+#define AOB_LERP(f) fmaf(l2, rv[2].f, fmaf(l1, rv[1].f, l0 * rv[0].f))
+        AobSurfel s;
+        s.texel_x = px; s.texel_y = py;
+        s.position[0] = AOB_LERP(wpos.x); s.position[1] = AOB_LERP(wpos.y); s.position[2] = AOB_LERP(wpos.z);
+        // RasterizePixelShader.hlsl:20-21: U rides with the fp32 position; the normal and V pass
+        // through the RGBA16F target (BakeEngine.cpp:446,584-585)
+        s.texcoord[0] = AOB_LERP(u);
+        s.texcoord[1] = quantise_fp16(AOB_LERP(v), fp16_mode);
+        s.normal[0] = quantise_fp16(AOB_LERP(wnrm.x), fp16_mode);
+        s.normal[1] = quantise_fp16(AOB_LERP(wnrm.y), fp16_mode);
+        s.normal[2] = quantise_fp16(AOB_LERP(wnrm.z), fp16_mode);
+#undef AOB_LERP
+        surfels[local] = s;
+        section_index[local] = local;
+        local++;
+    }
+}
+
+static int ensure_surfel_capacity(AobBake* b, DeviceMaterial& m, uint64_t need)
+{
+    if (need <= m.surfel_capacity) return AOB_OK;
+    uint64_t cap = m.surfel_capacity ? m.surfel_capacity : (uint64_t)m.width * m.height;
+    while (cap < need) cap *= 2;
+    AobSurfel* ns = nullptr; uint32_t* ni = nullptr;
+    AOB_HIP(hipMalloc((void**)&ns, sizeof(AobSurfel) * cap));
+    AOB_HIP(hipMalloc((void**)&ni, sizeof(uint32_t) * cap));
+    if (m.surfel_count) {
+        AOB_HIP(hipMemcpyAsync(ns, m.surfels, sizeof(AobSurfel) * m.surfel_count, hipMemcpyDeviceToDevice, b->stream));
+        AOB_HIP(hipMemcpyAsync(ni, m.section_index, sizeof(uint32_t) * m.surfel_count, hipMemcpyDeviceToDevice, b->stream));
+        AOB_HIP(hipStreamSynchronize(b->stream));
+    }
+    if (m.surfels) AOB_HIP(hipFree(m.surfels));
+    if (m.section_index) AOB_HIP(hipFree(m.section_index));
+    m.surfels = ns; m.section_index = ni; m.surfel_capacity = cap;
+    return AOB_OK;
+}
+
+int rasterize_material(AobBake* b, int32_t material)
+{
+    DeviceMaterial& m = b->materials[material];
+    hipStream_t s = b->stream;
+    const uint64_t cells = (uint64_t)m.width * m.height;
+    m.surfel_count = 0;
+    m.section_offsets.clear(); m.section_mesh.clear();
+    m.section_offsets.push_back(0);
+    AOB_HIP(hipMemsetAsync(m.results, 0, sizeof(AobResult) * cells, s));
+    const uint32_t nblocks = m.scan_blocks;
+    for (size_t mi = 0; mi < b->meshes.size(); mi++) {
+        const DeviceMesh& mesh = b->meshes[mi];
+        if (mesh.material != material) continue;                       // BakeEngine.cpp:523
+        AOB_HIP(hipMemsetAsync(m.cover, 0, sizeof(uint32_t) * cells, s));
+        if (mesh.triangle_count) {
+            uint32_t grid = (mesh.triangle_count + (kBlock / 64) - 1) / (kBlock / 64);
+            hipLaunchKernelGGL(k_cover, dim3(grid), dim3(kBlock), 0, s, mesh.uvs, mesh.indices, mesh.triangle_count,
+                               m.width, m.height, m.cover);
+        }
+        hipLaunchKernelGGL(k_scan_count, dim3(nblocks), dim3(kBlock), 0, s, m.cover, cells, m.block_sums);
+        hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(kBlock), 0, s, m.block_sums, nblocks);
+        // the section's surfel count decides the launch geometry of everything downstream
+        AOB_HIP(hipMemcpyAsync(b->pinned, m.block_sums + nblocks, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        AOB_HIP(hipStreamSynchronize(s));
+        const uint64_t count = b->pinned[0];
+        AOB_TRY(ensure_surfel_capacity(b, m, m.surfel_count + count));
+        if (count) {
+            MeshXform xf;
+            for (int k = 0; k < 16; k++) xf.m[k] = mesh.model[k];
+            hipLaunchKernelGGL(k_emit_surfels, dim3(nblocks), dim3(kBlock), 0, s, m.cover, cells, m.block_sums,
+                               mesh.positions, mesh.normals, mesh.uvs, mesh.indices, xf, m.width, m.height,
+                               b->opt.normal_fp16, m.surfels + m.surfel_count, m.section_index + m.surfel_count);
+        }
+        m.surfel_count += count;
+        m.section_offsets.push_back(m.surfel_count);
+        m.section_mesh.push_back((uint32_t)mi);
+    }
+    AOB_HIP(hipGetLastError());
+    m.rasterized = true;
+    return AOB_OK;
+}
+
+} // namespace aob

@@ -1,0 +1,221 @@
+/*
+ * aobaker.h — C ABI of the MI355X-native ambient-occlusion bake path.
+ *
+ * This is the drop-in boundary.  The reference (epicabsol/aobaker) has no FFI
+ * layer of its own: its bake is the free function
+ *     namespace BakeEngine { void Init(); void Dispose(); void Bake(Scene*); }
+ * (reference BakeEngine.h:5-10, implementation BakeEngine.cpp:118-751).
+ * The entry points below are what a C++ shim for that function binds
+ * (include/BakeEngine.h + aobaker_amd/host/BakeEngine.cpp in this repo);
+ * every entry point names the piece of the reference it replaces.
+ *
+ * Plain C, plain pointers and sizes; no torch / HIP types in any signature.
+ * All functions return AOB_OK (0) or a negative AobStatus; the text of the
+ * last failure on the calling thread is available from aob_last_error().
+ */
+#ifndef AOBAKER_H
+#define AOBAKER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AOB_ABI_VERSION 1
+
+typedef enum AobStatus {
+    AOB_OK = 0,
+    AOB_ERR_INVALID_ARGUMENT = -1,
+    AOB_ERR_NOT_INITIALISED = -2,
+    AOB_ERR_DEVICE = -3,          /* a HIP call failed; see aob_last_error() */
+    AOB_ERR_OUT_OF_MEMORY = -4,
+    AOB_ERR_UNSUPPORTED = -5,
+    AOB_ERR_BVH_TOO_DEEP = -6
+} AobStatus;
+
+/* ---- options ------------------------------------------------------------
+ * Defaults (aob_default_options) are the reference's compile-time constants,
+ * BakeEngine.cpp:13-18: sampleCount=100, falloffDistance=1.25f,
+ * useAnyHit=true, rayChunkSize=0xFFFFFF, bleedDistance=5. */
+
+enum { AOB_SAMPLER_REFERENCE_COMPAT = 0,   /* BakeEngine.cpp:312-333, MSVC rand() table */
+       AOB_SAMPLER_COSINE = 1 };           /* counter-based stratified cosine hemisphere */
+enum { AOB_ACCUMULATE_QUANTISED = 0,       /* ProcessIntersectionsComputeShader.hlsl:87-90 */
+       AOB_ACCUMULATE_FLOAT = 1 };
+enum { AOB_FP16_OFF = 0,                   /* keep normal + V in fp32 */
+       AOB_FP16_RTZ = 1,                   /* through fp16, round toward zero */
+       AOB_FP16_RNE = 2 };                 /* through fp16, round to nearest even */
+
+typedef struct AobOptions {
+    int32_t  sample_count;        /* rays per surfel (reference sampleCount)              */
+    int32_t  sampler;             /* AOB_SAMPLER_*                                        */
+    uint32_t seed;                /* COSINE sampler only                                  */
+    int32_t  use_any_hit;         /* 1: binary occlusion; 0: t/falloff scoring            */
+    float    falloff_distance;    /* reference falloffDistance                            */
+    float    ray_tmax;            /* parametric max t (reference 1e6, GenerateRays:49)    */
+    float    ray_bias;            /* origin offset along the ray (reference 0.001, :47)   */
+    int32_t  bleed_distance;      /* reference bleedDistance                              */
+    int32_t  accumulate;          /* AOB_ACCUMULATE_*                                     */
+    int32_t  normal_fp16;         /* AOB_FP16_*: the RGBA16F NormalV target, :446         */
+    int32_t  ray_chunk_size;      /* reference rayChunkSize; bounds the compat table      */
+    int32_t  clamp_tmax_to_falloff; /* falloff mode: cast with tmax=min(tmax,falloff)     */
+    int32_t  reserved[4];
+} AobOptions;
+
+/* ---- scene description ----------------------------------------------------
+ * One AobMeshDesc per (BakeObject, Section) pair in the order the reference
+ * walks them (BakeEngine.cpp:370-398 and :509-523).  Vertex attributes are
+ * strided so a reference RenderVertex* (48 B: pos@0, normal@12, uv@24,
+ * Render/RenderMesh.h:13-19) can be passed as is. */
+typedef struct AobMeshDesc {
+    const void*     positions;        /* float[3] per vertex */
+    const void*     normals;          /* float[3] per vertex */
+    const void*     uvs;              /* float[2] per vertex */
+    uint32_t        position_stride;  /* bytes */
+    uint32_t        normal_stride;
+    uint32_t        uv_stride;
+    uint32_t        vertex_count;
+    const uint32_t* indices;          /* triangle list */
+    uint32_t        index_count;      /* multiple of 3 (a trailing partial triangle is ignored) */
+    int32_t         material;         /* index into AobSceneDesc::materials, or -1: occluder only */
+    float           model[16];        /* row-major, row-vector: world = [p 1] * model
+                                         (TransformObject.cpp:21-24, RasterizeVertexShader.hlsl:30-32) */
+} AobMeshDesc;
+
+/* The output side: BakeTexture's data contract (Scene/BakeTexture.cpp:7-67,
+ * write-back BakeEngine.cpp:705-709): row-major, top row first, tightly
+ * packed width*height*channels*bytes_per_channel bytes; AO in channel 0. */
+typedef struct AobMaterialDesc {
+    int32_t  width;
+    int32_t  height;
+    int32_t  channels;            /* 1,2,4 (1- and 2-byte) or 1..4 (4-byte) */
+    int32_t  bytes_per_channel;   /* 1: UNORM8, 2: fp16, 4: fp32 */
+    uint8_t* data;                /* host memory, written by aob_bake / aob_bake_download */
+} AobMaterialDesc;
+
+typedef struct AobSceneDesc {
+    const AobMeshDesc*     meshes;
+    uint32_t               mesh_count;
+    const AobMaterialDesc* materials;
+    uint32_t               material_count;
+} AobSceneDesc;
+
+typedef struct AobDeviceConfig {
+    int32_t device;               /* HIP device ordinal, -1 = current device */
+    int32_t reserved[7];
+} AobDeviceConfig;
+
+typedef struct AobStats {
+    uint64_t triangle_count;
+    uint64_t node_count;
+    uint64_t surfel_count;        /* covered texels summed over sections and materials */
+    uint64_t ray_count;           /* surfel_count * sample_count */
+    uint32_t bvh_depth;
+    uint32_t reserved0;
+    float ms_upload;
+    float ms_bvh_build;
+    float ms_rasterize;
+    float ms_trace;
+    float ms_resolve;
+    float ms_download;
+    float ms_total_device;        /* bvh_build + rasterize + trace + resolve */
+    float reserved1;
+} AobStats;
+
+/* ---- device records (layouts shared with the parity tests) ---------------- */
+
+/* 40 B, identical to the reference TexelRasterization (BakeEngine.cpp:98-116,
+ * GenerateRaysComputeShader.hlsl:1-8). */
+typedef struct AobSurfel {
+    int32_t texel_x, texel_y;
+    float   position[3];
+    float   texcoord[2];
+    float   normal[3];
+} AobSurfel;
+
+/* 64 B traversal node, the layout of the reference's bvh_node
+ * (kernels/CL/intersect_bvh2_lds.cl:40-52).  Inner: child boxes + child
+ * addresses; leaf (addr_left == 0xffffffff): the triangle, inlined. */
+typedef struct AobBvhNode {
+    float    lmin_or_v0[3];  uint32_t addr_left;
+    float    lmax_or_v1[3];  uint32_t shape_id;
+    float    rmin_or_v2[3];  uint32_t addr_right;
+    float    rmax[3];        uint32_t prim_id;
+} AobBvhNode;
+#define AOB_INVALID_ADDR 0xffffffffu
+
+/* 8 B per texel (ResultValue, BakeEngine.cpp:298-309); both fields are int32
+ * in QUANTISED mode and float32 in FLOAT mode. */
+typedef struct AobResult { uint32_t total_bits, weight_bits; } AobResult;
+
+/* ---- one-shot API --------------------------------------------------------- */
+
+/* Replaces BakeEngine::Init (BakeEngine.cpp:118-213): selects the device and
+ * creates the stream + persistent workspaces. */
+int aob_init(const AobDeviceConfig* config);
+/* Replaces BakeEngine::Dispose (BakeEngine.cpp:215-279). */
+void aob_shutdown(void);
+/* Fills `out` with the reference's constants (BakeEngine.cpp:13-18). */
+void aob_default_options(AobOptions* out);
+/* Replaces BakeEngine::Bake (BakeEngine.cpp:335-751): uploads the scene,
+ * builds the BVH, and for every material rasterises, traces, resolves,
+ * bleeds and writes materials[i].data. `stats` may be NULL. */
+int aob_bake(const AobSceneDesc* scene, const AobOptions* options, AobStats* stats);
+const char* aob_last_error(void);
+int aob_abi_version(void);
+
+/* ---- staged API ------------------------------------------------------------
+ * The same path cut at the reference's own stage boundaries (S1..S6 in
+ * BakeEngine.cpp), so that a caller can keep the scene resident in HBM,
+ * time stages, shard the surfel list over GPUs, and read back intermediate
+ * buffers for parity tests. */
+typedef struct AobBake AobBake;
+
+/* S1 upload: copies vertex/index data to HBM (BakeEngine.cpp:370-398). */
+int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBake** out);
+void aob_bake_destroy(AobBake* bake);
+/* S1 Commit(): world-space triangles + LBVH build (BakeEngine.cpp:400;
+ * kernels/CL/build_hlbvh.cl). */
+int aob_bake_build_bvh(AobBake* bake);
+/* S2 + S2': UV rasterisation, last-fragment-wins, row-major compaction into
+ * the surfel list of `material` (BakeEngine.cpp:531-588). */
+int aob_bake_rasterize(AobBake* bake, int32_t material);
+/* S3..S5 for surfels [begin,end) of the material's concatenated surfel list:
+ * ray generation, traversal, scoring, accumulation into the material's
+ * W*H result buffer (BakeEngine.cpp:598-675).  end = UINT64_MAX means all. */
+int aob_bake_trace(AobBake* bake, int32_t material, uint64_t begin, uint64_t end);
+/* S6: resolve + bleed into the device image (BakeEngine.cpp:688-704). */
+int aob_bake_resolve(AobBake* bake, int32_t material);
+/* S6 write-back: device image -> host (BakeEngine.cpp:705-709).
+ * dst == NULL writes to the AobMaterialDesc::data given at creation. */
+int aob_bake_download(AobBake* bake, int32_t material, void* dst, size_t dst_bytes);
+/* All device stages for all materials, no host transfers:
+ * build_bvh, then per material rasterize + trace(all) + resolve. */
+int aob_bake_run_device(AobBake* bake);
+int aob_bake_sync(AobBake* bake);
+int aob_bake_get_stats(AobBake* bake, AobStats* stats);
+/* Zeroes the material's result buffer (done by rasterize as well). */
+int aob_bake_clear_results(AobBake* bake, int32_t material);
+
+/* Introspection used by the parity tests and the multi-GPU gather. */
+int aob_bake_node_count(AobBake* bake, uint64_t* count);
+int aob_bake_copy_nodes(AobBake* bake, AobBvhNode* dst, uint64_t capacity);
+int aob_bake_surfel_count(AobBake* bake, int32_t material, uint64_t* count);
+int aob_bake_copy_surfels(AobBake* bake, int32_t material, AobSurfel* dst, uint64_t capacity);
+int aob_bake_copy_results(AobBake* bake, int32_t material, AobResult* dst, uint64_t capacity);
+/* Device address of the material's W*H AobResult buffer (for an RCCL
+ * collective issued by the caller) and of its resolved image. */
+int aob_bake_results_device_ptr(AobBake* bake, int32_t material, void** ptr, uint64_t* bytes);
+int aob_bake_image_device_ptr(AobBake* bake, int32_t material, void** ptr, uint64_t* bytes);
+/* The HIP stream the stages are enqueued on (a hipStream_t as void*). */
+int aob_bake_stream(AobBake* bake, void** stream);
+/* Timing of the most recent aob_bake_trace launch, measured with HIP events
+ * on the library's own stream. */
+int aob_bake_last_trace_ms(AobBake* bake, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AOBAKER_H */

@@ -1,0 +1,928 @@
+/*
+ * aob_oracle.c — CPU restatement of the reference AO bake path (plain C).
+ *
+ * TEST INFRASTRUCTURE ONLY (see aob_oracle.h).  PARITY UNPINNED against the
+ * reference binary; pinned by closed-form tests and the MSVC rand() sequence.
+ *
+ * Arithmetic contract (shared with the HIP kernels, stated in DESIGN.md §4):
+ * IEEE-754 binary32, round-to-nearest-even, no contraction except where fmaf
+ * is written, correctly rounded / and sqrtf, denormals kept.  Build with
+ * -ffp-contract=off and without -ffast-math (oracle/Makefile does).
+ */
+#include "aob_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------ */
+/* small vector helpers; the evaluation order is part of the contract        */
+
+typedef struct { float x, y, z; } f3;
+
+static inline f3 f3_make(float x, float y, float z) { f3 r = { x, y, z }; return r; }
+static inline f3 f3_sub(f3 a, f3 b) { return f3_make(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline float f3_dot(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+static inline f3 f3_cross(f3 a, f3 b)
+{
+    return f3_make(fmaf(a.y, b.z, -(a.z * b.y)),
+                   fmaf(a.z, b.x, -(a.x * b.z)),
+                   fmaf(a.x, b.y, -(a.y * b.x)));
+}
+static inline f3 f3_normalize(f3 v)
+{
+    float l = sqrtf(f3_dot(v, v));
+    return f3_make(v.x / l, v.y / l, v.z / l);
+}
+static inline int f3_finite(f3 v) { return isfinite(v.x) && isfinite(v.y) && isfinite(v.z); }
+
+/* ------------------------------------------------------------------------ */
+/* scalar primitives                                                         */
+
+uint32_t orc_msvc_rand(uint32_t* state)
+{
+    *state = *state * 214013u + 2531011u;
+    return (*state >> 16) & 0x7fffu;
+}
+
+int32_t orc_ftoi(float v)
+{
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return INT32_MAX;
+    if (v <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)v;
+}
+
+uint16_t orc_f32_to_f16(float v, int mode)
+{
+    uint32_t u; memcpy(&u, &v, 4);
+    uint32_t sign = (u >> 16) & 0x8000u;
+    uint32_t a = u & 0x7fffffffu;
+    if (a > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);                 /* NaN */
+    if (a == 0x7f800000u) return (uint16_t)(sign | 0x7c00u);                /* inf */
+    int32_t e = (int32_t)(a >> 23) - 127;
+    uint32_t m = (a & 0x7fffffu) | 0x800000u;                               /* 24-bit significand */
+    if (a < 0x00800000u) return (uint16_t)sign;                             /* f32 denormal -> 0 */
+    if (e > 15) {
+        /* overflow: RTZ saturates to the largest finite half, RNE goes to inf */
+        return (uint16_t)(sign | (mode == AOB_FP16_RTZ ? 0x7bffu : 0x7c00u));
+    }
+    uint32_t shift, base;
+    if (e >= -14) { shift = 13; base = (uint32_t)(e + 15) << 10; m &= 0x7fffffu; }
+    else {
+        /* half denormal: value = m * 2^(e-23); unit = 2^-24 -> shift = -e - 1 */
+        if (e < -25) return (uint16_t)sign;
+        shift = (uint32_t)(-e - 1); base = 0;
+    }
+    uint32_t q = m >> shift;
+    uint32_t rem = m & ((1u << shift) - 1u);
+    uint32_t h = base + q;          /* carries ripple into the exponent correctly */
+    if (mode != AOB_FP16_RTZ) {
+        uint32_t half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (h & 1u))) h += 1;
+    }
+    return (uint16_t)(sign | h);
+}
+
+float orc_f16_to_f32(uint16_t h)
+{
+    uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1fu;
+    uint32_t m = h & 0x3ffu;
+    uint32_t u;
+    if (e == 0) {
+        if (m == 0) u = sign;
+        else {
+            /* normalise the denormal */
+            int s = 0;
+            while (!(m & 0x400u)) { m <<= 1; s++; }
+            m &= 0x3ffu;
+            u = sign | ((uint32_t)(127 - 15 - s + 1) << 23) | (m << 13);
+        }
+    } else if (e == 31) u = sign | 0x7f800000u | (m << 13);
+    else u = sign | ((e + 112u) << 23) | (m << 13);
+    float f; memcpy(&f, &u, 4);
+    return f;
+}
+
+/* kernels/CL/common.cl:177-218 (USE_SAFE_MATH branch: invd = 1.f / denom) */
+static inline float intersect_triangle(f3 o, f3 d, f3 v1, f3 v2, f3 v3, float t_max)
+{
+    f3 e1 = f3_sub(v2, v1);
+    f3 e2 = f3_sub(v3, v1);
+    f3 s1 = f3_cross(d, e2);
+    float denom = f3_dot(s1, e1);
+    if (denom == 0.0f) return t_max;
+    float invd = 1.0f / denom;
+    f3 dd = f3_sub(o, v1);
+    float b1 = f3_dot(dd, s1) * invd;
+    f3 s2 = f3_cross(dd, e1);
+    float b2 = f3_dot(d, s2) * invd;
+    float temp = f3_dot(e2, s2) * invd;
+    if (b1 < 0.0f || b1 > 1.0f || b2 < 0.0f || b1 + b2 > 1.0f || temp < 0.0f || temp > t_max)
+        return t_max;
+    return temp;
+}
+
+float orc_intersect_triangle(const float o[3], const float d[3],
+                             const float v1[3], const float v2[3], const float v3[3], float t_max)
+{
+    return intersect_triangle(f3_make(o[0], o[1], o[2]), f3_make(d[0], d[1], d[2]),
+                              f3_make(v1[0], v1[1], v1[2]), f3_make(v2[0], v2[1], v2[2]),
+                              f3_make(v3[0], v3[1], v3[2]), t_max);
+}
+
+/* kernels/CL/common.cl:220-232 */
+static inline float safe_inv1(float d)
+{
+    const float ooeps = 1e-8f;
+    return 1.0f / (fabsf(d) > ooeps ? d : copysignf(ooeps, d));
+}
+static inline f3 safe_invdir(f3 d) { return f3_make(safe_inv1(d.x), safe_inv1(d.y), safe_inv1(d.z)); }
+
+void orc_safe_invdir(const float d[3], float invdir[3])
+{
+    f3 r = safe_invdir(f3_make(d[0], d[1], d[2]));
+    invdir[0] = r.x; invdir[1] = r.y; invdir[2] = r.z;
+}
+
+/* kernels/CL/intersect_bvh2_lds.cl:54-63 (mad == fmaf here) */
+static inline void intersect_bbox(const float pmin[3], const float pmax[3], f3 invdir, f3 oxinvdir,
+                                  float t_max, float* t0, float* t1)
+{
+    float fx = fmaf(pmax[0], invdir.x, oxinvdir.x), nx = fmaf(pmin[0], invdir.x, oxinvdir.x);
+    float fy = fmaf(pmax[1], invdir.y, oxinvdir.y), ny = fmaf(pmin[1], invdir.y, oxinvdir.y);
+    float fz = fmaf(pmax[2], invdir.z, oxinvdir.z), nz = fmaf(pmin[2], invdir.z, oxinvdir.z);
+    float tmaxx = fmaxf(fx, nx), tminx = fminf(fx, nx);
+    float tmaxy = fmaxf(fy, ny), tminy = fminf(fy, ny);
+    float tmaxz = fmaxf(fz, nz), tminz = fminf(fz, nz);
+    *t1 = fminf(fminf(fminf(tmaxx, tmaxy), tmaxz), t_max);
+    *t0 = fmaxf(fmaxf(fmaxf(tminx, tminy), tminz), 0.0f);
+}
+
+void orc_intersect_bbox(const float pmin[3], const float pmax[3], const float invdir[3],
+                        const float oxinvdir[3], float t_max, float out[2])
+{
+    intersect_bbox(pmin, pmax, f3_make(invdir[0], invdir[1], invdir[2]),
+                   f3_make(oxinvdir[0], oxinvdir[1], oxinvdir[2]), t_max, &out[0], &out[1]);
+}
+
+/* ------------------------------------------------------------------------ */
+/* samplers                                                                  */
+
+/* BakeEngine.cpp:312-333 — note y = 1 - sqrt(x^2+z^2), not cos(theta). */
+void orc_hemisphere_table(float* out, uint64_t count)
+{
+    uint32_t state = 1u;
+    const float two_pi = 2.0f * 3.14159265358979323846f;   /* RadeonRays/math/mathutils.h:37 */
+    for (uint64_t i = 0; i < count; i++) {
+        float u = (float)orc_msvc_rand(&state) / 32767.0f;
+        float v = (float)orc_msvc_rand(&state) / 32767.0f;
+        float sintheta = sqrtf(-u * (u - 2.0f));
+        float phi = two_pi * v;
+        float x = sintheta * cosf(phi);
+        float z = sintheta * sinf(phi);
+        float len = sqrtf(x * x + z * z);
+        out[3 * i + 0] = x;
+        out[3 * i + 1] = 1.0f - len;
+        out[3 * i + 2] = z;
+    }
+}
+
+static uint64_t chunk_texel_max(const AobOptions* opt)
+{
+    /* BakeEngine.cpp:359-364 */
+    uint64_t spp = opt->sample_count > 0 ? (uint64_t)opt->sample_count : 1;
+    uint64_t c = (uint64_t)(opt->ray_chunk_size > 0 ? opt->ray_chunk_size : 0) / spp;
+    if (c > 65535) c = 65535;
+    if (c < 1) c = 1;
+    return c;
+}
+
+uint64_t orc_compat_table_entries(const AobOptions* opt)
+{
+    return chunk_texel_max(opt) * (uint64_t)(opt->sample_count > 0 ? opt->sample_count : 0);
+}
+
+static inline uint32_t pcg_hash(uint32_t v)
+{
+    uint32_t s = v * 747796405u + 2891336453u;
+    uint32_t w = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u;
+    return (w >> 22) ^ w;
+}
+
+void orc_sincos2pi(float u, float* s_out, float* c_out)
+{
+    float t = u * 4.0f;
+    int q = (int)t;
+    float f = t - (float)q;
+    float x = f * 1.57079637f;
+    float x2 = x * x;
+    float ps = fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, -2.50521084e-8f, 2.75573192e-6f),
+                 -1.98412698e-4f), 8.33333333e-3f), -1.66666667e-1f), 1.0f);
+    float s = x * ps;
+    float c = fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 2.08767570e-9f, -2.75573192e-7f),
+                 2.48015873e-5f), -1.38888889e-3f), 4.16666667e-2f), -0.5f), 1.0f);
+    switch (q & 3) {
+    case 0: *s_out = s;  *c_out = c;  break;
+    case 1: *s_out = c;  *c_out = -s; break;
+    case 2: *s_out = -s; *c_out = -c; break;
+    default: *s_out = -c; *c_out = s; break;
+    }
+}
+
+static void cosine_grid(int32_t spp, int32_t* sx, int32_t* sy)
+{
+    int32_t a = 1;
+    while ((int64_t)a * a < spp) a++;
+    *sx = a;
+    *sy = (spp + a - 1) / a;
+}
+
+typedef struct { int32_t sx, sy; float inv_sx, inv_sy; } CosineGrid;
+
+static inline f3 cosine_sample(uint32_t base, int32_t i, const CosineGrid* g)
+{
+    const float one_minus = 0.99999994f;
+    uint32_t a = pcg_hash(base + 2u * (uint32_t)i);
+    uint32_t b = pcg_hash(base + 2u * (uint32_t)i + 1u);
+    float j1 = (float)(a >> 8) * 5.9604644775390625e-8f;
+    float j2 = (float)(b >> 8) * 5.9604644775390625e-8f;
+    int32_t cx = i % g->sx, cy = i / g->sx;
+    float u1 = fminf(((float)cx + j1) * g->inv_sx, one_minus);
+    float u2 = fminf(((float)cy + j2) * g->inv_sy, one_minus);
+    float r = sqrtf(u1);
+    float y = sqrtf(1.0f - u1);
+    float s, c;
+    orc_sincos2pi(u2, &s, &c);
+    return f3_make(r * c, y, r * s);
+}
+
+void orc_cosine_sample(uint32_t seed, uint32_t texel, int32_t i, int32_t sample_count, float out[3])
+{
+    CosineGrid g;
+    cosine_grid(sample_count, &g.sx, &g.sy);
+    g.inv_sx = 1.0f / (float)g.sx; g.inv_sy = 1.0f / (float)g.sy;
+    uint32_t base = pcg_hash(texel + pcg_hash(seed));
+    f3 d = cosine_sample(base, i, &g);
+    out[0] = d.x; out[1] = d.y; out[2] = d.z;
+}
+
+/* ------------------------------------------------------------------------ */
+/* scene -> world-space geometry                                             */
+
+static inline const float* attr_ptr(const void* base, uint32_t stride, uint32_t i)
+{
+    return (const float*)((const uint8_t*)base + (size_t)stride * i);
+}
+
+/* RasterizeVertexShader.hlsl:32: worldpos = mul(float4(pos,1), model) (row vector) */
+static inline f3 transform_point(const float* m, const float* p)
+{
+    f3 r;
+    float* o = &r.x;
+    for (int j = 0; j < 3; j++) {
+        float t = p[0] * m[0 * 4 + j];
+        t = fmaf(p[1], m[1 * 4 + j], t);
+        t = fmaf(p[2], m[2 * 4 + j], t);
+        o[j] = t + m[3 * 4 + j];
+    }
+    return r;
+}
+
+/* RasterizeVertexShader.hlsl:30: normalize(mul(float4(norm,0), model)) — the model
+ * matrix itself, not its inverse transpose. */
+static inline f3 transform_normal(const float* m, const float* n)
+{
+    f3 r;
+    float* o = &r.x;
+    for (int j = 0; j < 3; j++) {
+        float t = n[0] * m[0 * 4 + j];
+        t = fmaf(n[1], m[1 * 4 + j], t);
+        t = fmaf(n[2], m[2 * 4 + j], t);
+        o[j] = t;
+    }
+    return f3_normalize(r);
+}
+
+uint64_t orc_scene_triangle_count(const AobSceneDesc* scene)
+{
+    uint64_t n = 0;
+    for (uint32_t i = 0; i < scene->mesh_count; i++) n += scene->meshes[i].index_count / 3;
+    return n;
+}
+
+/* BakeEngine.cpp:370-398: every section becomes a shape; RadeonRays applies the
+ * shape transform to the vertices, so the BVH holds world-space triangles.
+ * Shape ids start at 1 (RadeonRays/radeon_rays.h:238). */
+void orc_scene_triangles(const AobSceneDesc* scene, OrcTriangle* out)
+{
+    uint64_t k = 0;
+    for (uint32_t mi = 0; mi < scene->mesh_count; mi++) {
+        const AobMeshDesc* m = &scene->meshes[mi];
+        uint32_t ntri = m->index_count / 3;
+        for (uint32_t t = 0; t < ntri; t++, k++) {
+            for (int c = 0; c < 3; c++) {
+                uint32_t vi = m->indices[3 * t + c];
+                f3 w = transform_point(m->model, attr_ptr(m->positions, m->position_stride, vi));
+                out[k].v[c][0] = w.x; out[k].v[c][1] = w.y; out[k].v[c][2] = w.z;
+            }
+            out[k].shape_id = mi + 1;
+            out[k].prim_id = t;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* LBVH build (kernels/CL/build_hlbvh.cl), 63-bit Morton codes                */
+
+static inline uint64_t expand21(uint32_t v)
+{
+    uint64_t x = v & 0x1fffffu;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+static inline uint32_t morton_axis(float c, float smin, float extent)
+{
+    /* build_hlbvh.cl:122 (center - scene_min) / scene_extents, then :71-73 clamp */
+    float n = extent > 0.0f ? (c - smin) / extent : 0.0f;
+    float q = fminf(fmaxf(n * 2097152.0f, 0.0f), 2097151.0f);
+    return (uint32_t)q;
+}
+
+typedef struct { uint64_t code; uint32_t idx; } MortonKey;
+
+static int morton_cmp(const void* a, const void* b)
+{
+    const MortonKey* x = (const MortonKey*)a; const MortonKey* y = (const MortonKey*)b;
+    if (x->code != y->code) return x->code < y->code ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+
+/* build_hlbvh.cl:131-150 */
+static inline int lbvh_delta(const MortonKey* keys, int64_t n, int64_t i1, int64_t i2)
+{
+    int64_t left = i1 < i2 ? i1 : i2, right = i1 < i2 ? i2 : i1;
+    if (left < 0 || right >= n) return -1;
+    uint64_t lc = keys[left].code, rc = keys[right].code;
+    if (lc != rc) return __builtin_clzll(lc ^ rc);
+    return 64 + __builtin_clz((uint32_t)left ^ (uint32_t)right);
+}
+
+typedef struct { float pmin[3], pmax[3]; } Box;
+
+static inline void box_union(Box* d, const Box* a, const Box* b)
+{
+    for (int k = 0; k < 3; k++) { d->pmin[k] = fminf(a->pmin[k], b->pmin[k]); d->pmax[k] = fmaxf(a->pmax[k], b->pmax[k]); }
+}
+
+uint64_t orc_bvh_build(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes, uint32_t* depth_out)
+{
+    if (depth_out) *depth_out = 0;
+    if (n == 0) return 0;
+    Box* pb = (Box*)malloc(sizeof(Box) * n);
+    Box scene;
+    for (int k = 0; k < 3; k++) { scene.pmin[k] = INFINITY; scene.pmax[k] = -INFINITY; }
+    for (uint64_t i = 0; i < n; i++) {
+        for (int k = 0; k < 3; k++) {
+            pb[i].pmin[k] = fminf(fminf(tris[i].v[0][k], tris[i].v[1][k]), tris[i].v[2][k]);
+            pb[i].pmax[k] = fmaxf(fmaxf(tris[i].v[0][k], tris[i].v[1][k]), tris[i].v[2][k]);
+            scene.pmin[k] = fminf(scene.pmin[k], pb[i].pmin[k]);
+            scene.pmax[k] = fmaxf(scene.pmax[k], pb[i].pmax[k]);
+        }
+    }
+    MortonKey* keys = (MortonKey*)malloc(sizeof(MortonKey) * n);
+    float ext[3];
+    for (int k = 0; k < 3; k++) ext[k] = scene.pmax[k] - scene.pmin[k];
+    for (uint64_t i = 0; i < n; i++) {
+        uint32_t q[3];
+        for (int k = 0; k < 3; k++) {
+            float c = (pb[i].pmax[k] + pb[i].pmin[k]) * 0.5f;        /* build_hlbvh.cl:118 */
+            q[k] = morton_axis(c, scene.pmin[k], ext[k]);
+        }
+        keys[i].code = (expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]);
+        keys[i].idx = (uint32_t)i;
+    }
+    qsort(keys, n, sizeof(MortonKey), morton_cmp);
+
+    uint64_t node_count = 2 * n - 1;
+    memset(nodes, 0, sizeof(AobBvhNode) * node_count);
+    if (n == 1) {
+        const OrcTriangle* t = &tris[0];
+        memcpy(nodes[0].lmin_or_v0, t->v[0], 12); memcpy(nodes[0].lmax_or_v1, t->v[1], 12);
+        memcpy(nodes[0].rmin_or_v2, t->v[2], 12);
+        nodes[0].addr_left = AOB_INVALID_ADDR; nodes[0].shape_id = t->shape_id; nodes[0].prim_id = t->prim_id;
+        free(pb); free(keys);
+        return 1;
+    }
+
+    int64_t N = (int64_t)n;
+    uint32_t* left = (uint32_t*)malloc(4 * (n - 1));
+    uint32_t* right = (uint32_t*)malloc(4 * (n - 1));
+    uint32_t* parent = (uint32_t*)malloc(4 * node_count);
+    Box* bounds = (Box*)malloc(sizeof(Box) * node_count);
+    parent[0] = 0xffffffffu;
+    /* build_hlbvh.cl:152-261: span, split, child links */
+    for (int64_t idx = 0; idx < N - 1; idx++) {
+        int dnext = lbvh_delta(keys, N, idx, idx + 1), dprev = lbvh_delta(keys, N, idx, idx - 1);
+        int d = dnext >= dprev ? 1 : -1;
+        int delta_min = lbvh_delta(keys, N, idx, idx - d);
+        int64_t lmax = 2;
+        while (lbvh_delta(keys, N, idx, idx + lmax * d) > delta_min) lmax *= 2;
+        int64_t l = 0, t = lmax;
+        do {
+            t /= 2;
+            if (lbvh_delta(keys, N, idx, idx + (l + t) * d) > delta_min) l += t;
+        } while (t > 1);
+        int64_t sx = idx < idx + l * d ? idx : idx + l * d;
+        int64_t sy = idx < idx + l * d ? idx + l * d : idx;
+        int64_t lo = sx, hi = sy;
+        int num_identical = lbvh_delta(keys, N, lo, hi);
+        do {
+            int64_t ns = (hi + lo) / 2;
+            if (lbvh_delta(keys, N, lo, ns) > num_identical) lo = ns; else hi = ns;
+        } while (hi > lo + 1);
+        int64_t split = lo;
+        uint32_t c1 = (split == sx) ? (uint32_t)(N - 1 + split) : (uint32_t)split;
+        uint32_t c2 = (split + 1 == sy) ? (uint32_t)(N - 1 + split + 1) : (uint32_t)(split + 1);
+        left[idx] = c1; right[idx] = c2;
+        parent[c1] = (uint32_t)idx; parent[c2] = (uint32_t)idx;
+    }
+    /* leaves */
+    for (int64_t p = 0; p < N; p++) bounds[N - 1 + p] = pb[keys[p].idx];
+    /* refit (build_hlbvh.cl:264-314), serial: children before parents via visit counts */
+    uint8_t* flags = (uint8_t*)calloc(n - 1, 1);
+    uint32_t max_depth = 0;
+    for (int64_t p = 0; p < N; p++) {
+        uint32_t idx = (uint32_t)(N - 1 + p);
+        uint32_t dpt = 0;
+        for (uint32_t a = idx; parent[a] != 0xffffffffu; a = parent[a]) dpt++;
+        if (dpt > max_depth) max_depth = dpt;
+        do {
+            idx = parent[idx];
+            if (flags[idx]++ == 0) break;
+            box_union(&bounds[idx], &bounds[left[idx]], &bounds[right[idx]]);
+        } while (idx != 0);
+    }
+    if (depth_out) *depth_out = max_depth;
+    /* emit the 64-byte traversal nodes (intersect_bvh2_lds.cl:40-52) */
+    for (int64_t i = 0; i < N - 1; i++) {
+        AobBvhNode* nd = &nodes[i];
+        const Box* bl = &bounds[left[i]]; const Box* br = &bounds[right[i]];
+        memcpy(nd->lmin_or_v0, bl->pmin, 12); memcpy(nd->lmax_or_v1, bl->pmax, 12);
+        memcpy(nd->rmin_or_v2, br->pmin, 12); memcpy(nd->rmax, br->pmax, 12);
+        nd->addr_left = left[i]; nd->addr_right = right[i];
+        nd->shape_id = 0; nd->prim_id = 0;
+    }
+    for (int64_t p = 0; p < N; p++) {
+        AobBvhNode* nd = &nodes[N - 1 + p];
+        const OrcTriangle* t = &tris[keys[p].idx];
+        memcpy(nd->lmin_or_v0, t->v[0], 12); memcpy(nd->lmax_or_v1, t->v[1], 12);
+        memcpy(nd->rmin_or_v2, t->v[2], 12);
+        nd->addr_left = AOB_INVALID_ADDR; nd->addr_right = 0;
+        nd->shape_id = t->shape_id; nd->prim_id = t->prim_id;
+    }
+    free(flags); free(bounds); free(parent); free(right); free(left); free(keys); free(pb);
+    return node_count;
+}
+
+/* ------------------------------------------------------------------------ */
+/* UV rasterisation                                                          */
+
+#define SUBPIXEL 256
+#define COORD_LIMIT 67108864.0f   /* 2^26 sub-pixels: |screen coordinate| < 2^18 px */
+
+static inline int64_t edge_fn(int64_t ax, int64_t ay, int64_t bx, int64_t by, int64_t px, int64_t py)
+{
+    return (bx - ax) * (py - ay) - (by - ay) * (px - ax);
+}
+/* D3D11 top-left rule for an edge a->b of a triangle whose interior is edge_fn > 0 */
+static inline int edge_top_left(int64_t ax, int64_t ay, int64_t bx, int64_t by)
+{
+    int64_t dx = bx - ax, dy = by - ay;
+    return dy < 0 || (dy == 0 && dx > 0);
+}
+
+typedef struct { f3 wpos, wnrm; float u, v; } RasterVertex;
+
+static inline float quantise_fp16(float v, int mode)
+{
+    return mode == AOB_FP16_OFF ? v : orc_f16_to_f32(orc_f32_to_f16(v, mode));
+}
+
+uint64_t orc_rasterize(const AobSceneDesc* scene, int32_t material, const AobOptions* opt,
+                       AobSurfel* surfels, uint32_t* section_index, uint64_t capacity)
+{
+    if (material < 0 || (uint32_t)material >= scene->material_count) return 0;
+    const int32_t W = scene->materials[material].width, H = scene->materials[material].height;
+    if (W <= 0 || H <= 0) return 0;
+    uint32_t* cover = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)W * H);
+    uint64_t total = 0;
+    for (uint32_t mi = 0; mi < scene->mesh_count; mi++) {
+        const AobMeshDesc* m = &scene->meshes[mi];
+        if (m->material != material) continue;                       /* BakeEngine.cpp:523 */
+        memset(cover, 0, sizeof(uint32_t) * (size_t)W * H);
+        uint32_t ntri = m->index_count / 3;
+        /* pass 1: the stencil layer peel keeps, per texel, the LAST fragment drawn
+         * (BakeEngine.cpp:130-140,531-588): highest triangle index covering the centre */
+        for (uint32_t t = 0; t < ntri; t++) {
+            int64_t X[3], Y[3];
+            int ok = 1;
+            for (int c = 0; c < 3; c++) {
+                const float* uv = attr_ptr(m->uvs, m->uv_stride, m->indices[3 * t + c]);
+                /* RasterizeVertexShader.hlsl:29 + viewport: pixel = (u*W, v*H) */
+                float sx = uv[0] * (float)W * (float)SUBPIXEL, sy = uv[1] * (float)H * (float)SUBPIXEL;
+                if (!(fabsf(sx) < COORD_LIMIT) || !(fabsf(sy) < COORD_LIMIT)) { ok = 0; break; }
+                X[c] = (int64_t)rintf(sx); Y[c] = (int64_t)rintf(sy);
+            }
+            if (!ok) continue;
+            int64_t area = edge_fn(X[0], Y[0], X[1], Y[1], X[2], Y[2]);
+            if (area == 0) continue;
+            if (area < 0) { int64_t tx = X[1], ty = Y[1]; X[1] = X[2]; Y[1] = Y[2]; X[2] = tx; Y[2] = ty; }
+            int64_t minx = X[0] < X[1] ? X[0] : X[1]; if (X[2] < minx) minx = X[2];
+            int64_t maxx = X[0] > X[1] ? X[0] : X[1]; if (X[2] > maxx) maxx = X[2];
+            int64_t miny = Y[0] < Y[1] ? Y[0] : Y[1]; if (Y[2] < miny) miny = Y[2];
+            int64_t maxy = Y[0] > Y[1] ? Y[0] : Y[1]; if (Y[2] > maxy) maxy = Y[2];
+            int64_t px0 = (minx - 128 + 255) >> 8, px1 = (maxx - 128) >> 8;
+            int64_t py0 = (miny - 128 + 255) >> 8, py1 = (maxy - 128) >> 8;
+            if (px0 < 0) px0 = 0; if (py0 < 0) py0 = 0;
+            if (px1 > W - 1) px1 = W - 1; if (py1 > H - 1) py1 = H - 1;
+            int64_t b0 = edge_top_left(X[0], Y[0], X[1], Y[1]) ? 0 : -1;
+            int64_t b1 = edge_top_left(X[1], Y[1], X[2], Y[2]) ? 0 : -1;
+            int64_t b2 = edge_top_left(X[2], Y[2], X[0], Y[0]) ? 0 : -1;
+            for (int64_t py = py0; py <= py1; py++) {
+                for (int64_t px = px0; px <= px1; px++) {
+                    int64_t cx = px * 256 + 128, cy = py * 256 + 128;
+                    if (edge_fn(X[0], Y[0], X[1], Y[1], cx, cy) + b0 < 0) continue;
+                    if (edge_fn(X[1], Y[1], X[2], Y[2], cx, cy) + b1 < 0) continue;
+                    if (edge_fn(X[2], Y[2], X[0], Y[0], cx, cy) + b2 < 0) continue;
+                    uint32_t* c = &cover[(size_t)py * W + px];
+                    if (t + 1 > *c) *c = t + 1;
+                }
+            }
+        }
+        /* pass 2: attributes of the winning fragment, row-major extraction */
+        uint32_t local = 0;
+        for (int32_t py = 0; py < H; py++) {
+            for (int32_t px = 0; px < W; px++) {
+                uint32_t c = cover[(size_t)py * W + px];
+                if (!c) continue;
+                uint32_t t = c - 1;
+                RasterVertex rv[3];
+                int64_t X[3], Y[3];
+                for (int k = 0; k < 3; k++) {
+                    uint32_t vi = m->indices[3 * t + k];
+                    const float* uv = attr_ptr(m->uvs, m->uv_stride, vi);
+                    X[k] = (int64_t)rintf(uv[0] * (float)W * (float)SUBPIXEL);
+                    Y[k] = (int64_t)rintf(uv[1] * (float)H * (float)SUBPIXEL);
+                    rv[k].wpos = transform_point(m->model, attr_ptr(m->positions, m->position_stride, vi));
+                    rv[k].wnrm = transform_normal(m->model, attr_ptr(m->normals, m->normal_stride, vi));
+                    rv[k].u = uv[0]; rv[k].v = uv[1];
+                }
+                int64_t area = edge_fn(X[0], Y[0], X[1], Y[1], X[2], Y[2]);
+                if (area < 0) {
+                    int64_t tx = X[1], ty = Y[1]; X[1] = X[2]; Y[1] = Y[2]; X[2] = tx; Y[2] = ty;
+                    RasterVertex tv = rv[1]; rv[1] = rv[2]; rv[2] = tv;
+                    area = -area;
+                }
+                int64_t cx = (int64_t)px * 256 + 128, cy = (int64_t)py * 256 + 128;
+                float fa = (float)area;
+                float l0 = (float)edge_fn(X[1], Y[1], X[2], Y[2], cx, cy) / fa;
+                float l1 = (float)edge_fn(X[2], Y[2], X[0], Y[0], cx, cy) / fa;
+                float l2 = (float)edge_fn(X[0], Y[0], X[1], Y[1], cx, cy) / fa;
+#define LERP(f) fmaf(l2, rv[2].f, fmaf(l1, rv[1].f, l0 * rv[0].f))
+                if (total < capacity) {
+                    AobSurfel* s = &surfels[total];
+                    s->texel_x = px; s->texel_y = py;
+                    s->position[0] = LERP(wpos.x); s->position[1] = LERP(wpos.y); s->position[2] = LERP(wpos.z);
+                    /* RasterizePixelShader.hlsl:20-21: U rides with the fp32 position,
+                     * normal + V go through the RGBA16F target (BakeEngine.cpp:446,584-585) */
+                    s->texcoord[0] = LERP(u);
+                    s->texcoord[1] = quantise_fp16(LERP(v), opt->normal_fp16);
+                    s->normal[0] = quantise_fp16(LERP(wnrm.x), opt->normal_fp16);
+                    s->normal[1] = quantise_fp16(LERP(wnrm.y), opt->normal_fp16);
+                    s->normal[2] = quantise_fp16(LERP(wnrm.z), opt->normal_fp16);
+                    if (section_index) section_index[total] = local;
+                }
+#undef LERP
+                total++; local++;
+            }
+        }
+    }
+    free(cover);
+    return total;
+}
+
+/* ------------------------------------------------------------------------ */
+/* trace                                                                     */
+
+#define ORC_STACK 128
+
+typedef struct {
+    const AobBvhNode* nodes; uint64_t node_count;
+    const AobSurfel* surfels; const uint32_t* section_index;
+    const AobOptions* opt; const float* hemisphere;
+    int32_t width, height; AobResult* results;
+    uint64_t begin, end;
+    uint64_t next;            /* dynamic work distribution */
+    pthread_mutex_t lock;
+    OrcTraceStats stats;
+    int error;
+} TraceJob;
+
+/* intersect_bvh2_lds.cl:65-226 (closest) / :228-363 (any hit): near child first,
+ * deferred child on a stack, leaf = inlined triangle. Returns hit flag, *t_out. */
+static inline int traverse(const AobBvhNode* nodes, uint64_t node_count, f3 o, f3 d, float t_max,
+                           int any_hit, float* t_out, OrcTraceStats* st, int* error)
+{
+    if (node_count == 0) { *t_out = t_max; return 0; }
+    f3 invdir = safe_invdir(d);
+    f3 oxinvdir = f3_make(-o.x * invdir.x, -o.y * invdir.y, -o.z * invdir.z);
+    float closest_t = t_max;
+    int hit = 0;
+    uint32_t stack[ORC_STACK];
+    int sp = 0;
+    stack[sp++] = AOB_INVALID_ADDR;
+    uint32_t addr = 0;
+    while (addr != AOB_INVALID_ADDR) {
+        const AobBvhNode* n = &nodes[addr];
+        if (n->addr_left != AOB_INVALID_ADDR) {
+            st->inner_visits++;
+            float s0x, s0y, s1x, s1y;
+            intersect_bbox(n->lmin_or_v0, n->lmax_or_v1, invdir, oxinvdir, closest_t, &s0x, &s0y);
+            intersect_bbox(n->rmin_or_v2, n->rmax, invdir, oxinvdir, closest_t, &s1x, &s1y);
+            int c0 = s0x <= s0y, c1 = s1x <= s1y;
+            int c1first = c1 && (s0x > s1x);
+            if (c0 || c1) {
+                uint32_t deferred;
+                if (c1first || !c0) { addr = n->addr_right; deferred = n->addr_left; }
+                else { addr = n->addr_left; deferred = n->addr_right; }
+                if (c0 && c1) {
+                    if (sp >= ORC_STACK) { *error = AOB_ERR_BVH_TOO_DEEP; *t_out = t_max; return 0; }
+                    stack[sp++] = deferred;
+                }
+                continue;
+            }
+        } else {
+            st->leaf_visits++;
+            float t = intersect_triangle(o, d,
+                                         f3_make(n->lmin_or_v0[0], n->lmin_or_v0[1], n->lmin_or_v0[2]),
+                                         f3_make(n->lmax_or_v1[0], n->lmax_or_v1[1], n->lmax_or_v1[2]),
+                                         f3_make(n->rmin_or_v2[0], n->rmin_or_v2[1], n->rmin_or_v2[2]),
+                                         closest_t);
+            if (t < closest_t) {
+                closest_t = t; hit = 1;
+                if (any_hit) break;
+            }
+        }
+        addr = stack[--sp];
+    }
+    *t_out = closest_t;
+    return hit;
+}
+
+static void trace_surfel(const TraceJob* job, uint64_t k, OrcTraceStats* st, int* error,
+                         const CosineGrid* grid, uint64_t chunk_max)
+{
+    const AobOptions* opt = job->opt;
+    const AobSurfel* s = &job->surfels[k];
+    const int32_t spp = opt->sample_count;
+    f3 P = f3_make(s->position[0], s->position[1], s->position[2]);
+    f3 N = f3_make(s->normal[0], s->normal[1], s->normal[2]);
+    if (s->texel_x < 0 || s->texel_y < 0 || s->texel_x >= job->width || s->texel_y >= job->height) return;
+    AobResult* cell = &job->results[(size_t)s->texel_y * job->width + s->texel_x];
+    /* GenerateRaysComputeShader.hlsl:34-41 */
+    f3 X = f3_make(1.0f, 0.0f, 0.0f), Z = f3_make(0.0f, 0.0f, 1.0f);
+    if (N.y < 0.9999f && N.y > -0.9999f) {
+        X = f3_normalize(f3_make(-N.z, 0.0f, N.x));      /* cross(N, (0,1,0)) */
+        Z = f3_normalize(f3_cross(X, N));
+    }
+    /* a non-finite frame makes every weight NaN, and (int)NaN == 0 in HLSL: the
+     * surfel contributes nothing in the reference, so it contributes nothing here */
+    if (!f3_finite(P) || !f3_finite(N) || !f3_finite(X) || !f3_finite(Z)) return;
+
+    const int compat = opt->sampler == AOB_SAMPLER_REFERENCE_COMPAT;
+    const int any_hit = opt->use_any_hit != 0;
+    float t_max = opt->ray_tmax;
+    if (!any_hit && opt->clamp_tmax_to_falloff && opt->falloff_distance < t_max) t_max = opt->falloff_distance;
+    const float F = opt->falloff_distance;
+    uint32_t texel = (uint32_t)s->texel_y * (uint32_t)job->width + (uint32_t)s->texel_x;
+    uint32_t base = pcg_hash(texel + pcg_hash(opt->seed));
+    /* GenerateRaysComputeShader.hlsl:45 Hemisphere[DTid.x * SampleCount + i], DTid.x chunk-local */
+    uint64_t local = job->section_index ? job->section_index[k] : k;
+    const float* table = compat ? job->hemisphere + 3 * ((local % chunk_max) * (uint64_t)spp) : NULL;
+
+    int32_t qT = 0, qW = 0;
+    float fT = 0.0f, fW = 0.0f;
+    for (int32_t i = 0; i < spp; i++) {
+        f3 h = compat ? f3_make(table[3 * i], table[3 * i + 1], table[3 * i + 2]) : cosine_sample(base, i, grid);
+        /* :46 */
+        f3 dir = f3_make(fmaf(h.z, Z.x, fmaf(h.y, N.x, h.x * X.x)),
+                         fmaf(h.z, Z.y, fmaf(h.y, N.y, h.x * X.y)),
+                         fmaf(h.z, Z.z, fmaf(h.y, N.z, h.x * X.z)));
+        /* :47 origin offset along the ray */
+        f3 org = f3_make(fmaf(dir.x, opt->ray_bias, P.x), fmaf(dir.y, opt->ray_bias, P.y), fmaf(dir.z, opt->ray_bias, P.z));
+        float t;
+        st->rays++;
+        int hit = traverse(job->nodes, job->node_count, org, dir, t_max, any_hit, &t, st, error);
+        st->hits += (uint64_t)hit;
+        /* ProcessIntersectionsComputeShader.hlsl:52-85 */
+        float w = compat ? f3_dot(N, dir) : 1.0f;
+        float r;
+        if (any_hit) r = hit ? 0.0f : 1.0f;
+        else r = (hit && t < F) ? t / F : 1.0f;
+        if (opt->accumulate == AOB_ACCUMULATE_QUANTISED) {
+            qT += orc_ftoi(r * w * 255.0f);          /* :87 */
+            qW += orc_ftoi(w * 255.0f);              /* :88 */
+        } else {
+            fT += r * w; fW += w;
+        }
+    }
+    /* :89-90 InterlockedAdd into Results[y*W+x] (one surfel per cell per section) */
+    if (opt->accumulate == AOB_ACCUMULATE_QUANTISED) {
+        cell->total_bits = (uint32_t)((int32_t)cell->total_bits + qT);
+        cell->weight_bits = (uint32_t)((int32_t)cell->weight_bits + qW);
+    } else {
+        float a, b;
+        memcpy(&a, &cell->total_bits, 4); memcpy(&b, &cell->weight_bits, 4);
+        a += fT; b += fW;
+        memcpy(&cell->total_bits, &a, 4); memcpy(&cell->weight_bits, &b, 4);
+    }
+}
+
+static void* trace_worker(void* arg)
+{
+    TraceJob* job = (TraceJob*)arg;
+    OrcTraceStats st; memset(&st, 0, sizeof st);
+    int error = 0;
+    CosineGrid grid;
+    cosine_grid(job->opt->sample_count, &grid.sx, &grid.sy);
+    grid.inv_sx = 1.0f / (float)grid.sx; grid.inv_sy = 1.0f / (float)grid.sy;
+    uint64_t chunk_max = chunk_texel_max(job->opt);
+    const uint64_t grain = 64;
+    for (;;) {
+        pthread_mutex_lock(&job->lock);
+        uint64_t b = job->next;
+        job->next = b + grain;
+        pthread_mutex_unlock(&job->lock);
+        if (b >= job->end) break;
+        uint64_t e = b + grain < job->end ? b + grain : job->end;
+        for (uint64_t k = b; k < e; k++) trace_surfel(job, k, &st, &error, &grid, chunk_max);
+    }
+    pthread_mutex_lock(&job->lock);
+    job->stats.rays += st.rays; job->stats.inner_visits += st.inner_visits;
+    job->stats.leaf_visits += st.leaf_visits; job->stats.hits += st.hits;
+    if (error) job->error = error;
+    pthread_mutex_unlock(&job->lock);
+    return NULL;
+}
+
+int orc_trace(const AobBvhNode* nodes, uint64_t node_count,
+              const AobSurfel* surfels, const uint32_t* section_index,
+              uint64_t begin, uint64_t end, const AobOptions* opt, const float* hemisphere,
+              int32_t width, int32_t height, AobResult* results, int32_t threads, OrcTraceStats* stats)
+{
+    if (opt->sampler == AOB_SAMPLER_REFERENCE_COMPAT && !hemisphere && end > begin) return AOB_ERR_INVALID_ARGUMENT;
+    TraceJob job;
+    memset(&job, 0, sizeof job);
+    job.nodes = nodes; job.node_count = node_count; job.surfels = surfels; job.section_index = section_index;
+    job.opt = opt; job.hemisphere = hemisphere; job.width = width; job.height = height; job.results = results;
+    job.begin = begin; job.end = end; job.next = begin;
+    pthread_mutex_init(&job.lock, NULL);
+    if (threads <= 1) trace_worker(&job);
+    else {
+        if (threads > 256) threads = 256;
+        pthread_t th[256];
+        for (int i = 0; i < threads; i++) pthread_create(&th[i], NULL, trace_worker, &job);
+        for (int i = 0; i < threads; i++) pthread_join(th[i], NULL);
+    }
+    pthread_mutex_destroy(&job.lock);
+    if (stats) {
+        stats->rays += job.stats.rays; stats->inner_visits += job.stats.inner_visits;
+        stats->leaf_visits += job.stats.leaf_visits; stats->hits += job.stats.hits;
+    }
+    return job.error;
+}
+
+/* ------------------------------------------------------------------------ */
+/* resolve + bleed + format conversion                                       */
+
+static inline int32_t as_i32(uint32_t u) { return (int32_t)u; }
+static inline float as_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+static inline int cell_covered(const AobResult* r, int quantised)
+{
+    /* PostprocessPixelShader.hlsl:43 (== 0) and :66 (> 0) */
+    return quantised ? as_i32(r->weight_bits) != 0 : as_f32(r->weight_bits) != 0.0f;
+}
+static inline int cell_positive(const AobResult* r, int quantised)
+{
+    return quantised ? as_i32(r->weight_bits) > 0 : as_f32(r->weight_bits) > 0.0f;
+}
+/* PostprocessPixelShader.hlsl:31-35,81: ((T*255)/Wt)/255.0f with integer division */
+static inline float cell_value(const AobResult* r, int quantised)
+{
+    if (quantised) {
+        int32_t T = as_i32(r->total_bits), Wt = as_i32(r->weight_bits);
+        /* 32-bit wrap-around multiply as in HLSL; division truncates toward zero */
+        int32_t num = (int32_t)((uint32_t)T * 255u);
+        int32_t q = (Wt == -1 && num == INT32_MIN) ? INT32_MIN : num / Wt;
+        return (float)q / 255.0f;
+    }
+    return as_f32(r->total_bits) / as_f32(r->weight_bits);
+}
+
+static inline uint8_t to_unorm8(float v)
+{
+    /* D3D11 float -> UNORM: NaN -> 0, clamp to [0,1], scale, add 0.5, truncate */
+    if (!(v == v)) return 0;
+    float c = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+    return (uint8_t)(c * 255.0f + 0.5f);
+}
+
+void orc_resolve(const AobResult* results, int32_t W, int32_t H, const AobOptions* opt,
+                 int32_t channels, int32_t bpc, uint8_t* out)
+{
+    const int quantised = opt->accumulate == AOB_ACCUMULATE_QUANTISED;
+    const int32_t B = opt->bleed_distance;
+    const int64_t cells = (int64_t)W * H;
+    const int f16mode = opt->normal_fp16 == AOB_FP16_RTZ ? AOB_FP16_RTZ : AOB_FP16_RNE;
+    for (int32_t py = 0; py < H; py++) {
+        for (int32_t px = 0; px < W; px++) {
+            const AobResult* me = &results[(size_t)py * W + px];
+            float result = 0.0f;
+            if (!cell_covered(me, quantised)) {
+                /* :43-78: scan x outer / y inner; the read uses the RAW (x, y), so a negative x
+                 * aliases into the previous row and an index outside the buffer reads zeros */
+                int32_t closest = (B + 1) * (B + 1);
+                for (int32_t x = px - B; x <= px + B; x++) {
+                    for (int32_t y = py - B; y <= py + B; y++) {
+                        int64_t idx = (int64_t)y * W + x;
+                        if (idx < 0 || idx >= cells) continue;
+                        const AobResult* nb = &results[idx];
+                        if (cell_positive(nb, quantised)) {
+                            int32_t d2 = (x - px) * (x - px) + (y - py) * (y - py);
+                            if (d2 < closest && d2 < B * B) {
+                                closest = d2;
+                                result = cell_value(nb, quantised);
+                            }
+                        }
+                    }
+                }
+            } else {
+                result = cell_value(me, quantised);
+            }
+            /* :85 float4(result, 0, 0, 1) into the AO texture's format (BakeEngine.cpp:482) */
+            const float px4[4] = { result, 0.0f, 0.0f, 1.0f };
+            uint8_t* dst = out + ((size_t)py * W + px) * (size_t)channels * (size_t)bpc;
+            for (int c = 0; c < channels; c++) {
+                float v = px4[c < 4 ? c : 3];
+                if (bpc == 1) dst[c] = to_unorm8(v);
+                else if (bpc == 2) { uint16_t h = orc_f32_to_f16(v, f16mode); memcpy(dst + 2 * c, &h, 2); }
+                else memcpy(dst + 4 * c, &v, 4);
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* end to end                                                                */
+
+int orc_bake(const AobSceneDesc* scene, const AobOptions* opt, int32_t threads, OrcTraceStats* stats)
+{
+    if (!scene || !opt || opt->sample_count <= 0) return AOB_ERR_INVALID_ARGUMENT;
+    uint64_t ntri = orc_scene_triangle_count(scene);
+    OrcTriangle* tris = (OrcTriangle*)malloc(sizeof(OrcTriangle) * (ntri ? ntri : 1));
+    orc_scene_triangles(scene, tris);
+    AobBvhNode* nodes = (AobBvhNode*)malloc(sizeof(AobBvhNode) * (ntri ? 2 * ntri : 1));
+    uint32_t depth = 0;
+    uint64_t node_count = orc_bvh_build(tris, ntri, nodes, &depth);
+    float* hemi = NULL;
+    if (opt->sampler == AOB_SAMPLER_REFERENCE_COMPAT) {
+        uint64_t n = orc_compat_table_entries(opt);
+        hemi = (float*)malloc(sizeof(float) * 3 * (n ? n : 1));
+        orc_hemisphere_table(hemi, n);
+    }
+    int rc = 0;
+    for (uint32_t mi = 0; mi < scene->material_count && rc == 0; mi++) {
+        const AobMaterialDesc* mat = &scene->materials[mi];
+        if (mat->width <= 0 || mat->height <= 0) continue;
+        size_t cells = (size_t)mat->width * mat->height;
+        uint64_t cnt = orc_rasterize(scene, (int32_t)mi, opt, NULL, NULL, 0);
+        AobSurfel* surfels = (AobSurfel*)malloc(sizeof(AobSurfel) * (cnt ? cnt : 1));
+        uint32_t* sidx = (uint32_t*)malloc(sizeof(uint32_t) * (cnt ? cnt : 1));
+        orc_rasterize(scene, (int32_t)mi, opt, surfels, sidx, cnt);
+        AobResult* results = (AobResult*)calloc(cells, sizeof(AobResult));
+        rc = orc_trace(nodes, node_count, surfels, sidx, 0, cnt, opt, hemi, mat->width, mat->height, results, threads, stats);
+        if (rc == 0 && mat->data) orc_resolve(results, mat->width, mat->height, opt, mat->channels, mat->bytes_per_channel, mat->data);
+        free(results); free(sidx); free(surfels);
+    }
+    free(hemi); free(nodes); free(tris);
+    return rc;
+}

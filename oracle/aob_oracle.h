@@ -1,0 +1,115 @@
+/*
+ * aob_oracle.h — CPU restatement of the reference AO bake path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under aobaker_amd/ (the product) may
+ * include, link, load or call this.  Callers: tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg.
+ *
+ * PARITY UNPINNED: the reference (epicabsol/aobaker) has no tests, golden
+ * vectors or fixtures for this path, and neither its D3D11/HLSL pipeline nor
+ * the stripped RadeonRays 2.0 library can be built or run here (SURVEY.md
+ * §8(c)).  The oracle is pinned only by (i) the widely known MSVC rand()
+ * sequence the reference's sampler draws from, (ii) closed-form geometry
+ * (tests/test_oracle_*.py) and (iii) the in-tree OpenCL arithmetic it follows
+ * line by line (kernels/CL/common.cl, intersect_bvh2_lds.cl, build_hlbvh.cl).
+ *
+ * Every function cites the reference file:line it restates.  The POD types
+ * of the boundary (AobOptions, AobSceneDesc, AobSurfel, AobBvhNode,
+ * AobResult) come from include/aobaker.h so the same buffers can be handed
+ * to the oracle and to the HIP library.
+ */
+#ifndef AOB_ORACLE_H
+#define AOB_ORACLE_H
+
+#include "../include/aobaker.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- scalar primitives (exported for known-answer tests) ---------------- */
+
+/* MSVC CRT rand(): s = s*214013 + 2531011; return (s >> 16) & 0x7fff.
+ * The reference never seeds it (BakeEngine.cpp:316-317), so s starts at 1. */
+uint32_t orc_msvc_rand(uint32_t* state);
+/* D3D ftoi: truncate toward zero, NaN -> 0, saturate
+ * (the (int) casts at ProcessIntersectionsComputeShader.hlsl:87-88). */
+int32_t orc_ftoi(float v);
+uint16_t orc_f32_to_f16(float v, int mode /* AOB_FP16_RTZ | AOB_FP16_RNE */);
+float orc_f16_to_f32(uint16_t h);
+/* common.cl:177-218 with USE_SAFE_MATH (1.f/denom): returns t, or t_max on a miss. */
+float orc_intersect_triangle(const float o[3], const float d[3],
+                             const float v1[3], const float v2[3], const float v3[3],
+                             float t_max);
+/* common.cl:220-232 */
+void orc_safe_invdir(const float d[3], float invdir[3]);
+/* common.cl:236-246 / intersect_bvh2_lds.cl:54-63: out[0]=t0, out[1]=t1; hit iff t0<=t1 */
+void orc_intersect_bbox(const float pmin[3], const float pmax[3], const float invdir[3],
+                        const float oxinvdir[3], float t_max, float out[2]);
+/* The COSINE sampler: local-frame direction (x,z tangent, y normal) of sample i
+ * of the texel with linear index `texel`. */
+void orc_cosine_sample(uint32_t seed, uint32_t texel, int32_t i, int32_t sample_count, float out[3]);
+/* The polynomial sin/cos of 2*pi*u the COSINE sampler is defined with. */
+void orc_sincos2pi(float u, float* s, float* c);
+
+/* ---- stages ---------------------------------------------------------------- */
+
+/* BakeEngine.cpp:312-333: fills `count` local-frame directions (x, 1-sin, z). */
+void orc_hemisphere_table(float* out_xyz, uint64_t count);
+/* Entries of the table a bake with these options can index:
+ * min(ray_chunk_size / spp, 65535) * spp (BakeEngine.cpp:359-364). */
+uint64_t orc_compat_table_entries(const AobOptions* opt);
+
+/* World-space triangle soup of the whole scene in the order the reference
+ * attaches shapes (BakeEngine.cpp:370-398): 9 floats + shape id + prim id. */
+typedef struct OrcTriangle { float v[3][3]; uint32_t shape_id, prim_id; } OrcTriangle;
+uint64_t orc_scene_triangle_count(const AobSceneDesc* scene);
+void orc_scene_triangles(const AobSceneDesc* scene, OrcTriangle* out);
+
+/* LBVH (build_hlbvh.cl:69-314, 63-bit codes) emitted in the 64-byte
+ * traversal layout of intersect_bvh2_lds.cl:40-52.  `nodes` must hold
+ * max(1, 2n-1) entries.  Returns the node count; *depth = max leaf depth
+ * (root = depth 0). */
+uint64_t orc_bvh_build(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes, uint32_t* depth);
+
+/* UV rasterisation + texel extraction for one material
+ * (Rasterize{Vertex,Pixel}Shader.hlsl, BakeEngine.cpp:130-145,531-588).
+ * Writes up to `capacity` surfels (row-major per section, sections
+ * concatenated in scene order) and, per surfel, its index within its own
+ * section's list (the reference's chunk-local sample indexing needs it).
+ * Returns the number of surfels the material has (may exceed capacity). */
+uint64_t orc_rasterize(const AobSceneDesc* scene, int32_t material, const AobOptions* opt,
+                       AobSurfel* surfels, uint32_t* section_index, uint64_t capacity);
+
+typedef struct OrcTraceStats {
+    uint64_t rays;
+    uint64_t inner_visits;    /* inner-node fetches */
+    uint64_t leaf_visits;     /* leaf-node fetches (triangle tests) */
+    uint64_t hits;
+} OrcTraceStats;
+
+/* Ray generation + traversal + scoring + accumulation for surfels
+ * [begin,end) (GenerateRaysComputeShader.hlsl:31-55, intersect_bvh2_lds.cl,
+ * ProcessIntersectionsComputeShader.hlsl:52-92).  Accumulates (+=) into
+ * `results` (width*height cells).  `hemisphere` is the compat table (NULL
+ * for the COSINE sampler).  threads <= 1 runs inline. */
+int orc_trace(const AobBvhNode* nodes, uint64_t node_count,
+              const AobSurfel* surfels, const uint32_t* section_index,
+              uint64_t begin, uint64_t end,
+              const AobOptions* opt, const float* hemisphere,
+              int32_t width, int32_t height, AobResult* results,
+              int32_t threads, OrcTraceStats* stats);
+
+/* PostprocessPixelShader.hlsl:31-86 + the render-target format conversion
+ * (BakeEngine.cpp:482) + write-back layout (:705-709). */
+void orc_resolve(const AobResult* results, int32_t width, int32_t height, const AobOptions* opt,
+                 int32_t channels, int32_t bytes_per_channel, uint8_t* out);
+
+/* BakeEngine::Bake end to end (BakeEngine.cpp:335-751) into
+ * scene->materials[i].data. */
+int orc_bake(const AobSceneDesc* scene, const AobOptions* opt, int32_t threads, OrcTraceStats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,210 @@
+"""ctypes wrapper of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product (aobaker_amd/) never imports this.
+PARITY UNPINNED against the reference binary (see aob_oracle.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from aobaker_amd import capi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class OrcTraceStats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("inner_visits", C.c_uint64),
+                ("leaf_visits", C.c_uint64), ("hits", C.c_uint64)]
+
+
+TRIANGLE = np.dtype([("v", "<f4", (3, 3)), ("shape_id", "<u4"), ("prim_id", "<u4")])
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", _HERE, "liboracle.so"], check=True)
+
+
+def load():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = os.path.join(_HERE, "liboracle.so")
+    if not os.path.exists(path):
+        build()
+    lib = C.CDLL(path)
+    P, vp, u64, i32, u32, f32 = C.POINTER, C.c_void_p, C.c_uint64, C.c_int32, C.c_uint32, C.c_float
+    fp = P(f32)
+    sig = {
+        "orc_msvc_rand": (u32, [P(u32)]),
+        "orc_ftoi": (i32, [f32]),
+        "orc_f32_to_f16": (C.c_uint16, [f32, C.c_int]),
+        "orc_f16_to_f32": (f32, [C.c_uint16]),
+        "orc_intersect_triangle": (f32, [fp, fp, fp, fp, fp, f32]),
+        "orc_safe_invdir": (None, [fp, fp]),
+        "orc_intersect_bbox": (None, [fp, fp, fp, fp, f32, fp]),
+        "orc_cosine_sample": (None, [u32, u32, i32, i32, fp]),
+        "orc_sincos2pi": (None, [f32, fp, fp]),
+        "orc_hemisphere_table": (None, [vp, u64]),
+        "orc_compat_table_entries": (u64, [P(capi.AobOptions)]),
+        "orc_scene_triangle_count": (u64, [P(capi.AobSceneDesc)]),
+        "orc_scene_triangles": (None, [P(capi.AobSceneDesc), vp]),
+        "orc_bvh_build": (u64, [vp, u64, vp, P(u32)]),
+        "orc_rasterize": (u64, [P(capi.AobSceneDesc), i32, P(capi.AobOptions), vp, vp, u64]),
+        "orc_trace": (C.c_int, [vp, u64, vp, vp, u64, u64, P(capi.AobOptions), vp, i32, i32, vp, i32,
+                                P(OrcTraceStats)]),
+        "orc_resolve": (None, [vp, i32, i32, P(capi.AobOptions), i32, i32, vp]),
+        "orc_bake": (C.c_int, [P(capi.AobSceneDesc), P(capi.AobOptions), i32, P(OrcTraceStats)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _LIB = lib
+    return lib
+
+
+def _f3(a):
+    return (C.c_float * 3)(*[float(x) for x in a])
+
+
+def msvc_rand_sequence(n, state=1):
+    lib = load()
+    s = C.c_uint32(state)
+    return [lib.orc_msvc_rand(C.byref(s)) for _ in range(n)]
+
+
+def ftoi(v):
+    return load().orc_ftoi(C.c_float(v))
+
+
+def f32_to_f16(v, mode):
+    return load().orc_f32_to_f16(C.c_float(v), mode)
+
+
+def f16_to_f32(h):
+    return load().orc_f16_to_f32(C.c_uint16(h))
+
+
+def intersect_triangle(o, d, v1, v2, v3, t_max):
+    return load().orc_intersect_triangle(_f3(o), _f3(d), _f3(v1), _f3(v2), _f3(v3), C.c_float(t_max))
+
+
+def safe_invdir(d):
+    out = (C.c_float * 3)()
+    load().orc_safe_invdir(_f3(d), out)
+    return np.array(out[:], dtype=np.float32)
+
+
+def intersect_bbox(pmin, pmax, invdir, oxinvdir, t_max):
+    out = (C.c_float * 2)()
+    load().orc_intersect_bbox(_f3(pmin), _f3(pmax), _f3(invdir), _f3(oxinvdir), C.c_float(t_max), out)
+    return float(out[0]), float(out[1])
+
+
+def cosine_sample(seed, texel, i, spp):
+    out = (C.c_float * 3)()
+    load().orc_cosine_sample(seed, texel, i, spp, out)
+    return np.array(out[:], dtype=np.float32)
+
+
+def sincos2pi(u):
+    s, c = C.c_float(), C.c_float()
+    load().orc_sincos2pi(C.c_float(u), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def hemisphere_table(count):
+    out = np.empty((count, 3), dtype=np.float32)
+    load().orc_hemisphere_table(out.ctypes.data, count)
+    return out
+
+
+def compat_table(opt):
+    return hemisphere_table(int(load().orc_compat_table_entries(C.byref(opt))))
+
+
+def scene_triangles(desc):
+    lib = load()
+    n = int(lib.orc_scene_triangle_count(C.byref(desc)))
+    out = np.zeros(max(n, 1), dtype=TRIANGLE)
+    lib.orc_scene_triangles(C.byref(desc), out.ctypes.data)
+    return out[:n]
+
+
+def bvh_build(tris):
+    lib = load()
+    n = len(tris)
+    tris = np.ascontiguousarray(tris)
+    nodes = np.zeros(max(1, 2 * n), dtype=capi.node_dtype())
+    depth = C.c_uint32()
+    cnt = int(lib.orc_bvh_build(tris.ctypes.data, n, nodes.ctypes.data, C.byref(depth)))
+    return nodes[:cnt], depth.value
+
+
+def rasterize(desc, material, opt):
+    lib = load()
+    n = int(lib.orc_rasterize(C.byref(desc), material, C.byref(opt), None, None, 0))
+    surfels = np.zeros(max(n, 1), dtype=capi.surfel_dtype())
+    sidx = np.zeros(max(n, 1), dtype=np.uint32)
+    lib.orc_rasterize(C.byref(desc), material, C.byref(opt), surfels.ctypes.data, sidx.ctypes.data, n)
+    return surfels[:n], sidx[:n]
+
+
+def trace(nodes, surfels, section_index, opt, width, height, hemisphere=None, begin=0, end=None,
+          threads=1, results=None):
+    lib = load()
+    if end is None:
+        end = len(surfels)
+    if results is None:
+        results = np.zeros(width * height, dtype=capi.result_dtype())
+    stats = OrcTraceStats()
+    nodes = np.ascontiguousarray(nodes)
+    surfels = np.ascontiguousarray(surfels)
+    sidx = None if section_index is None else np.ascontiguousarray(section_index, dtype=np.uint32)
+    hemi = None if hemisphere is None else np.ascontiguousarray(hemisphere, dtype=np.float32)
+    rc = lib.orc_trace(nodes.ctypes.data if len(nodes) else None, len(nodes),
+                       surfels.ctypes.data if len(surfels) else None,
+                       None if sidx is None or not len(sidx) else sidx.ctypes.data,
+                       begin, end, C.byref(opt), None if hemi is None else hemi.ctypes.data,
+                       width, height, results.ctypes.data, threads, C.byref(stats))
+    if rc != 0:
+        raise RuntimeError(f"orc_trace failed: {rc}")
+    return results, stats
+
+
+def resolve(results, width, height, opt, channels=1, bpc=1):
+    out = np.zeros(width * height * channels * bpc, dtype=np.uint8)
+    results = np.ascontiguousarray(results)
+    load().orc_resolve(results.ctypes.data, width, height, C.byref(opt), channels, bpc, out.ctypes.data)
+    return out
+
+
+def bake(desc, opt, threads=1):
+    stats = OrcTraceStats()
+    rc = load().orc_bake(C.byref(desc), C.byref(opt), threads, C.byref(stats))
+    if rc != 0:
+        raise RuntimeError(f"orc_bake failed: {rc}")
+    return stats
+
+
+def default_options():
+    """The reference's constants (BakeEngine.cpp:13-18), stated independently of the library."""
+    o = capi.AobOptions()
+    o.sample_count = 100
+    o.sampler = capi.SAMPLER_REFERENCE_COMPAT
+    o.seed = 0
+    o.use_any_hit = 1
+    o.falloff_distance = 1.25
+    o.ray_tmax = 1000000.0
+    o.ray_bias = 0.001
+    o.bleed_distance = 5
+    o.accumulate = capi.ACCUMULATE_QUANTISED
+    o.normal_fp16 = capi.FP16_RTZ
+    o.ray_chunk_size = 0xFFFFFF
+    o.clamp_tmax_to_falloff = 0
+    return o

@@ -1,0 +1,206 @@
+"""GPU parity: every stage of the HIP path against the CPU oracle, through the C ABI.
+
+Bit-exact for integer/index work (coverage, surfel order, BVH topology, quantised sums, u8 image)
+and — because both sides follow one arithmetic contract — expected bit-exact for the
+float work too; the contractual tolerance for AO values is 1e-4 (BASELINE.json north_star) and is
+what the asserts enforce, with the number of non-identical texels reported.
+"""
+import numpy as np
+import pytest
+
+from aobaker_amd import Baker, capi, scenes
+from aobaker_amd.scene import FlatScene
+
+pytestmark = pytest.mark.gpu
+
+AO_TOL = 1e-4
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint8)
+
+
+def make_options(orc, **kw):
+    o = orc.default_options()
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+SCENES = {
+    "cube": lambda: scenes.cube_scene(64),
+    "cube_inward": lambda: scenes.cube_scene(64, inward=True),
+    "plane": lambda: scenes.plane_scene(32),
+    "two_section": lambda: scenes.two_section_scene(32),
+    "floor_wall": lambda: scenes.floor_wall_scene(32),
+    "sphere": lambda: scenes.sphere_scene(n=48, atlas=128),
+    "terrain": lambda: scenes.terrain_scene(grid=96, atlas=128),
+}
+
+
+@pytest.mark.parametrize("name", ["cube", "two_section", "sphere", "terrain", "floor_wall"])
+def test_bvh_nodes_bit_exact(engine, orc, name):
+    flat = FlatScene(SCENES[name]())
+    ref_nodes, ref_depth = orc.bvh_build(orc.scene_triangles(flat.desc))
+    with Baker(flat, make_options(orc)) as b:
+        b.build_bvh()
+        nodes = b.nodes()
+        st = b.stats()
+    assert len(nodes) == len(ref_nodes)
+    assert st.bvh_depth == ref_depth
+    assert st.triangle_count == flat.triangle_count()
+    assert bits(nodes).tobytes() == bits(ref_nodes).tobytes()
+
+
+@pytest.mark.parametrize("fp16", [capi.FP16_OFF, capi.FP16_RTZ, capi.FP16_RNE])
+@pytest.mark.parametrize("name", ["cube", "two_section", "sphere", "terrain"])
+def test_surfels_bit_exact(engine, orc, name, fp16):
+    flat = FlatScene(SCENES[name]())
+    opt = make_options(orc, normal_fp16=fp16)
+    ref, ref_idx = orc.rasterize(flat.desc, 0, opt)
+    with Baker(flat, opt) as b:
+        b.rasterize(0)
+        got = b.surfels(0)
+    assert len(got) == len(ref) > 0
+    assert bits(got).tobytes() == bits(ref).tobytes()
+
+
+MODES = [
+    dict(sampler=capi.SAMPLER_REFERENCE_COMPAT, accumulate=capi.ACCUMULATE_QUANTISED, use_any_hit=1),
+    dict(sampler=capi.SAMPLER_REFERENCE_COMPAT, accumulate=capi.ACCUMULATE_QUANTISED, use_any_hit=0),
+    dict(sampler=capi.SAMPLER_COSINE, accumulate=capi.ACCUMULATE_FLOAT, use_any_hit=1, seed=7),
+    dict(sampler=capi.SAMPLER_COSINE, accumulate=capi.ACCUMULATE_FLOAT, use_any_hit=0, seed=7,
+         clamp_tmax_to_falloff=1),
+    dict(sampler=capi.SAMPLER_COSINE, accumulate=capi.ACCUMULATE_QUANTISED, use_any_hit=1, seed=3),
+    dict(sampler=capi.SAMPLER_REFERENCE_COMPAT, accumulate=capi.ACCUMULATE_FLOAT, use_any_hit=0),
+]
+
+
+@pytest.mark.parametrize("mode", range(len(MODES)))
+@pytest.mark.parametrize("name", ["cube", "two_section", "sphere", "terrain", "cube_inward"])
+def test_trace_results_match_oracle(engine, orc, name, mode):
+    flat = FlatScene(SCENES[name]())
+    opt = make_options(orc, sample_count=24, **MODES[mode])
+    m = flat.material_array[0]
+    nodes, _ = orc.bvh_build(orc.scene_triangles(flat.desc))
+    surfels, sidx = orc.rasterize(flat.desc, 0, opt)
+    hemi = orc.compat_table(opt) if opt.sampler == capi.SAMPLER_REFERENCE_COMPAT else None
+    ref, stats = orc.trace(nodes, surfels, sidx, opt, m.width, m.height, hemi, threads=4)
+    with Baker(flat, opt) as b:
+        b.build_bvh()
+        b.rasterize(0)
+        b.trace(0)
+        got = b.results(0)
+    if opt.accumulate == capi.ACCUMULATE_QUANTISED:
+        assert np.array_equal(got["total_bits"], ref["total_bits"])
+        assert np.array_equal(got["weight_bits"], ref["weight_bits"])
+    else:
+        gt, gw = got["total_bits"].view(np.float32), got["weight_bits"].view(np.float32)
+        rt, rw = ref["total_bits"].view(np.float32), ref["weight_bits"].view(np.float32)
+        assert np.array_equal(gw != 0, rw != 0)
+        cov = rw != 0
+        err = np.abs(gt[cov] / gw[cov] - rt[cov] / rw[cov])
+        assert err.max() <= AO_TOL
+        # the arithmetic contract makes the sums themselves identical
+        assert np.array_equal(got["total_bits"], ref["total_bits"])
+        assert np.array_equal(got["weight_bits"], ref["weight_bits"])
+    assert stats.rays == len(surfels) * opt.sample_count
+
+
+@pytest.mark.parametrize("fmt", [(1, 1), (4, 1), (1, 2), (2, 2), (1, 4), (3, 4), (4, 4)])
+def test_resolve_formats(engine, orc, fmt):
+    channels, bpc = fmt
+    sc = scenes.cube_scene(64, channels=channels, bpc=bpc)
+    flat = FlatScene(sc)
+    opt = make_options(orc, sample_count=16)
+    m = flat.material_array[0]
+    with Baker(flat, opt) as b:
+        b.build_bvh(); b.rasterize(0); b.trace(0); b.resolve(0)
+        res = b.results(0)
+        img = np.zeros(m.width * m.height * channels * bpc, dtype=np.uint8)
+        b.download(0, img)
+    ref = orc.resolve(res, m.width, m.height, opt, channels, bpc)
+    assert np.array_equal(img, ref)
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("name", ["cube", "two_section", "terrain", "plane", "cube_inward"])
+def test_bake_end_to_end(engine, orc, name, mode):
+    """BakeEngine.Bake(scene) against orc_bake: the final texture bytes."""
+    opt = make_options(orc, sample_count=16, **MODES[mode])
+    bpc = 1 if opt.accumulate == capi.ACCUMULATE_QUANTISED else 4
+    mk = {"cube": lambda: scenes.cube_scene(64, bpc=bpc), "two_section": lambda: scenes.two_section_scene(32, bpc=bpc),
+          "terrain": lambda: scenes.terrain_scene(grid=96, atlas=128, bpc=bpc), "plane": lambda: scenes.plane_scene(32, bpc=bpc),
+          "cube_inward": lambda: scenes.cube_scene(64, inward=True, bpc=bpc)}[name]
+    gpu_scene, cpu_scene = mk(), mk()
+    engine.Options = opt
+    engine.Bake(gpu_scene)
+    orc.bake(FlatScene(cpu_scene).desc, opt, threads=4)
+    g = gpu_scene.GetMaterial(0).GetAOTexture()
+    c = cpu_scene.GetMaterial(0).GetAOTexture()
+    err = np.abs(g.ao() - c.ao()).max()
+    assert err <= AO_TOL
+    assert np.array_equal(g.GetData(), c.GetData())
+    if name == "plane":
+        assert (g.ao() == 1.0).all()            # nothing above an open plane
+    if name == "cube_inward" and bpc == 1:
+        assert (g.GetData()[g.GetData() != 0].size == 0)   # a closed cube is black inside
+
+
+def test_bake_texture_overload(engine, orc):
+    """Bake(Scene*, BakeTexture*): only the named material's texture is written."""
+    from aobaker_amd.scene import BakeObject, MaterialObject, RenderMesh, Scene, Section, make_vertices
+    sc = Scene()
+    a = sc.AddMaterial(MaterialObject("A", 32, 32))
+    b_ = sc.AddMaterial(MaterialObject("B", 16, 16))
+    q1 = scenes.quad((0, 0, 0), (1, 0, 0), (1, 0, 1), (0, 0, 1), (0, 1, 0))
+    q2 = scenes.quad((0, 0.3, 0), (1, 0.3, 0), (1, 0.3, 1), (0, 0.3, 1), (0, 1, 0))
+    o = sc.AddObject(BakeObject("O"))
+    o.AddSection(Section("a", RenderMesh(make_vertices(*q1[:3]), q1[3]), a))
+    o.AddSection(Section("b", RenderMesh(make_vertices(*q2[:3]), q2[3]), b_))
+    engine.Options = make_options(orc, sample_count=8)
+    engine.Bake(sc, b_.GetAOTexture())
+    assert (a.GetAOTexture().GetData() == 0xFF).all()          # untouched (BakeTexture.cpp:63)
+    assert (b_.GetAOTexture().GetData() == 255).all()          # top quad sees the sky
+    engine.Bake(sc, a.GetAOTexture())
+    assert a.GetAOTexture().ao()[16, 16] < 0.35                # the bottom quad sits under the top one
+    assert (b_.GetAOTexture().GetData() == 255).all()
+
+
+def test_empty_and_degenerate_inputs(engine, orc):
+    from aobaker_amd.scene import BakeObject, MaterialObject, RenderMesh, Scene, Section, make_vertices
+    opt = make_options(orc, sample_count=4)
+    # no meshes at all: every material is written black (BakeEngine.cpp:404-709 with no sections)
+    sc = Scene(); sc.AddMaterial(MaterialObject("A", 8, 8))
+    engine.Options = opt
+    engine.Bake(sc)
+    assert (sc.GetMaterial(0).GetAOTexture().GetData() == 0).all()
+    # degenerate triangles only (the reference's import bug feeds (0,0,0) triangles, BakeObject.cpp:96)
+    p = np.zeros((3, 3), np.float32); n = np.tile(np.float32([0, 1, 0]), (3, 1)); uv = np.zeros((3, 2), np.float32)
+    sc = Scene(); m = sc.AddMaterial(MaterialObject("A", 8, 8))
+    o = sc.AddObject(BakeObject("O")); o.AddSection(Section("s", RenderMesh(make_vertices(p, n, uv), np.uint32([0, 0, 0, 0, 1, 2])), m))
+    engine.Bake(sc)
+    assert (m.GetAOTexture().GetData() == 0).all()
+    # zero normals (LoadFromCube's fixture, BakeObject.cpp:197-207): NaN frame, contributes nothing
+    q = scenes.quad((0, 0, 0), (1, 0, 0), (1, 0, 1), (0, 0, 1), (0, 0, 0))
+    sc = Scene(); m = sc.AddMaterial(MaterialObject("A", 8, 8))
+    o = sc.AddObject(BakeObject("O")); o.AddSection(Section("s", RenderMesh(make_vertices(*q[:3]), q[3]), m))
+    engine.Bake(sc)
+    cpu = Scene(); mc = cpu.AddMaterial(MaterialObject("A", 8, 8))
+    oc = cpu.AddObject(BakeObject("O")); oc.AddSection(Section("s", RenderMesh(make_vertices(*q[:3]), q[3]), mc))
+    orc.bake(FlatScene(cpu).desc, opt)
+    assert np.array_equal(m.GetAOTexture().GetData(), mc.GetAOTexture().GetData())
+
+
+def test_invalid_arguments_are_reported(engine, orc):
+    flat = FlatScene(scenes.plane_scene(8))
+    opt = make_options(orc, sample_count=0)
+    with pytest.raises(capi.AobError) as e:
+        Baker(flat, opt)
+    assert e.value.code == -1 and "sample_count" in str(e.value)
+    opt = make_options(orc)
+    with Baker(flat, opt) as b:
+        with pytest.raises(capi.AobError):
+            b.trace(0)                      # BVH not built yet
+        with pytest.raises(capi.AobError):
+            b.rasterize(3)                  # no such material
