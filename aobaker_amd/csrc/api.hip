@@ -138,7 +138,7 @@ void aob_default_options(AobOptions* o)
     o->ray_bias = 0.001f;
     o->bleed_distance = 5;
     o->accumulate = AOB_ACCUMULATE_QUANTISED;
-    o->normal_fp16 = AOB_FP16_RTZ;
+    o->normal_fp16 = AOB_FP16_RNE;
     o->ray_chunk_size = 0xFFFFFF;
     o->clamp_tmax_to_falloff = 0;
 }

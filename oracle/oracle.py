@@ -204,7 +204,7 @@ def default_options():
     o.ray_bias = 0.001
     o.bleed_distance = 5
     o.accumulate = capi.ACCUMULATE_QUANTISED
-    o.normal_fp16 = capi.FP16_RTZ
+    o.normal_fp16 = capi.FP16_RNE
     o.ray_chunk_size = 0xFFFFFF
     o.clamp_tmax_to_falloff = 0
     return o
