@@ -135,6 +135,7 @@ EXPORTED_SYMBOLS = [
     "aob_bake_node_count", "aob_bake_copy_nodes", "aob_bake_surfel_count",
     "aob_bake_copy_surfels", "aob_bake_copy_results", "aob_bake_results_device_ptr",
     "aob_bake_image_device_ptr", "aob_bake_stream", "aob_bake_last_trace_ms",
+    "aob_bake_surfel_cell_range",
 ]
 
 
@@ -191,6 +192,7 @@ def load() -> C.CDLL:
         "aob_bake_image_device_ptr": (C.c_int, [vp, i32, P(vp), P(u64)]),
         "aob_bake_stream": (C.c_int, [vp, P(vp)]),
         "aob_bake_last_trace_ms": (C.c_int, [vp, P(C.c_float)]),
+        "aob_bake_surfel_cell_range": (C.c_int, [vp, i32, u64, u64, P(u64), P(u64), P(i32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

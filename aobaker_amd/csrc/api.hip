@@ -463,6 +463,24 @@ int aob_bake_copy_results(AobBake* b, int32_t material, AobResult* dst, uint64_t
     return AOB_OK;
 }
 
+int aob_bake_surfel_cell_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end,
+                               uint64_t* first_cell, uint64_t* last_cell, int32_t* overlapping)
+{
+    AOB_TRY(check_bake(b, material, true));
+    DeviceMaterial& m = b->materials[material];
+    if (end > m.surfel_count) end = m.surfel_count;
+    if (!first_cell || !last_cell) { set_error("first_cell/last_cell is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
+    if (overlapping) *overlapping = m.section_offsets.size() > 2 ? 1 : 0;
+    if (begin >= end) { *first_cell = 1; *last_cell = 0; return AOB_OK; }      // empty range
+    AobSurfel ends[2];
+    AOB_HIP(hipMemcpyAsync(&ends[0], m.surfels + begin, sizeof(AobSurfel), hipMemcpyDeviceToHost, b->stream));
+    AOB_HIP(hipMemcpyAsync(&ends[1], m.surfels + (end - 1), sizeof(AobSurfel), hipMemcpyDeviceToHost, b->stream));
+    AOB_HIP(hipStreamSynchronize(b->stream));
+    *first_cell = (uint64_t)ends[0].texel_y * m.width + ends[0].texel_x;
+    *last_cell = (uint64_t)ends[1].texel_y * m.width + ends[1].texel_x;
+    return AOB_OK;
+}
+
 int aob_bake_results_device_ptr(AobBake* b, int32_t material, void** ptr, uint64_t* bytes)
 {
     AOB_TRY(check_bake(b, material, true));

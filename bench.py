@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py — AO rays/s of the bake hot path on MI355X (BASELINE.json metric).
+
+A step is one full device-side bake of the workload with the scene already resident in HBM:
+LBVH build -> UV rasterise + compact -> fused trace -> (N>1: gather of texel strips to rank 0)
+-> resolve + bleed.  value = rays all ranks cast / max-over-ranks step time.
+
+N=1 workload = BASELINE configs[2]: synthetic 999 698-triangle terrain, 2048^2 atlas, 256 spp,
+COSINE sampler, any-hit scoring, float accumulation.  N>1 is weak scaling: the atlas grows to
+N x 2048^2 texels (N=4 is configs[3]'s 4096^2) and each rank traces an equal strip.
+
+The JSON line also carries
+  roofline     the trace kernel against HBM peak, ALGORITHMIC bytes:
+               B_ray = 64*(n_inner+n_leaf) + 40/spp, node visits counted by the CPU oracle on
+               a texel subsample of the same rays; kernel time from HIP events on the library's
+               own stream.  frac can exceed 1: every node visit is counted as memory traffic
+               although most are served by L1/L2/Infinity Cache — `traffic` is what reaches HBM.
+  cpu_baseline the CPU oracle (a port, oracle/) timed on this box's host cores on a bounded
+               texel subsample of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--atlas", type=int, default=2048)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--grid", type=int, default=708, help="terrain grid (708 -> 999 698 triangles)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+
+    import torch                       # first: one HIP runtime for torch and the library
+    import torch.distributed as dist
+    import numpy as np
+    from aobaker_amd import BakeEngine, Baker, capi, scenes
+    from aobaker_amd import dist as aod
+    from aobaker_amd.scene import FlatScene
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    W, H = aod.weak_scaling_atlas(args.atlas, world)
+    scene = scenes.terrain_scene(grid=args.grid, atlas=(W, H), seed=3, bpc=4)
+    flat = FlatScene(scene)
+    BakeEngine.Init(local_rank)
+    opts = capi.default_options()
+    opts.sample_count = args.spp
+    opts.sampler = capi.SAMPLER_COSINE
+    opts.seed = 3
+    opts.use_any_hit = 1
+    opts.accumulate = capi.ACCUMULATE_FLOAT
+    opts.normal_fp16 = capi.FP16_OFF
+
+    baker = Baker(flat, opts)           # uploads the scene: inputs resident in HBM from here on
+    cells = aod.alias_results(baker, 0, as_float=True) if world > 1 else None
+    trace_ms = []
+    counts = {}
+
+    def step():
+        baker.build_bvh()
+        baker.rasterize(0)
+        n = baker.surfel_count(0)
+        begin, end = aod.shard_range(n, rank, world)
+        baker.trace(0, begin, end)
+        if world > 1:
+            c0, c1, overlapping = baker.surfel_cell_range(0, begin, end)   # syncs the stream
+            aod.gather_strips(cells, (c0, c1), rank, world, 0, overlapping)
+            torch.cuda.synchronize()
+        if rank == 0:
+            baker.resolve(0)
+        baker.sync()
+        trace_ms.append(baker.last_trace_ms())
+        counts["surfels"] = n
+        counts["mine"] = end - begin
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        baker.sync()
+
+    for _ in range(args.warmup):
+        step()
+    trace_ms.clear()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    stats = baker.stats()
+    total_rays = counts["surfels"] * args.spp                  # all ranks together
+    my_rays = counts["mine"] * args.spp
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_rays / (elapsed / args.steps)
+    kernel_ms = sum(trace_ms) / len(trace_ms)
+
+    cpu = None
+    roofline = None
+    if rank == 0:
+        n_visits = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu, n_visits = cpu_baseline(flat, opts, W, H, args.cpu_seconds)
+        if n_visits is None:
+            n_visits = visits_per_ray(flat, opts, W, H)
+        b_ray = 64.0 * n_visits + 40.0 / args.spp
+        achieved = my_rays * b_ray / (kernel_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(),
+                    "kernel": "k_trace", "kernel_ms": round(kernel_ms, 3),
+                    "bytes_per_ray": round(b_ray, 1), "node_visits_per_ray": round(n_visits, 3),
+                    "rays_per_launch": my_rays}
+        line = {
+            "metric": "AO rays/sec", "value": value, "unit": "rays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"terrain {flat.triangle_count()} tris, {W}x{H} atlas, {args.spp} spp, "
+                                   f"cosine sampler, any-hit, float accumulate (BASELINE configs[2]"
+                                   f"{' scaled: N x 2048^2 texels' if world > 1 else ''})",
+                       "triangles": flat.triangle_count(), "atlas": [W, H], "spp": args.spp,
+                       "surfels": counts["surfels"], "rays": total_rays, "sharding": f"texel strips x{world}",
+                       "bvh_nodes": stats.node_count, "bvh_depth": stats.bvh_depth},
+            "stage_ms": {"bvh_build": round(stats.ms_bvh_build, 3), "trace_kernel": round(kernel_ms, 3)},
+            "bake_wallclock_ms": round(ms_per_step, 3),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    baker.close()
+    BakeEngine.Dispose()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _oracle_inputs(flat, opts):
+    from oracle import oracle as orc
+    tris = orc.scene_triangles(flat.desc)
+    nodes, _ = orc.bvh_build(tris)
+    surfels, _ = orc.rasterize(flat.desc, 0, opts)
+    return orc, nodes, surfels
+
+
+def _subsample(surfels, stride):
+    import numpy as np
+    keep = (surfels["texel_x"] % stride == 0) & (surfels["texel_y"] % stride == 0)
+    return np.ascontiguousarray(surfels[keep])
+
+
+def visits_per_ray(flat, opts, W, H):
+    """Mean BVH node fetches per ray, counted by the oracle on every 32nd texel in x and y."""
+    orc, nodes, surfels = _oracle_inputs(flat, opts)
+    sub = _subsample(surfels, 32)
+    _, st = orc.trace(nodes, sub, None, opts, W, H, threads=os.cpu_count() or 1)
+    return (st.inner_visits + st.leaf_visits) / max(1, st.rays)
+
+
+def cpu_baseline(flat, opts, W, H, seconds):
+    """The CPU oracle on the same BVH, sampler and rays, on a bounded texel subsample."""
+    cores = os.cpu_count() or 1
+    orc, nodes, surfels = _oracle_inputs(flat, opts)
+    probe = _subsample(surfels, 64)
+    t = time.perf_counter()
+    _, st = orc.trace(nodes, probe, None, opts, W, H, threads=cores)
+    rate = st.rays / max(1e-9, time.perf_counter() - t)
+    want = rate * seconds
+    stride = 64
+    while stride > 1 and len(surfels) / (stride // 2) ** 2 * opts.sample_count <= want:
+        stride //= 2
+    sub = _subsample(surfels, stride)
+    t = time.perf_counter()
+    _, st = orc.trace(nodes, sub, None, opts, W, H, threads=cores)
+    dt = time.perf_counter() - t
+    visits = (st.inner_visits + st.leaf_visits) / max(1, st.rays)
+    return ({"value": st.rays / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+             "sample": f"every {stride}th texel in x and y of the same atlas ({len(sub)} surfels, {st.rays} rays, "
+                       f"{dt:.1f} s); trace stage only, same BVH/sampler/rays as the GPU",
+             "extrapolated_full_trace_s": len(surfels) * opts.sample_count / (st.rays / dt)}, visits)
+
+
+def measured_traffic():
+    """HBM bytes per k_trace launch from the committed rocprofv3 PMC passes (profiles/), or None."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(p):
+        try:
+            with open(p) as f:
+                return json.load(f).get("k_trace_hbm_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+if __name__ == "__main__":
+    main()

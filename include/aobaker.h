@@ -205,6 +205,12 @@ int aob_bake_copy_nodes(AobBake* bake, AobBvhNode* dst, uint64_t capacity);
 int aob_bake_surfel_count(AobBake* bake, int32_t material, uint64_t* count);
 int aob_bake_copy_surfels(AobBake* bake, int32_t material, AobSurfel* dst, uint64_t capacity);
 int aob_bake_copy_results(AobBake* bake, int32_t material, AobResult* dst, uint64_t capacity);
+/* First and last result cell (y*W+x) touched by surfels [begin,end): with a single section the
+ * surfel list is row-major, so disjoint surfel ranges own disjoint, ordered cell ranges — the
+ * "texel tiles" a multi-GPU bake gathers.  *overlapping is set when the material has several
+ * sections (their cell ranges may interleave; the caller must then reduce instead of gather). */
+int aob_bake_surfel_cell_range(AobBake* bake, int32_t material, uint64_t begin, uint64_t end,
+                               uint64_t* first_cell, uint64_t* last_cell, int32_t* overlapping);
 /* Device address of the material's W*H AobResult buffer (for an RCCL
  * collective issued by the caller) and of its resolved image. */
 int aob_bake_results_device_ptr(AobBake* bake, int32_t material, void** ptr, uint64_t* bytes);
