@@ -49,6 +49,7 @@ struct DeviceMaterial {
     uint32_t  scan_blocks = 0;
     AobSurfel* surfels = nullptr;         // concatenated, row-major per section
     uint32_t* section_index = nullptr;    // surfel -> index inside its section's list
+    float4*   frames = nullptr;           // 64 B per surfel: P, N, tangent frame X/Z, texel, sample-table base, valid
     uint64_t  surfel_capacity = 0, surfel_count = 0;
     std::vector<uint64_t> section_offsets; // prefix offsets per contributing mesh (+ total)
     std::vector<uint32_t> section_mesh;
@@ -83,6 +84,9 @@ struct AobBake {
     bool bvh_built = false, depth_known = false, bvh_timed = false;
     uint32_t* pinned = nullptr;         // 64 B of pinned host memory for small read-backs
 
+    uint32_t* gstack = nullptr;         // traversal stacks in HBM, only for trees deeper than 62 levels
+    uint64_t gstack_words = 0;
+
     float* hemisphere = nullptr;        // compat sampler table (float3 packed)
     uint64_t hemisphere_entries = 0;
 
@@ -98,4 +102,5 @@ int build_bvh(AobBake* b);                                   // bvh_build.hip
 int rasterize_material(AobBake* b, int32_t material);        // raster.hip (syncs once per section)
 int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end);   // trace.hip
 int resolve_material(AobBake* b, int32_t material);          // resolve.hip
+uint64_t chunk_texel_max(const AobOptions& opt);             // trace.hip (BakeEngine.cpp:359-364)
 }

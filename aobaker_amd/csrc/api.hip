@@ -25,7 +25,6 @@ void set_error(const char* fmt, ...)
     va_end(ap);
 }
 
-uint64_t chunk_texel_max(const AobOptions& opt);   // trace.hip
 
 // BakeEngine.cpp:312-333 with the MSVC CRT rand() the reference draws from (never seeded, so
 // the state starts at 1): x = sin(theta)cos(phi), z = sin(theta)sin(phi), y = 1 - sin(theta).
@@ -80,14 +79,14 @@ static void free_bake(AobBake* b)
     if (!b) return;
     for (auto& m : b->meshes) { hipFree(m.positions); hipFree(m.normals); hipFree(m.uvs); hipFree(m.indices); }
     for (auto& m : b->materials) {
-        hipFree(m.cover); hipFree(m.block_sums); hipFree(m.surfels); hipFree(m.section_index);
+        hipFree(m.cover); hipFree(m.block_sums); hipFree(m.surfels); hipFree(m.section_index); hipFree(m.frames);
         hipFree(m.results); hipFree(m.image);
     }
     hipFree(b->tri_verts); hipFree(b->prim_bounds); hipFree(b->scene_bounds_enc);
     hipFree(b->codes[0]); hipFree(b->codes[1]); hipFree(b->prim_idx[0]); hipFree(b->prim_idx[1]);
     hipFree(b->sort_temp); hipFree(b->child_left); hipFree(b->child_right); hipFree(b->parent);
     hipFree(b->node_bounds); hipFree(b->refit_flags); hipFree(b->depth_dev); hipFree(b->nodes);
-    hipFree(b->hemisphere);
+    hipFree(b->hemisphere); hipFree(b->gstack);
     if (b->pinned) hipHostFree(b->pinned);
     for (auto& e : b->ev) if (e) hipEventDestroy(e);
     for (auto& e : b->ev_trace) if (e) hipEventDestroy(e);
@@ -276,6 +275,7 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
         AOB_C(dev_alloc(&d.image, cells * d.channels * d.bytes_per_channel));
         AOB_C(dev_alloc(&d.surfels, cells));
         AOB_C(dev_alloc(&d.section_index, cells));
+        AOB_C(dev_alloc(&d.frames, 4 * cells));
         d.surfel_capacity = cells;
         AOB_CH(hipMemsetAsync(d.results, 0, sizeof(AobResult) * cells, b->stream));
         d.section_offsets.push_back(0);

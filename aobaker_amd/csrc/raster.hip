@@ -210,22 +210,56 @@ void k_emit_surfels(const uint32_t* __restrict__ cover, uint64_t cells, const ui
     }
 }
 
+// Per-surfel trace record: everything the trace kernel needs when a lane picks up a block of
+// samples of an arbitrary surfel of its wave — position, normal, the tangent frame of
+// GenerateRaysComputeShader.hlsl:34-41, the result cell and the base of the surfel's run in the
+// compat hemisphere table (Hemisphere[DTid.x * SampleCount + i] with DTid.x chunk-local, :45).
+// A surfel with a non-finite frame or an out-of-range texel is flagged invalid: all its weights
+// would be NaN, and (int)NaN == 0 in HLSL, so it contributes nothing.
+__global__ __launch_bounds__(kBlock)
+void k_surfel_frames(const AobSurfel* __restrict__ surfels, const uint32_t* __restrict__ section_index, uint64_t count,
+                     int32_t W, int32_t H, uint32_t chunk_max, uint32_t spp, float4* __restrict__ frames)
+{
+    uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= count) return;
+    AobSurfel sf = surfels[k];
+    const f3 P = make_f3(sf.position[0], sf.position[1], sf.position[2]);
+    const f3 N = make_f3(sf.normal[0], sf.normal[1], sf.normal[2]);
+    f3 X = make_f3(1.0f, 0.0f, 0.0f), Z = make_f3(0.0f, 0.0f, 1.0f);
+    if (N.y < 0.9999f && N.y > -0.9999f) {
+        X = normalize(make_f3(-N.z, 0.0f, N.x));          // cross(N, (0,1,0))
+        Z = normalize(cross(X, N));
+    }
+    bool valid = sf.texel_x >= 0 && sf.texel_y >= 0 && sf.texel_x < W && sf.texel_y < H &&
+                 finite3(P) && finite3(N) && finite3(X) && finite3(Z);
+    uint32_t texel = (uint32_t)sf.texel_y * (uint32_t)W + (uint32_t)sf.texel_x;
+    uint32_t table_base = (section_index[k] % chunk_max) * spp;
+    float4* out = frames + 4ull * k;
+    out[0] = make_float4(P.x, P.y, P.z, N.x);
+    out[1] = make_float4(N.y, N.z, X.x, X.y);
+    out[2] = make_float4(X.z, Z.x, Z.y, Z.z);
+    out[3] = make_float4(__uint_as_float(texel), __uint_as_float(table_base), __uint_as_float(valid ? 1u : 0u), 0.0f);
+}
+
 static int ensure_surfel_capacity(AobBake* b, DeviceMaterial& m, uint64_t need)
 {
     if (need <= m.surfel_capacity) return AOB_OK;
     uint64_t cap = m.surfel_capacity ? m.surfel_capacity : (uint64_t)m.width * m.height;
     while (cap < need) cap *= 2;
-    AobSurfel* ns = nullptr; uint32_t* ni = nullptr;
+    AobSurfel* ns = nullptr; uint32_t* ni = nullptr; float4* nf = nullptr;
     AOB_HIP(hipMalloc((void**)&ns, sizeof(AobSurfel) * cap));
     AOB_HIP(hipMalloc((void**)&ni, sizeof(uint32_t) * cap));
+    AOB_HIP(hipMalloc((void**)&nf, sizeof(float4) * 4 * cap));
     if (m.surfel_count) {
         AOB_HIP(hipMemcpyAsync(ns, m.surfels, sizeof(AobSurfel) * m.surfel_count, hipMemcpyDeviceToDevice, b->stream));
         AOB_HIP(hipMemcpyAsync(ni, m.section_index, sizeof(uint32_t) * m.surfel_count, hipMemcpyDeviceToDevice, b->stream));
+        AOB_HIP(hipMemcpyAsync(nf, m.frames, sizeof(float4) * 4 * m.surfel_count, hipMemcpyDeviceToDevice, b->stream));
         AOB_HIP(hipStreamSynchronize(b->stream));
     }
     if (m.surfels) AOB_HIP(hipFree(m.surfels));
     if (m.section_index) AOB_HIP(hipFree(m.section_index));
-    m.surfels = ns; m.section_index = ni; m.surfel_capacity = cap;
+    if (m.frames) AOB_HIP(hipFree(m.frames));
+    m.surfels = ns; m.section_index = ni; m.frames = nf; m.surfel_capacity = cap;
     return AOB_OK;
 }
 
@@ -261,6 +295,10 @@ int rasterize_material(AobBake* b, int32_t material)
             hipLaunchKernelGGL(k_emit_surfels, dim3(nblocks), dim3(kBlock), 0, s, m.cover, cells, m.block_sums,
                                mesh.positions, mesh.normals, mesh.uvs, mesh.indices, xf, m.width, m.height,
                                b->opt.normal_fp16, m.surfels + m.surfel_count, m.section_index + m.surfel_count);
+            hipLaunchKernelGGL(k_surfel_frames, dim3((uint32_t)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                               m.surfels + m.surfel_count, m.section_index + m.surfel_count, count, m.width, m.height,
+                               (uint32_t)chunk_texel_max(b->opt), (uint32_t)b->opt.sample_count,
+                               m.frames + 4ull * m.surfel_count);
         }
         m.surfel_count += count;
         m.section_offsets.push_back(m.surfel_count);

@@ -4,53 +4,80 @@
 //   GenerateRaysComputeShader.hlsl:31-55   (48-byte ray records, numthreads(1,1,1))
 //   IntersectionApi::QueryIntersection     (RadeonRays; kernels/CL/intersect_bvh2_lds.cl)
 //   ProcessIntersectionsComputeShader.hlsl:52-92 (2 atomics per sample, numthreads(1,1,1))
-// with ONE kernel in which a lane owns a surfel: it generates each of its rays in
-// registers (no ray or hit records ever reach HBM), walks the 64-byte-node BVH2 with
-// the reference's near-child-first order and a per-lane LDS stack
-// (intersect_bvh2_lds.cl:78,123-153), scores the result and keeps the two running sums
-// in registers; the texel's result cell is written once, without atomics.
+// with ONE kernel: rays are generated in registers (no ray or hit records ever reach
+// HBM), walk the 64-byte-node BVH2 with the reference's near-child-first order and a
+// per-lane LDS stack (intersect_bvh2_lds.cl:78,123-153), are scored in registers, and
+// each texel's result cell is written once.
 //
-// Wavefront-level scheduling: lanes run asynchronously through their sample lists.
-// A lane whose ray has terminated (any-hit vote or empty stack) idles only until
-// kRefillIdle lanes of its wave are idle, then all idle lanes generate their next ray
-// together — the while-while / ray-refetch scheme, with __ballot as the vote.
+// Work distribution.  A wavefront owns 64 consecutive surfels; their samples form a pool
+// of (surfel, sample block) items — 16 blocks per surfel — that the wave's lanes draw
+// from with a wave-uniform counter (__ballot + mbcnt ranking, no atomics, no LDS queue).
+// A lane that finishes its block early takes the next item of ANY surfel of its wave, so
+// lanes whose surfels have cheap rays do not idle behind the expensive ones.  Per-surfel
+// sums live in LDS as 64-bit integers (int32-range quantised sums in the reference's mode,
+// exact Q32.32 sums in float mode), which makes the result independent of which lane
+// traced which block, and bit-identical to the oracle's sequential loop.
 //
-// The hot data is the node array (64 B per visit, shared by neighbouring lanes of a
-// wave and served from L1/L2/Infinity Cache); the surfel read (40 B) and the result
-// write (8 B) happen once per spp rays.
+// Wave scheduling (the kernel is VALU-issue bound, not HBM bound — see profiles/): one
+// loop whose three sections are entered on wave-wide votes:
+//   refill   idle lanes pick their next ray (and, at block ends, their next item) once
+//            `refill_idle` of them are waiting;
+//   leaf     lanes parked at a leaf (leaf-ness is known from the address alone: leaves
+//            live at [leaf_base, 2n-1)) run Möller–Trumbore once `leaf_wait` are waiting;
+//   inner    every lane at an inner node does its two slab tests each iteration.
+// Keeping the leaf test out of the common iteration stops the 64 lanes from serialising
+// both code paths every step.  Each ray still visits its nodes in exactly the reference's
+// depth-first order, so the per-ray arithmetic — and the result — does not depend on it.
+//
+// The hot data is the node array (64 B per inner visit, 48 B per leaf visit, shared by
+// neighbouring lanes and served from L1/L2/Infinity Cache); the per-surfel record (64 B)
+// is read once per sample block and the result cell (8 B) written once per surfel.
 #include "aob_internal.h"
 #include "aob_math.h"
+
+#include <cstdlib>
 
 namespace aob {
 
 static constexpr int kBlock = 256;
-static constexpr int kLdsStack = 16;          // entries per lane kept in LDS
-static constexpr int kRefillIdle = 16;        // idle lanes that trigger a wave-wide refill
+static constexpr int kBlocksPerSurfel = 16;       // sample blocks per surfel
 static constexpr uint32_t kInvalid = 0xffffffffu;
 
 struct TraceParams {
     const float4* nodes;
-    const AobSurfel* surfels;
-    const uint32_t* section_index;
+    const float4* frames;          // 4 x float4 per surfel (k_surfel_frames)
     AobResult* results;
     const float* hemisphere;
+    uint32_t* gstack;              // overflow stack in HBM: entries beyond the LDS stack
     uint64_t begin, end;
     uint32_t node_count;
-    uint32_t chunk_max;
-    int32_t width, height;
+    uint32_t leaf_base;            // first leaf address (n - 1)
     int32_t spp;
+    int32_t block_samples;         // ceil(spp / kBlocksPerSurfel)
     uint32_t seed_hash;
     float tmax, bias, falloff;
     CosineGrid grid;
     uint32_t nblocks, blocks_per_xcd;
+    int32_t refill_idle;           // idle lanes that trigger the refill section
+    int32_t leaf_wait;             // lanes parked at a leaf that trigger the leaf section
 };
 
-template <int SAMPLER, int ANYHIT, int ACCUM, int OVF>
+// exact float -> Q32.32 (a float times 2^32 is exact; the conversion truncates)
+__device__ __forceinline__ long long f2fix(float v)
+{
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) v = 2147483520.0f;
+    if (v <= -2147483648.0f) v = -2147483520.0f;
+    return (long long)(v * 4294967296.0f);
+}
+
+// LDS_N: stack entries per lane kept in LDS; deeper entries spill to p.gstack.
+template <int SAMPLER, int ANYHIT, int ACCUM, int LDS_N>
 __global__ __launch_bounds__(kBlock)
 void k_trace(TraceParams p)
 {
-    __shared__ uint32_t lds_stack[kLdsStack * kBlock];
-    uint32_t ovf[OVF];
+    __shared__ uint32_t lds_stack[LDS_N * kBlock];
+    __shared__ unsigned long long acc[kBlock][2];       // per surfel of this block: total, weight
 
     // Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8).  Give each XCD
     // a contiguous run of surfel tiles so that its private 4 MiB L2 keeps seeing the same part
@@ -58,160 +85,199 @@ void k_trace(TraceParams p)
     const uint32_t lb = (blockIdx.x & 7u) * p.blocks_per_xcd + (blockIdx.x >> 3);
     if (lb >= p.nblocks) return;
     const uint32_t tid = threadIdx.x;
-    const uint64_t k = p.begin + (uint64_t)lb * kBlock + tid;
-    bool valid = k < p.end;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    const uint64_t wave_first = p.begin + (uint64_t)lb * kBlock + (uint64_t)wave * 64u;   // first surfel of this wave
+    const uint32_t nsurf = wave_first >= p.end ? 0u : (uint32_t)min((uint64_t)64, p.end - wave_first);
+    const uint32_t total_items = nsurf ? 64u * kBlocksPerSurfel : 0u;      // item = block * 64 + surfel slot
+    uint32_t item_next = 0;                                                // wave-uniform
 
-    AobSurfel sf;
-    if (valid) sf = p.surfels[k];
-    else { sf.texel_x = sf.texel_y = 0; sf.position[0] = sf.position[1] = sf.position[2] = 0.f; sf.normal[0] = sf.normal[2] = 0.f; sf.normal[1] = 1.f; }
-    const f3 P = make_f3(sf.position[0], sf.position[1], sf.position[2]);
-    const f3 N = make_f3(sf.normal[0], sf.normal[1], sf.normal[2]);
-    valid = valid && sf.texel_x >= 0 && sf.texel_y >= 0 && sf.texel_x < p.width && sf.texel_y < p.height;
-    // GenerateRaysComputeShader.hlsl:34-41
-    f3 X = make_f3(1.0f, 0.0f, 0.0f), Z = make_f3(0.0f, 0.0f, 1.0f);
-    if (N.y < 0.9999f && N.y > -0.9999f) {
-        X = normalize(make_f3(-N.z, 0.0f, N.x));          // cross(N, (0,1,0))
-        Z = normalize(cross(X, N));
-    }
-    // a non-finite frame gives NaN weights, and (int)NaN == 0 in HLSL: such a surfel adds nothing
-    valid = valid && finite3(P) && finite3(N) && finite3(X) && finite3(Z);
+    acc[tid][0] = 0ull; acc[tid][1] = 0ull;
+    lds_stack[tid] = kInvalid;       // entry 0: the INVALID sentinel (intersect_bvh2_lds.cl:103): a pop is one read
+    uint32_t* gs = p.gstack + ((uint64_t)blockIdx.x * kBlock + tid);       // overflow entry e at gs[e * gstride]
+    const uint64_t gstride = (uint64_t)gridDim.x * kBlock;
 
-    const uint32_t texel = (uint32_t)sf.texel_y * (uint32_t)p.width + (uint32_t)sf.texel_x;
-    const uint32_t base = pcg_hash(texel + p.seed_hash);
+    // current block of samples: [cur, blk_end) of surfel slot `slot`
+    int32_t cur = 0, blk_end = 0;
+    uint32_t slot = 0;
+    bool has_partial = false;
+    long long pT = 0, pW = 0;                // partial sums of the current block
+    f3 P, N, X, Z;
+    P = N = X = Z = make_f3(0.f, 0.f, 0.f);
+    uint32_t hash_base = 0;
     const float* table = nullptr;
-    if (SAMPLER == AOB_SAMPLER_REFERENCE_COMPAT && valid) {
-        // GenerateRaysComputeShader.hlsl:45: Hemisphere[DTid.x * SampleCount + i], DTid.x chunk-local
-        uint64_t local = p.section_index[k];
-        table = p.hemisphere + 3ull * ((local % p.chunk_max) * (uint64_t)p.spp);
-    }
 
-    int32_t next = valid ? 0 : p.spp;      // next sample to generate
     bool active = false;
-    int32_t qT = 0, qW = 0;
-    float fT = 0.0f, fW = 0.0f;
-
     f3 org, dir, invdir, oxinvdir;
+    org = dir = invdir = oxinvdir = make_f3(0.f, 0.f, 0.f);
     float w = 0.0f, closest_t = 0.0f;
     bool hit = false;
     uint32_t addr = kInvalid;
-    int sp = 0;
-    org = dir = invdir = oxinvdir = make_f3(0.f, 0.f, 0.f);
+    int sp = 1;
 
     auto push = [&](uint32_t v) {
-        if (sp < kLdsStack) lds_stack[sp * kBlock + tid] = v; else ovf[sp - kLdsStack] = v;
+        if (sp < LDS_N) lds_stack[sp * kBlock + tid] = v;
+        else gs[(uint64_t)(sp - LDS_N) * gstride] = v;
         sp++;
     };
     auto pop = [&]() -> uint32_t {
-        if (sp == 0) return kInvalid;
         sp--;
-        return sp < kLdsStack ? lds_stack[sp * kBlock + tid] : ovf[sp - kLdsStack];
+        uint32_t v;
+        if (sp < LDS_N) { v = lds_stack[sp * kBlock + tid]; asm volatile("" : "+v"(v)); }
+        else { v = gs[(uint64_t)(sp - LDS_N) * gstride]; asm volatile("" : "+v"(v)); }
+        return v;
     };
     // ProcessIntersectionsComputeShader.hlsl:69-90
     auto finish = [&]() {
         float r;
         if (ANYHIT) r = hit ? 0.0f : 1.0f;
         else r = (hit && closest_t < p.falloff) ? closest_t / p.falloff : 1.0f;
-        if (ACCUM == AOB_ACCUMULATE_QUANTISED) { qT += ftoi(r * w * 255.0f); qW += ftoi(w * 255.0f); }
-        else { fT += r * w; fW += w; }
+        if (ACCUM == AOB_ACCUMULATE_QUANTISED) { pT += ftoi(r * w * 255.0f); pW += ftoi(w * 255.0f); }
+        else { pT += f2fix(r * w); pW += f2fix(w); }
         active = false;
     };
 
     for (;;) {
-        // ---- refill: every idle lane with samples left generates its next ray ----
-        if (!active && next < p.spp) {
-            f3 h;
-            if (SAMPLER == AOB_SAMPLER_REFERENCE_COMPAT) h = make_f3(table[3 * next], table[3 * next + 1], table[3 * next + 2]);
-            else h = cosine_sample(base, next, p.grid);
-            next++;
-            dir = make_f3(fmaf(h.z, Z.x, fmaf(h.y, N.x, h.x * X.x)),
-                          fmaf(h.z, Z.y, fmaf(h.y, N.y, h.x * X.y)),
-                          fmaf(h.z, Z.z, fmaf(h.y, N.z, h.x * X.z)));                       // :46
-            org = make_f3(fmaf(dir.x, p.bias, P.x), fmaf(dir.y, p.bias, P.y), fmaf(dir.z, p.bias, P.z)); // :47
-            w = SAMPLER == AOB_SAMPLER_REFERENCE_COMPAT ? dot(N, dir) : 1.0f;
-            invdir = make_f3(safe_inv1(dir.x), safe_inv1(dir.y), safe_inv1(dir.z));
-            oxinvdir = make_f3(-org.x * invdir.x, -org.y * invdir.y, -org.z * invdir.z);
-            closest_t = p.tmax; hit = false; sp = 0;
-            active = true;
-            addr = 0;
-            if (p.node_count == 0) finish();          // empty scene: every ray misses
-        }
-        if (__ballot(active) == 0ull) {
-            if (__ballot(next < p.spp) == 0ull) break;   // nothing in flight, nothing left to generate
-            continue;                                    // (only an empty scene gets here)
-        }
+        const bool pool_empty = item_next >= total_items;
+        const bool refillable = !active && (cur < blk_end || !pool_empty);
+        const uint64_t active_m = __ballot(active);
+        const int n_refill = __popcll(__ballot(refillable));
+        if (active_m == 0ull && n_refill == 0) break;
 
-        // ---- traverse until enough lanes are idle (and refillable) ----
-        for (;;) {
-            if (active) {
-                const float4* np = p.nodes + 4ull * addr;
-                const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-                if (__float_as_uint(n0.w) != kInvalid) {
-                    // intersect_bvh2_lds.cl:108-160
-                    float s0x, s0y, s1x, s1y;
-                    intersect_bbox(make_f3(n0.x, n0.y, n0.z), make_f3(n1.x, n1.y, n1.z), invdir, oxinvdir, closest_t, s0x, s0y);
-                    intersect_bbox(make_f3(n2.x, n2.y, n2.z), make_f3(n3.x, n3.y, n3.z), invdir, oxinvdir, closest_t, s1x, s1y);
-                    const bool c0 = s0x <= s0y, c1 = s1x <= s1y;
-                    const bool c1first = c1 && (s0x > s1x);
-                    const uint32_t al = __float_as_uint(n0.w), ar = __float_as_uint(n2.w);
-                    if (c0 || c1) {
-                        const bool right_first = c1first || !c0;
-                        addr = right_first ? ar : al;
-                        if (c0 && c1) push(right_first ? al : ar);
-                    } else {
-                        addr = pop();
-                    }
-                } else {
-                    // :162-182 (closest) / :323-339 (any hit)
-                    const float t = intersect_triangle(org, dir, make_f3(n0.x, n0.y, n0.z), make_f3(n1.x, n1.y, n1.z),
-                                                       make_f3(n2.x, n2.y, n2.z), closest_t);
-                    if (t < closest_t) {
-                        closest_t = t; hit = true;
-                        addr = ANYHIT ? kInvalid : pop();
-                    } else {
-                        addr = pop();
+        // ---- refill section ----
+        if (n_refill >= p.refill_idle || active_m == 0ull) {
+            const bool need_item = !active && cur >= blk_end;
+            if (need_item && has_partial) {
+                // block finished: fold its sums into the surfel's accumulators
+                atomicAdd(&acc[wave * 64u + slot][0], (unsigned long long)pT);
+                atomicAdd(&acc[wave * 64u + slot][1], (unsigned long long)pW);
+                has_partial = false;
+            }
+            const uint64_t want_m = __ballot(need_item && !pool_empty);
+            if (want_m != 0ull) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want_m, 0u));
+                const uint32_t item = item_next + rank;
+                item_next += (uint32_t)__popcll(want_m);
+                if (need_item && !pool_empty && item < total_items) {
+                    const uint32_t s = item & 63u, blk = item >> 6;
+                    if (s < nsurf) {
+                        const float4* fr = p.frames + 4ull * (wave_first + s);
+                        const float4 a = fr[0], b = fr[1], c = fr[2], d = fr[3];
+                        if (__float_as_uint(d.z) != 0u) {
+                            P = make_f3(a.x, a.y, a.z); N = make_f3(a.w, b.x, b.y);
+                            X = make_f3(b.z, b.w, c.x); Z = make_f3(c.y, c.z, c.w);
+                            slot = s;
+                            cur = (int32_t)blk * p.block_samples;
+                            blk_end = min(p.spp, cur + p.block_samples);
+                            pT = 0; pW = 0;
+                            has_partial = cur < blk_end;
+                            hash_base = pcg_hash(__float_as_uint(d.x) + p.seed_hash);
+                            if (SAMPLER == AOB_SAMPLER_REFERENCE_COMPAT)
+                                table = p.hemisphere + 3ull * __float_as_uint(d.y);   // Hemisphere[DTid.x * SampleCount + i]
+                        }
                     }
                 }
+            }
+            if (!active && cur < blk_end) {
+                f3 h;
+                if (SAMPLER == AOB_SAMPLER_REFERENCE_COMPAT) h = make_f3(table[3 * cur], table[3 * cur + 1], table[3 * cur + 2]);
+                else h = cosine_sample(hash_base, cur, p.grid);
+                cur++;
+                dir = make_f3(fmaf(h.z, Z.x, fmaf(h.y, N.x, h.x * X.x)),
+                              fmaf(h.z, Z.y, fmaf(h.y, N.y, h.x * X.y)),
+                              fmaf(h.z, Z.z, fmaf(h.y, N.z, h.x * X.z)));                       // GenerateRays:46
+                org = make_f3(fmaf(dir.x, p.bias, P.x), fmaf(dir.y, p.bias, P.y), fmaf(dir.z, p.bias, P.z)); // :47
+                w = SAMPLER == AOB_SAMPLER_REFERENCE_COMPAT ? dot(N, dir) : 1.0f;
+                invdir = make_f3(safe_inv1(dir.x), safe_inv1(dir.y), safe_inv1(dir.z));
+                oxinvdir = make_f3(-org.x * invdir.x, -org.y * invdir.y, -org.z * invdir.z);
+                closest_t = p.tmax; hit = false; sp = 1;
+                active = true;
+                addr = 0;
+                if (p.node_count == 0) finish();          // empty scene: every ray misses
+            }
+        }
+
+        // ---- leaf section: :162-182 (closest) / :323-339 (any hit); the triangle is inlined in the node ----
+        const bool at_leaf = active && addr >= p.leaf_base;
+        const bool inner = active && addr < p.leaf_base;
+        const uint64_t inner_m = __ballot(inner);
+        if (__popcll(__ballot(at_leaf)) >= p.leaf_wait || inner_m == 0ull) {
+            if (at_leaf) {
+                const float4* np = p.nodes + 4ull * addr;
+                const float4 n0 = np[0], n1 = np[1], n2 = np[2];
+                const float t = intersect_triangle(org, dir, make_f3(n0.x, n0.y, n0.z), make_f3(n1.x, n1.y, n1.z),
+                                                   make_f3(n2.x, n2.y, n2.z), closest_t);
+                const bool closer = t < closest_t;
+                if (closer) { closest_t = t; hit = true; }
+                addr = (ANYHIT && closer) ? kInvalid : pop();
                 if (addr == kInvalid) finish();
             }
-            const uint64_t am = __ballot(active);
-            const uint64_t refillable = __ballot(!active && next < p.spp);
-            if (am == 0ull || __popcll(refillable) >= kRefillIdle) break;
+        }
+
+        // ---- inner section: intersect_bvh2_lds.cl:108-160 ----
+        if (inner) {
+            const float4* np = p.nodes + 4ull * addr;
+            const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+            float s0x, s0y, s1x, s1y;
+            intersect_bbox(make_f3(n0.x, n0.y, n0.z), make_f3(n1.x, n1.y, n1.z), invdir, oxinvdir, closest_t, s0x, s0y);
+            intersect_bbox(make_f3(n2.x, n2.y, n2.z), make_f3(n3.x, n3.y, n3.z), invdir, oxinvdir, closest_t, s1x, s1y);
+            const bool c0 = s0x <= s0y, c1 = s1x <= s1y;
+            const bool right_first = (c1 && (s0x > s1x)) || !c0;
+            const uint32_t al = __float_as_uint(n0.w), ar = __float_as_uint(n2.w);
+            if (c0 && c1) push(right_first ? al : ar);
+            addr = right_first ? ar : al;
+            if (!(c0 || c1)) {
+                addr = pop();
+                if (addr == kInvalid) finish();
+            }
         }
     }
 
+    // blocks still held by lanes when the pool ran dry
+    if (has_partial) {
+        atomicAdd(&acc[wave * 64u + slot][0], (unsigned long long)pT);
+        atomicAdd(&acc[wave * 64u + slot][1], (unsigned long long)pW);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS atomics have landed
+
     // ProcessIntersectionsComputeShader.hlsl:89-90: one surfel per cell per launch, so a plain
     // read-modify-write replaces the 2*spp InterlockedAdds
-    if (valid) {
-        AobResult* cell = p.results + texel;
-        AobResult c = *cell;
-        if (ACCUM == AOB_ACCUMULATE_QUANTISED) {
-            c.total_bits = (uint32_t)((int32_t)c.total_bits + qT);
-            c.weight_bits = (uint32_t)((int32_t)c.weight_bits + qW);
-        } else {
-            c.total_bits = __float_as_uint(__uint_as_float(c.total_bits) + fT);
-            c.weight_bits = __float_as_uint(__uint_as_float(c.weight_bits) + fW);
+    if (lane < nsurf) {
+        const float4 d = p.frames[4ull * (wave_first + lane) + 3];
+        if (__float_as_uint(d.z) != 0u) {
+            const long long sT = (long long)acc[tid][0], sW = (long long)acc[tid][1];
+            AobResult* cell = p.results + __float_as_uint(d.x);
+            AobResult c = *cell;
+            if (ACCUM == AOB_ACCUMULATE_QUANTISED) {
+                c.total_bits = (uint32_t)((int32_t)c.total_bits + (int32_t)sT);
+                c.weight_bits = (uint32_t)((int32_t)c.weight_bits + (int32_t)sW);
+            } else {
+                // exact sums, rounded to float once
+                c.total_bits = __float_as_uint(__uint_as_float(c.total_bits) + (float)sT * 2.3283064365386962890625e-10f);
+                c.weight_bits = __float_as_uint(__uint_as_float(c.weight_bits) + (float)sW * 2.3283064365386962890625e-10f);
+            }
+            *cell = c;
         }
-        *cell = c;
     }
 }
 
 template <int SAMPLER, int ANYHIT, int ACCUM>
-static void launch_ovf(int ovf, dim3 grid, hipStream_t s, const TraceParams& p)
+static void launch_stack(int lds_n, dim3 grid, hipStream_t s, const TraceParams& p)
 {
-    if (ovf <= 48) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, 48>), grid, dim3(kBlock), 0, s, p);
-    else hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, 112>), grid, dim3(kBlock), 0, s, p);
+    if (lds_n <= 16) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, 16>), grid, dim3(kBlock), 0, s, p);
+    else if (lds_n <= 24) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, 24>), grid, dim3(kBlock), 0, s, p);
+    else hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, 32>), grid, dim3(kBlock), 0, s, p);
 }
 template <int SAMPLER, int ANYHIT>
-static void launch_acc(int accum, int ovf, dim3 grid, hipStream_t s, const TraceParams& p)
+static void launch_acc(int accum, int lds_n, dim3 grid, hipStream_t s, const TraceParams& p)
 {
-    if (accum == AOB_ACCUMULATE_QUANTISED) launch_ovf<SAMPLER, ANYHIT, AOB_ACCUMULATE_QUANTISED>(ovf, grid, s, p);
-    else launch_ovf<SAMPLER, ANYHIT, AOB_ACCUMULATE_FLOAT>(ovf, grid, s, p);
+    if (accum == AOB_ACCUMULATE_QUANTISED) launch_stack<SAMPLER, ANYHIT, AOB_ACCUMULATE_QUANTISED>(lds_n, grid, s, p);
+    else launch_stack<SAMPLER, ANYHIT, AOB_ACCUMULATE_FLOAT>(lds_n, grid, s, p);
 }
 template <int SAMPLER>
-static void launch_hit(int anyhit, int accum, int ovf, dim3 grid, hipStream_t s, const TraceParams& p)
+static void launch_hit(int anyhit, int accum, int lds_n, dim3 grid, hipStream_t s, const TraceParams& p)
 {
-    if (anyhit) launch_acc<SAMPLER, 1>(accum, ovf, grid, s, p);
-    else launch_acc<SAMPLER, 0>(accum, ovf, grid, s, p);
+    if (anyhit) launch_acc<SAMPLER, 1>(accum, lds_n, grid, s, p);
+    else launch_acc<SAMPLER, 0>(accum, lds_n, grid, s, p);
 }
 
 static void cosine_grid(int32_t spp, CosineGrid& g)
@@ -239,6 +305,12 @@ uint64_t chunk_texel_max(const AobOptions& opt)
     return c;
 }
 
+static int env_int(const char* name, int fallback)
+{
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : fallback;
+}
+
 int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
 {
     DeviceMaterial& m = b->materials[material];
@@ -247,23 +319,25 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
     hipStream_t s = b->stream;
     AOB_HIP(hipEventRecord(b->ev_trace[0], s));
     if (begin < end) {
-        // the traversal stack holds at most one deferred sibling per level
-        if (b->bvh_depth > (uint32_t)(kLdsStack + 112)) {
-            set_error("BVH depth %u exceeds the traversal stack (%d)", b->bvh_depth, kLdsStack + 112);
-            return AOB_ERR_BVH_TOO_DEEP;
-        }
-        const int ovf = b->bvh_depth > (uint32_t)(kLdsStack + 48) ? 112 : 48;
+        // a lane's stack holds the sentinel plus at most one deferred sibling per tree level
+        const uint32_t need = b->bvh_depth + 2;
+        const int lds_n = env_int("AOB_TRACE_LDS_STACK", 24);       // tuning/test hook (16 | 24 | 32)
+        const int lds_eff = lds_n <= 16 ? 16 : (lds_n <= 24 ? 24 : 32);
+        const uint32_t overflow = need > (uint32_t)lds_eff ? need - (uint32_t)lds_eff : 0u;
         TraceParams p;
         p.nodes = (const float4*)b->nodes;
-        p.surfels = m.surfels; p.section_index = m.section_index; p.results = m.results;
+        p.frames = m.frames; p.results = m.results;
         p.hemisphere = b->hemisphere;
         p.node_count = (uint32_t)b->node_count;
-        p.chunk_max = (uint32_t)chunk_texel_max(o);
-        p.width = m.width; p.height = m.height; p.spp = o.sample_count;
+        p.leaf_base = b->triangle_count ? (uint32_t)(b->triangle_count - 1) : 0u;
+        p.spp = o.sample_count;
+        p.block_samples = (o.sample_count + kBlocksPerSurfel - 1) / kBlocksPerSurfel;
         p.seed_hash = host_pcg(o.seed);
         p.tmax = o.ray_tmax;
         if (!o.use_any_hit && o.clamp_tmax_to_falloff && o.falloff_distance < p.tmax) p.tmax = o.falloff_distance;
         p.bias = o.ray_bias; p.falloff = o.falloff_distance;
+        p.refill_idle = max(1, env_int("AOB_TRACE_REFILL_IDLE", 16));
+        p.leaf_wait = max(1, env_int("AOB_TRACE_LEAF_WAIT", 16));
         cosine_grid(o.sample_count, p.grid);
         // one launch per section: two sections of a material may cover the same texel, and
         // their contributions are added in section order (BakeEngine.cpp:473,659)
@@ -275,8 +349,17 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
             p.nblocks = (uint32_t)((se - sb + kBlock - 1) / kBlock);
             p.blocks_per_xcd = (p.nblocks + 7) / 8;
             dim3 grid(p.blocks_per_xcd * 8);
-            if (o.sampler == AOB_SAMPLER_REFERENCE_COMPAT) launch_hit<AOB_SAMPLER_REFERENCE_COMPAT>(o.use_any_hit, o.accumulate, ovf, grid, s, p);
-            else launch_hit<AOB_SAMPLER_COSINE>(o.use_any_hit, o.accumulate, ovf, grid, s, p);
+            const uint64_t words = (uint64_t)grid.x * kBlock * (overflow ? overflow : 1u);
+            if (overflow && words > b->gstack_words) {
+                AOB_HIP(hipStreamSynchronize(s));
+                if (b->gstack) AOB_HIP(hipFree(b->gstack));
+                b->gstack = nullptr; b->gstack_words = 0;
+                AOB_HIP(hipMalloc((void**)&b->gstack, sizeof(uint32_t) * words));
+                b->gstack_words = words;
+            }
+            p.gstack = b->gstack;
+            if (o.sampler == AOB_SAMPLER_REFERENCE_COMPAT) launch_hit<AOB_SAMPLER_REFERENCE_COMPAT>(o.use_any_hit, o.accumulate, lds_eff, grid, s, p);
+            else launch_hit<AOB_SAMPLER_COSINE>(o.use_any_hit, o.accumulate, lds_eff, grid, s, p);
         }
         AOB_HIP(hipGetLastError());
     }

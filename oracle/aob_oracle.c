@@ -687,6 +687,19 @@ static inline int traverse(const AobBvhNode* nodes, uint64_t node_count, f3 o, f
     return hit;
 }
 
+/* FLOAT accumulation is order independent by construction: every sample's r*w and w are
+ * converted (exactly: a float times 2^32, truncated) to Q32.32 fixed point, the 64-bit integer
+ * sums are exact, and each sum is rounded to float once.  The reference has no float mode
+ * (it sums (int)(x*255), ProcessIntersectionsComputeShader.hlsl:87-90); this is the build's
+ * higher-precision variant of the same accumulation. */
+static inline int64_t f2fix(float v)
+{
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) v = 2147483520.0f;
+    if (v <= -2147483648.0f) v = -2147483520.0f;
+    return (int64_t)(v * 4294967296.0f);
+}
+
 static void trace_surfel(const TraceJob* job, uint64_t k, OrcTraceStats* st, int* error,
                          const CosineGrid* grid, uint64_t chunk_max)
 {
@@ -719,7 +732,7 @@ static void trace_surfel(const TraceJob* job, uint64_t k, OrcTraceStats* st, int
     const float* table = compat ? job->hemisphere + 3 * ((local % chunk_max) * (uint64_t)spp) : NULL;
 
     int32_t qT = 0, qW = 0;
-    float fT = 0.0f, fW = 0.0f;
+    int64_t xT = 0, xW = 0;     /* FLOAT mode: exact Q32.32 sums, rounded to float once at the end */
     for (int32_t i = 0; i < spp; i++) {
         f3 h = compat ? f3_make(table[3 * i], table[3 * i + 1], table[3 * i + 2]) : cosine_sample(base, i, grid);
         /* :46 */
@@ -741,7 +754,7 @@ static void trace_surfel(const TraceJob* job, uint64_t k, OrcTraceStats* st, int
             qT += orc_ftoi(r * w * 255.0f);          /* :87 */
             qW += orc_ftoi(w * 255.0f);              /* :88 */
         } else {
-            fT += r * w; fW += w;
+            xT += f2fix(r * w); xW += f2fix(w);
         }
     }
     /* :89-90 InterlockedAdd into Results[y*W+x] (one surfel per cell per section) */
@@ -751,7 +764,7 @@ static void trace_surfel(const TraceJob* job, uint64_t k, OrcTraceStats* st, int
     } else {
         float a, b;
         memcpy(&a, &cell->total_bits, 4); memcpy(&b, &cell->weight_bits, 4);
-        a += fT; b += fW;
+        a += (float)xT * 2.3283064365386962890625e-10f; b += (float)xW * 2.3283064365386962890625e-10f;
         memcpy(&cell->total_bits, &a, 4); memcpy(&cell->weight_bits, &b, 4);
     }
 }
