@@ -177,6 +177,7 @@ __device__ __forceinline__ f3 cosine_sample(uint32_t base, int32_t i, const Cosi
     int32_t cy = i / g.sx, cx = i - cy * g.sx;
     float u1 = fminf(((float)cx + j1) * g.inv_sx, one_minus);
     float u2 = fminf(((float)cy + j2) * g.inv_sy, one_minus);
+    if (cy >= g.sy) { u1 = j1; u2 = j2; }      // samples beyond the sx*sy grid are plain random
     float r = sqrtf(u1);
     float y = sqrtf(1.0f - u1);
     float s, c;

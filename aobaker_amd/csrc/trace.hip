@@ -282,9 +282,10 @@ static void launch_hit(int anyhit, int accum, int lds_n, dim3 grid, hipStream_t 
 
 static void cosine_grid(int32_t spp, CosineGrid& g)
 {
+    // sx = floor(sqrt(spp)), sy = spp / sx; samples beyond sx*sy are unstratified
     int32_t a = 1;
-    while ((int64_t)a * a < spp) a++;
-    g.sx = a; g.sy = (spp + a - 1) / a;
+    while ((int64_t)(a + 1) * (a + 1) <= spp) a++;
+    g.sx = a; g.sy = spp / a;
     g.inv_sx = 1.0f / (float)g.sx; g.inv_sy = 1.0f / (float)g.sy;
 }
 

@@ -234,10 +234,13 @@ void orc_sincos2pi(float u, float* s_out, float* c_out)
 
 static void cosine_grid(int32_t spp, int32_t* sx, int32_t* sy)
 {
+    /* sx = floor(sqrt(spp)), sy = spp / sx: the first sx*sy samples are one per cell of an
+     * sx x sy grid, the remaining spp - sx*sy are plain random (an incomplete last grid row
+     * would bias the estimate) */
     int32_t a = 1;
-    while ((int64_t)a * a < spp) a++;
+    while ((int64_t)(a + 1) * (a + 1) <= spp) a++;
     *sx = a;
-    *sy = (spp + a - 1) / a;
+    *sy = spp / a;
 }
 
 typedef struct { int32_t sx, sy; float inv_sx, inv_sy; } CosineGrid;
@@ -250,8 +253,11 @@ static inline f3 cosine_sample(uint32_t base, int32_t i, const CosineGrid* g)
     float j1 = (float)(a >> 8) * 5.9604644775390625e-8f;
     float j2 = (float)(b >> 8) * 5.9604644775390625e-8f;
     int32_t cx = i % g->sx, cy = i / g->sx;
-    float u1 = fminf(((float)cx + j1) * g->inv_sx, one_minus);
-    float u2 = fminf(((float)cy + j2) * g->inv_sy, one_minus);
+    float u1, u2;
+    if (cy < g->sy) {
+        u1 = fminf(((float)cx + j1) * g->inv_sx, one_minus);
+        u2 = fminf(((float)cy + j2) * g->inv_sy, one_minus);
+    } else { u1 = j1; u2 = j2; }
     float r = sqrtf(u1);
     float y = sqrtf(1.0f - u1);
     float s, c;

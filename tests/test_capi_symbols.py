@@ -1,0 +1,73 @@
+"""The C-ABI library loads on a GPU-less box and exports exactly what include/aobaker.h declares."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from aobaker_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "aobaker.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(aob_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_python_mirror_agree():
+    assert declared_functions() == sorted(capi.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = capi.load()          # raises ImportError when the HIP library has not been built
+    for name in declared_functions():
+        assert hasattr(lib, name), name
+    out = subprocess.run(["nm", "-D", "--defined-only", capi.library_path()], capture_output=True, text=True, check=True).stdout
+    exported = sorted(l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("aob_"))
+    assert exported == declared_functions()
+
+
+def test_struct_layouts_match_the_header():
+    # sizes the C compiler gives the header's structs (x86-64 SysV), checked without a GPU
+    src = '#include "aobaker.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",sizeof(AobOptions),sizeof(AobMeshDesc),sizeof(AobMaterialDesc),sizeof(AobSceneDesc),sizeof(AobDeviceConfig),sizeof(AobStats),sizeof(AobSurfel),sizeof(AobBvhNode),sizeof(AobResult));return 0;}'
+    exe = "/tmp/aob_sizes"
+    subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src, text=True, check=True)
+    sizes = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
+    assert sizes == [ctypes.sizeof(capi.AobOptions), ctypes.sizeof(capi.AobMeshDesc), ctypes.sizeof(capi.AobMaterialDesc),
+                     ctypes.sizeof(capi.AobSceneDesc), ctypes.sizeof(capi.AobDeviceConfig), ctypes.sizeof(capi.AobStats),
+                     capi.surfel_dtype().itemsize, capi.node_dtype().itemsize, capi.result_dtype().itemsize]
+    assert sizes[6:] == [40, 64, 8]
+
+
+def test_defaults_are_the_reference_constants(orc):
+    # BakeEngine.cpp:13-18; the library and the oracle state them independently
+    a, b = capi.default_options(), orc.default_options()
+    for name, _ in capi.AobOptions._fields_:
+        if name != "reserved":
+            assert getattr(a, name) == getattr(b, name), name
+    assert (a.sample_count, a.bleed_distance, a.ray_chunk_size, a.use_any_hit) == (100, 5, 0xFFFFFF, 1)
+    assert a.falloff_distance == 1.25
+
+
+def test_no_cpu_fallback_in_the_product():
+    """The product never routes through oracle/ (or any CPU path): nothing under aobaker_amd/
+    or include/ mentions it."""
+    for base in ("aobaker_amd", "include", "tools"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hip", ".cpp", ".c")) or f == "Makefile":
+                    text = open(os.path.join(dirpath, f), errors="replace").read()
+                    assert "liboracle" not in text and "from oracle" not in text and "import oracle" not in text and "aob_oracle" not in text, os.path.join(dirpath, f)
+
+
+def test_calls_fail_loudly_without_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = capi.load()
+    cfg = capi.AobDeviceConfig(); cfg.device = 0
+    assert lib.aob_init(ctypes.byref(cfg)) != 0
+    assert lib.aob_last_error()           # a message, not a silent fallback

@@ -1,0 +1,108 @@
+"""Host-side logic above the C ABI: the scene mirror, flattening, transforms, sharding maths."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from aobaker_amd import capi, scenes
+from aobaker_amd import dist as aod
+from aobaker_amd.scene import (RENDER_VERTEX, BakeObject, BakeTexture, FlatScene, MaterialObject, RenderMesh, Scene,
+                               Section, make_vertices)
+
+
+def test_bake_texture_contract():
+    # Scene/BakeTexture.cpp:7-67: valid (channels, bytes) combinations, 0xFF fill, tight packing
+    t = BakeTexture(7, 5, 4, 2)
+    assert t.GetDataLength() == 7 * 5 * 4 * 2 and (t.GetData() == 0xFF).all()
+    assert t.as_array().shape == (5, 7, 4) and t.as_array().dtype == np.float16
+    for bad in ((3, 1), (3, 2), (5, 4), (1, 3)):
+        with pytest.raises(ValueError):
+            BakeTexture(4, 4, *bad)
+
+
+def test_render_vertex_layout_and_flatten():
+    assert RENDER_VERTEX.itemsize == 48
+    assert [RENDER_VERTEX.fields[n][1] for n in ("Position", "Normal", "UV", "Color")] == [0, 12, 24, 32]
+    sc = scenes.two_section_scene(16)
+    flat = FlatScene(sc)
+    assert flat.desc.mesh_count == 2 and flat.desc.material_count == 1
+    m0 = flat.mesh_array[0]
+    assert (m0.position_stride, m0.normal_stride, m0.uv_stride) == (48, 48, 48)
+    assert m0.normals - m0.positions == 12 and m0.uvs - m0.positions == 24
+    assert m0.vertex_count == 4 and m0.index_count == 6 and m0.material == 0
+    # the descriptor aliases the scene's own arrays: the bake writes straight into BakeTexture.Data
+    assert flat.material_array[0].data == sc.GetMaterial(0).GetAOTexture().GetData().ctypes.data
+    assert flat.triangle_count() == 4
+
+
+def test_material_association_is_by_identity():
+    sc = Scene()
+    a = sc.AddMaterial(MaterialObject("same", 8, 8)); b = sc.AddMaterial(MaterialObject("same", 8, 8))
+    q = scenes.quad((0, 0, 0), (1, 0, 0), (1, 0, 1), (0, 0, 1), (0, 1, 0))
+    o = sc.AddObject(BakeObject("O"))
+    o.AddSection(Section("s", RenderMesh(make_vertices(*q[:3]), q[3]), b))
+    o.AddSection(Section("t", RenderMesh(make_vertices(*q[:3]), q[3]), None))
+    flat = FlatScene(sc)
+    assert flat.mesh_array[0].material == 1 and flat.mesh_array[1].material == -1
+    assert a is not b
+
+
+def test_build_transform_matches_simplemath_convention():
+    # TransformObject.cpp:16-24: Scale * Rotation(yaw=rot.y, pitch=rot.x, roll=rot.z) * Translation, row vectors
+    o = BakeObject("O", position=(1, 2, 3), rotation=(0, np.pi / 2, 0), scale=(2, 2, 2))
+    m = o.BuildTransform()
+    p = np.float32([1, 0, 0, 1]) @ m
+    # yaw of +90 degrees about Y (left-handed, row vectors) sends +X to -Z
+    assert np.allclose(p[:3], [1, 2, 3 - 2], atol=1e-6)
+    o = BakeObject("O", rotation=(np.pi / 2, 0, 0))
+    p = np.float32([0, 0, 1, 0]) @ o.BuildTransform()
+    assert np.allclose(p[:3], [0, -1, 0], atol=1e-6)       # pitch +90 sends +Z to -Y
+    assert np.allclose(BakeObject("I").BuildTransform(), np.eye(4))
+
+
+def test_shard_range_partitions_exactly():
+    for total in (0, 1, 7, 64, 4194304, 4194305):
+        for world in (1, 2, 3, 4, 8):
+            parts = [aod.shard_range(total, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == total
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            sizes = [e - b for b, e in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_weak_scaling_atlas():
+    assert aod.weak_scaling_atlas(2048, 1) == (2048, 2048)
+    assert aod.weak_scaling_atlas(2048, 2) == (2048, 4096)
+    assert aod.weak_scaling_atlas(2048, 4) == (4096, 4096)       # BASELINE configs[3]
+    assert aod.weak_scaling_atlas(2048, 8) == (4096, 8192)
+    for n in (1, 2, 3, 4, 6, 8):
+        w, h = aod.weak_scaling_atlas(128, n)
+        assert w * h == n * 128 * 128
+
+
+def test_terrain_scene_matches_baseline_config():
+    sc = scenes.terrain_scene(grid=708, atlas=64)
+    mesh = sc.GetObject(0).GetSection(0).GetPreviewMesh()
+    assert mesh.GetIndexCount() // 3 == 999698
+    v = mesh.GetVertices()
+    assert np.allclose(np.linalg.norm(v["Normal"], axis=1), 1.0, atol=1e-5)
+    assert v["UV"].min() == 0.0 and v["UV"].max() == 1.0
+    again = scenes.terrain_scene(grid=708, atlas=64).GetObject(0).GetSection(0).GetPreviewMesh().GetVertices()
+    assert np.array_equal(v, again)                              # seeded, reproducible
+
+
+def test_sphere_scene_triangle_count():
+    mesh = scenes.sphere_scene(n=187, atlas=64).GetObject(0).GetSection(0).GetPreviewMesh()
+    assert mesh.GetIndexCount() // 3 == 69938                    # BASELINE.md cfg2 stand-in
+
+
+def test_scene_file_roundtrip(tmp_path):
+    import struct
+    from aobaker_amd.scenefile import write_scene
+    sc = scenes.cube_scene(32)
+    path = tmp_path / "cube.aobs"
+    write_scene(sc, str(path))
+    raw = path.read_bytes()
+    assert raw[:4] == b"AOBS" and struct.unpack("<III", raw[4:16]) == (1, 1, 1)
+    mesh = sc.GetObject(0).GetSection(0).GetPreviewMesh()
+    assert len(raw) == 16 + 16 + 36 + 4 + 12 + 48 * mesh.GetVertexCount() + 4 * mesh.GetIndexCount()

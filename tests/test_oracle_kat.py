@@ -1,0 +1,307 @@
+"""Known-answer tests that pin the CPU oracle.
+
+The reference has no tests or golden vectors of its own, so the oracle is pinned by
+(1) the published MSVC rand() sequence its sampler draws from, (2) the arithmetic of the in-tree
+OpenCL primitives it restates, checked on their edge cases, and (3) closed-form geometry.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from aobaker_amd import capi, scenes
+from aobaker_amd.scene import FlatScene
+
+
+def opts(orc, **kw):
+    o = orc.default_options()
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+# ---- (9) MSVC rand ---------------------------------------------------------------
+def test_msvc_rand_sequence(orc):
+    # the first values of the unseeded MSVC CRT rand(), which BakeEngine.cpp:316-317 consumes
+    assert orc.msvc_rand_sequence(8) == [41, 18467, 6334, 26500, 19169, 15724, 11478, 29358]
+
+
+def test_hemisphere_table_matches_formula(orc):
+    # BakeEngine.cpp:312-333: x = s*cos(phi), z = s*sin(phi), y = 1 - s (NOT cos(theta))
+    t = orc.hemisphere_table(1000)
+    seq = orc.msvc_rand_sequence(2000)
+    u = np.float32(seq[0]) / np.float32(32767.0)
+    v = np.float32(seq[1]) / np.float32(32767.0)
+    s = np.sqrt(np.float32(-u * (u - np.float32(2.0))))
+    phi = np.float32(2.0 * 3.14159265358979323846) * v
+    assert abs(t[0, 0] - s * math.cos(phi)) < 1e-6 and abs(t[0, 2] - s * math.sin(phi)) < 1e-6
+    r = np.sqrt(t[:, 0] ** 2 + t[:, 2] ** 2)
+    assert np.allclose(t[:, 1], 1.0 - r, atol=1e-6)
+    assert (t[:, 1] >= -1e-6).all() and (t[:, 1] <= 1.0).all()
+    # |dir|^2 = s^2 + (1-s)^2 lies in [0.5, 1]: the directions are deliberately unnormalised
+    n2 = (t ** 2).sum(axis=1)
+    assert n2.min() >= 0.5 - 1e-5 and n2.max() <= 1.0 + 1e-5
+
+
+def test_compat_table_size(orc):
+    # BakeEngine.cpp:359-364: chunkTexelMax = min(rayChunkSize / sampleCount, 65535)
+    assert orc.load().orc_compat_table_entries(opts(orc, sample_count=100)) == 65535 * 100
+    assert orc.load().orc_compat_table_entries(opts(orc, sample_count=1024)) == (0xFFFFFF // 1024) * 1024
+
+
+# ---- D3D ftoi and fp16 -------------------------------------------------------------
+def test_ftoi(orc):
+    assert orc.ftoi(254.999) == 254 and orc.ftoi(-3.9) == -3 and orc.ftoi(0.0) == 0
+    assert orc.ftoi(float("nan")) == 0
+    assert orc.ftoi(float("inf")) == 2**31 - 1 and orc.ftoi(-float("inf")) == -2**31
+    assert orc.ftoi(3e9) == 2**31 - 1
+
+
+def test_fp16_rne_matches_numpy(orc):
+    rng = np.random.default_rng(0)
+    vals = np.concatenate([rng.standard_normal(2000).astype(np.float32) * np.float32(10) ** rng.integers(-8, 5, 2000),
+                           np.float32([0.0, -0.0, 1.0, 0.99999994, 65504.0, 65519.9, 65520.0, 1e-8, 6e-8, 6.1e-5, np.inf, -np.inf])])
+    for v in vals:
+        want = np.float32(v).astype(np.float16).view(np.uint16)
+        assert orc.f32_to_f16(float(v), capi.FP16_RNE) == int(want), v
+    for h in list(range(0, 0x7c01, 37)) + [0x8000, 0xfbff, 0x0001, 0x03ff, 0x0400]:
+        want = np.uint16(h).view(np.float16).astype(np.float32)
+        assert orc.f16_to_f32(h) == float(want)
+
+
+def test_fp16_rtz_never_rounds_away(orc):
+    rng = np.random.default_rng(1)
+    for v in rng.standard_normal(2000).astype(np.float32):
+        h = orc.f32_to_f16(float(v), capi.FP16_RTZ)
+        back = orc.f16_to_f32(h)
+        assert abs(back) <= abs(float(v))
+        assert abs(float(v)) - abs(back) < abs(float(v)) * 2.0 ** -10 + 1e-8
+    assert orc.f32_to_f16(0.99999994, capi.FP16_RTZ) == 0x3bff      # the quirk that motivates the RNE default
+    assert orc.f32_to_f16(1e6, capi.FP16_RTZ) == 0x7bff and orc.f32_to_f16(1e6, capi.FP16_RNE) == 0x7c00
+
+
+# ---- (5) Möller–Trumbore edge cases, common.cl:193-216 ------------------------------------
+V1, V2, V3 = (0, 0, 0), (1, 0, 0), (0, 1, 0)
+
+
+def test_triangle_hit_and_miss(orc):
+    assert orc.intersect_triangle((0.25, 0.25, 1), (0, 0, -1), V1, V2, V3, 10.0) == pytest.approx(1.0)
+    assert orc.intersect_triangle((0.75, 0.75, 1), (0, 0, -1), V1, V2, V3, 10.0) == 10.0     # b1+b2 > 1
+    assert orc.intersect_triangle((0.25, 0.25, -1), (0, 0, -1), V1, V2, V3, 10.0) == 10.0    # behind the origin
+    # no back-face culling (doBackfaceCulling = 0, GenerateRaysComputeShader.hlsl:52)
+    assert orc.intersect_triangle((0.25, 0.25, -1), (0, 0, 1), V1, V2, V3, 10.0) == pytest.approx(1.0)
+
+
+def test_triangle_parallel_ray_is_a_miss(orc):
+    assert orc.intersect_triangle((0.25, 0.25, 1), (1, 0, 0), V1, V2, V3, 10.0) == 10.0      # denom == 0
+
+
+def test_triangle_edges_inclusive(orc):
+    # b1 == 0, b2 == 0 and b1 + b2 == 1 are all accepted (the comparisons are strict)
+    assert orc.intersect_triangle((0.0, 0.5, 1), (0, 0, -1), V1, V2, V3, 10.0) == pytest.approx(1.0)
+    assert orc.intersect_triangle((0.5, 0.0, 1), (0, 0, -1), V1, V2, V3, 10.0) == pytest.approx(1.0)
+    assert orc.intersect_triangle((0.5, 0.5, 1), (0, 0, -1), V1, V2, V3, 10.0) == pytest.approx(1.0)
+    # t == t_max is accepted, t just beyond is not
+    assert orc.intersect_triangle((0.25, 0.25, 1), (0, 0, -1), V1, V2, V3, 1.0) == 1.0
+    assert orc.intersect_triangle((0.25, 0.25, 1.5), (0, 0, -1), V1, V2, V3, 1.0) == 1.0     # returns t_max = miss
+    # t scales with the (unnormalised) direction: the reference never normalises its rays
+    assert orc.intersect_triangle((0.25, 0.25, 1), (0, 0, -0.5), V1, V2, V3, 10.0) == pytest.approx(2.0)
+
+
+def test_degenerate_triangle_never_hit(orc):
+    # the reference's importer feeds (0,0,0) triangles (BakeObject.cpp:96,127): denom == 0
+    assert orc.intersect_triangle((0, 0, 1), (0, 0, -1), (0, 0, 0), (0, 0, 0), (0, 0, 0), 5.0) == 5.0
+
+
+# ---- (6) slab test with zero direction components, common.cl:220-246 ----------------------
+def test_safe_invdir_clamps(orc):
+    inv = orc.safe_invdir((0.0, -0.0, 2.0))
+    assert inv[0] == np.float32(1.0) / np.float32(1e-8)
+    assert inv[1] == -(np.float32(1.0) / np.float32(1e-8))
+    assert inv[2] == 0.5
+
+
+def test_bbox_axis_parallel_ray(orc):
+    d = (0.0, 0.0, 1.0)
+    inv = orc.safe_invdir(d)
+    for o, expect in (((0.5, 0.5, -1.0), True), ((1.5, 0.5, -1.0), False), ((0.5, 0.5, 2.0), False)):
+        ox = -np.float32(o) * inv
+        t0, t1 = orc.intersect_bbox((0, 0, 0), (1, 1, 1), inv, ox, 100.0)
+        assert (t0 <= t1) == expect
+    # t_max clips the far side, 0 clips the near side
+    ox = -np.float32((0.5, 0.5, -1.0)) * inv
+    t0, t1 = orc.intersect_bbox((0, 0, 0), (1, 1, 1), inv, ox, 0.5)
+    assert t0 == pytest.approx(1.0) and t1 == 0.5 and not t0 <= t1
+    ox = -np.float32((0.5, 0.5, 0.5)) * inv
+    t0, t1 = orc.intersect_bbox((0, 0, 0), (1, 1, 1), inv, ox, 100.0)
+    assert t0 == 0.0 and t1 == pytest.approx(0.5)
+
+
+# ---- COSINE sampler ------------------------------------------------------------------------
+def test_sincos_polynomial(orc):
+    for u in np.linspace(0, 0.999, 200):
+        s, c = orc.sincos2pi(float(np.float32(u)))
+        assert abs(s - math.sin(2 * math.pi * np.float32(u))) < 2e-6
+        assert abs(c - math.cos(2 * math.pi * np.float32(u))) < 2e-6
+
+
+def test_cosine_sampler_distribution(orc):
+    spp = 1024
+    d = np.array([orc.cosine_sample(5, 1234, i, spp) for i in range(spp)])
+    assert np.allclose((d ** 2).sum(axis=1), 1.0, atol=1e-5)              # unit vectors
+    assert (d[:, 1] >= 0).all()                                             # upper hemisphere
+    assert abs(d[:, 1].mean() - 2.0 / 3.0) < 0.01                           # E[cos] under a cosine pdf
+    assert abs(d[:, 0].mean()) < 0.02 and abs(d[:, 2].mean()) < 0.02
+    # counter-based: depends on (seed, texel, sample) only
+    assert np.array_equal(orc.cosine_sample(5, 1234, 17, spp), d[17])
+    assert not np.array_equal(orc.cosine_sample(6, 1234, 17, spp), d[17])
+    assert not np.array_equal(orc.cosine_sample(5, 1235, 17, spp), d[17])
+
+
+# ---- (7) rasterisation rules --------------------------------------------------------------
+def test_raster_top_left_rule_and_last_triangle_wins(orc):
+    from aobaker_amd.scene import BakeObject, MaterialObject, RenderMesh, Scene, Section, make_vertices
+    # two texel-aligned right triangles forming the square [2,6]x[2,6] of an 8x8 atlas, plus a
+    # second copy of the first triangle at a different height drawn LAST
+    uv = np.float32([[2, 2], [6, 2], [6, 6], [2, 6]]) / 8
+    p = np.float32([[0, 0, 0], [1, 0, 0], [1, 0, 1], [0, 0, 1]])
+    p2 = p + np.float32([0, 5, 0])
+    pos = np.concatenate([p, p2]); nrm = np.tile(np.float32([0, 1, 0]), (8, 1)); uvs = np.concatenate([uv, uv])
+    idx = np.uint32([0, 1, 2, 0, 2, 3, 4, 5, 6])
+    sc = Scene(); m = sc.AddMaterial(MaterialObject("A", 8, 8))
+    o = sc.AddObject(BakeObject("O")); o.AddSection(Section("s", RenderMesh(make_vertices(pos, nrm, uvs), idx), m))
+    surfels, sidx = orc.rasterize(FlatScene(sc).desc, 0, opts(orc, normal_fp16=capi.FP16_OFF))
+    # exactly the 16 texels whose centres lie inside: every centre is covered once (shared diagonal
+    # and shared edges produce neither holes nor doubles), none outside
+    assert len(surfels) == 16
+    xy = set(zip(surfels["texel_x"].tolist(), surfels["texel_y"].tolist()))
+    assert xy == {(x, y) for x in range(2, 6) for y in range(2, 6)}
+    # row-major extraction order (BakeEngine.cpp:569-588)
+    assert list(zip(surfels["texel_y"].tolist(), surfels["texel_x"].tolist())) == sorted(zip(surfels["texel_y"].tolist(), surfels["texel_x"].tolist()))
+    assert np.array_equal(sidx, np.arange(16))
+    # the third triangle (same UVs as the first, drawn last) wins where it covers: y = 5 there
+    upper = surfels["position"][:, 1] == 5.0
+    for s, up in zip(surfels, upper):
+        x, y = s["texel_x"] + 0.5, s["texel_y"] + 0.5
+        in_first = (x - 2) >= (y - 2)          # triangle (0,1,2): u >= v side of the diagonal
+        assert up == in_first or (x - 2) == (y - 2)
+    # interpolated world position = the affine map of the texel centre
+    s0 = surfels[0]
+    assert s0["texel_x"] == 2 and s0["texel_y"] == 2
+    assert np.allclose(s0["position"][[0, 2]], [(2.5 - 2) / 4, (2.5 - 2) / 4], atol=1e-6)
+
+
+def test_raster_edge_on_texel_centre(orc):
+    """A vertical edge through texel centres belongs to the triangle on its right (left edge)."""
+    from aobaker_amd.scene import BakeObject, MaterialObject, RenderMesh, Scene, Section, make_vertices
+    uv = np.float32([[2.5, 0], [6.5, 0], [6.5, 8], [2.5, 8]]) / 8
+    p = np.float32([[0, 0, 0], [1, 0, 0], [1, 0, 1], [0, 0, 1]])
+    sc = Scene(); m = sc.AddMaterial(MaterialObject("A", 8, 8))
+    o = sc.AddObject(BakeObject("O"))
+    o.AddSection(Section("s", RenderMesh(make_vertices(p, np.tile(np.float32([0, 1, 0]), (4, 1)), uv), np.uint32([0, 1, 2, 0, 2, 3])), m))
+    surfels, _ = orc.rasterize(FlatScene(sc).desc, 0, opts(orc))
+    xs = sorted(set(surfels["texel_x"].tolist()))
+    assert xs == [2, 3, 4, 5]        # x=2 (centre 2.5 on the left edge) in, x=6 (centre 6.5 on the right edge) out
+    assert len(surfels) == 4 * 8
+
+
+# ---- (1)(2) trivial scenes -------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["compat", "cosine"])
+def test_open_plane_is_white(orc, mode):
+    sc = scenes.plane_scene(16, bpc=1)
+    o = opts(orc, sample_count=32)
+    if mode == "cosine":
+        o.sampler, o.accumulate = capi.SAMPLER_COSINE, capi.ACCUMULATE_FLOAT
+    st = orc.bake(FlatScene(sc).desc, o)
+    assert st.hits == 0 and st.rays == 16 * 16 * 32
+    assert (sc.GetMaterial(0).GetAOTexture().GetData() == 255).all()
+
+
+def test_closed_cube_is_black_inside(orc):
+    sc = scenes.cube_scene(64, inward=True)
+    o = opts(orc, sample_count=32, sampler=capi.SAMPLER_COSINE, accumulate=capi.ACCUMULATE_FLOAT)
+    st = orc.bake(FlatScene(sc).desc, o)
+    tex = sc.GetMaterial(0).GetAOTexture().as_array()[..., 0]
+    assert st.hits >= st.rays * 0.999          # only rays through the (non-watertight) edges escape
+    assert tex.max() <= 8                      # covered texels ~0, gutters bleed ~0
+
+
+# ---- (3) floor under a ceiling, falloff scoring ----------------------------------------------
+def test_floor_under_ceiling_falloff_closed_form(orc):
+    """Cosine sampler, falloff mode: AO = E[min(t,F)/F], t = h/cos(theta), cos^2 uniform.
+    With c0 = h/F:  AO = c0 * 2 * (1 - c0) + c0^2 ... evaluated by the exact integral below."""
+    h, F = 0.5, 1.25
+    sc = scenes.floor_ceiling_scene(8, height=h, bpc=4)
+    o = opts(orc, sample_count=4096, sampler=capi.SAMPLER_COSINE, accumulate=capi.ACCUMULATE_FLOAT, use_any_hit=0,
+             falloff_distance=F, normal_fp16=capi.FP16_OFF)
+    orc.bake(FlatScene(sc).desc, o, threads=4)
+    ao = sc.GetMaterial(0).GetAOTexture().as_array()[..., 0]
+    # pdf of c = cos(theta) under cosine weighting is 2c on [0,1]; hit at t = h/c; score t/F if t<F else 1
+    c0 = h / F
+    expect = c0 * c0 + (2 * h / F) * (1 - c0)           # int_0^c0 2c dc  +  int_c0^1 (h/(cF)) 2c dc
+    assert abs(ao.mean() - expect) < 3e-3
+    assert np.abs(ao - expect).max() < 0.02
+
+
+# ---- (4) floor next to a long wall ------------------------------------------------------------
+def test_floor_wall_form_factor(orc):
+    H = 1.0
+    sc = scenes.floor_wall_scene(16, wall_height=H, bpc=4)
+    o = opts(orc, sample_count=2048, sampler=capi.SAMPLER_COSINE, accumulate=capi.ACCUMULATE_FLOAT, normal_fp16=capi.FP16_OFF)
+    orc.bake(FlatScene(sc).desc, o, threads=4)
+    ao = sc.GetMaterial(0).GetAOTexture().as_array()[..., 0]
+    d = (np.arange(16) + 0.5) / 16 * 2.0
+    expect = 0.5 * (1 + d / np.sqrt(d * d + H * H))
+    assert np.abs(ao.mean(axis=0) - expect).max() < 4e-3
+
+
+# ---- quantised accumulation + resolve (ProcessIntersections:87-90, Postprocess:81) ----------
+def test_resolve_integer_division(orc):
+    res = np.zeros(4, dtype=capi.result_dtype())
+    res["total_bits"] = np.int32([100, 0, 51, 7]).view(np.uint32)
+    res["weight_bits"] = np.int32([200, 10, 100, 7]).view(np.uint32)
+    out = orc.resolve(res, 4, 1, opts(orc, bleed_distance=0), 1, 1)
+    # floor(T*255/Wt) written as UNORM8
+    assert out.tolist() == [100 * 255 // 200, 0, 51 * 255 // 100, 255]
+    out = orc.resolve(res, 4, 1, opts(orc, bleed_distance=0), 4, 4).view(np.float32).reshape(4, 4)
+    assert np.allclose(out[:, 0], np.float32([127, 0, 130, 255]) / np.float32(255))
+    assert (out[:, 1] == 0).all() and (out[:, 2] == 0).all() and (out[:, 3] == 1).all()
+
+
+# ---- (8) bleed -------------------------------------------------------------------------------
+def test_bleed_single_texel_makes_an_open_disc(orc):
+    W = H = 21
+    res = np.zeros(W * H, dtype=capi.result_dtype())
+    res["total_bits"][10 * W + 10] = 200
+    res["weight_bits"][10 * W + 10] = 255
+    out = orc.resolve(res, W, H, opts(orc, bleed_distance=5), 1, 1).reshape(H, W)
+    yy, xx = np.mgrid[0:H, 0:W]
+    d2 = (xx - 10) ** 2 + (yy - 10) ** 2
+    assert (out[d2 < 25] == 200).all()          # strict d^2 < B^2: the ring at distance exactly 5 is excluded
+    assert (out[d2 >= 25] == 0).all()
+
+
+def test_bleed_row_aliasing_quirk(orc):
+    """PostprocessPixelShader.hlsl:65 reads ResultBuffer[y*W + x] with the RAW x: a covered texel
+    at the end of row r bleeds into the START of row r+1 (x = -1 aliases to the previous row)."""
+    W, H = 16, 4
+    res = np.zeros(W * H, dtype=capi.result_dtype())
+    res["total_bits"][1 * W + 15] = 255
+    res["weight_bits"][1 * W + 15] = 255
+    out = orc.resolve(res, W, H, opts(orc, bleed_distance=5), 1, 1).reshape(H, W)
+    assert out[1, 15] == 255 and out[1, 12] == 255
+    assert out[2, 0] == 255          # (x=-1, y=2) aliases to index 2*W-1 = (15, 1)
+    assert out[0, 0] == 255          # (x=-1, y=2) again: d^2 = 1 + 4
+    assert out[3, 8] == 0 and out[1, 9] == 0
+
+
+def test_two_sections_sum_into_the_same_cells(orc):
+    sc = scenes.two_section_scene(32)
+    o = opts(orc, sample_count=16)
+    flat = FlatScene(sc)
+    surfels, sidx = orc.rasterize(flat.desc, 0, o)
+    # both sections contribute a surfel to the overlap; section-local indices restart at 0
+    n_a = int((sidx[1:] < sidx[:-1]).argmax()) + 1
+    assert sidx[0] == 0 and sidx[n_a] == 0 and n_a == 24 * 24
+    cells = surfels["texel_y"] * 32 + surfels["texel_x"]
+    assert len(set(cells[:n_a].tolist()) & set(cells[n_a:].tolist())) == 16 * 16

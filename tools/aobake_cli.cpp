@@ -1,0 +1,111 @@
+// aobake_cli — minimal headless caller of the drop-in: builds a scene through the reference's
+// own accessors (include/aobaker_scene.h), calls BakeEngine::Init / Bake / Dispose exactly as
+// Main.cpp:16,21 and AOBaker.cpp:243 do, and writes each AO texture as raw bytes (and a PGM for
+// 1-channel 8-bit textures).
+//
+//   aobake_cli --scene <file.aobs> --out <prefix> [--spp N] [--sampler 0|1] [--accumulate 0|1]
+//
+// Scene file (little endian), written by aobaker_amd/scenefile.py:
+//   "AOBS" u32 version=1, u32 material_count, u32 object_count
+//   per material: i32 width, height, channels, bytes_per_channel
+//   per object:   f32 position[3], rotation[3], scale[3], u32 section_count
+//     per section: i32 material, u32 vertex_count, u32 index_count, RenderVertex[vertex_count], u32[index_count]
+#include "../include/BakeEngine.h"
+#include "../include/aobaker.h"
+#include "../include/aobaker_scene.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static bool read_exact(FILE* f, void* dst, size_t n) { return std::fread(dst, 1, n, f) == n; }
+
+static Scene* load_scene(const char* path)
+{
+	FILE* f = std::fopen(path, "rb");
+	if (!f) { std::perror(path); return nullptr; }
+	char magic[4]; uint32_t version, nmat, nobj;
+	if (!read_exact(f, magic, 4) || std::memcmp(magic, "AOBS", 4) || !read_exact(f, &version, 4) || version != 1 ||
+	    !read_exact(f, &nmat, 4) || !read_exact(f, &nobj, 4)) { std::fprintf(stderr, "%s: bad header\n", path); std::fclose(f); return nullptr; }
+	Scene* scene = new Scene();
+	for (uint32_t i = 0; i < nmat; i++)
+	{
+		int32_t d[4];
+		if (!read_exact(f, d, sizeof d)) { std::fclose(f); delete scene; return nullptr; }
+		scene->AddMaterial(new MaterialObject(L"Material", d[0], d[1], d[2], d[3]));
+	}
+	for (uint32_t i = 0; i < nobj; i++)
+	{
+		float trs[9]; uint32_t nsec;
+		if (!read_exact(f, trs, sizeof trs) || !read_exact(f, &nsec, 4)) { std::fclose(f); delete scene; return nullptr; }
+		BakeObject* object = new BakeObject(L"Object");
+		object->SetPosition({ trs[0], trs[1], trs[2] });
+		object->SetRotation({ trs[3], trs[4], trs[5] });
+		object->SetScale({ trs[6], trs[7], trs[8] });
+		for (uint32_t s = 0; s < nsec; s++)
+		{
+			int32_t material; uint32_t nv, ni;
+			if (!read_exact(f, &material, 4) || !read_exact(f, &nv, 4) || !read_exact(f, &ni, 4)) { std::fclose(f); delete scene; return nullptr; }
+			std::vector<RenderVertex> v(nv); std::vector<unsigned int> idx(ni);
+			if (!read_exact(f, v.data(), sizeof(RenderVertex) * nv) || !read_exact(f, idx.data(), 4ull * ni)) { std::fclose(f); delete scene; return nullptr; }
+			MaterialObject* mat = material >= 0 && material < scene->GetMaterialCount() ? scene->GetMaterial(material) : nullptr;
+			object->AddSection(new BakeObject::Section(L"Geometry", new RenderMesh(v.data(), (int)nv, idx.data(), (int)ni), mat));
+		}
+		scene->AddObject(object);
+	}
+	std::fclose(f);
+	return scene;
+}
+
+int main(int argc, char** argv)
+{
+	const char* scene_path = nullptr; std::string out = "ao";
+	AobOptions& opt = BakeEngine::Options();
+	for (int i = 1; i < argc; i++)
+	{
+		std::string a = argv[i];
+		auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
+		if (a == "--scene") scene_path = next();
+		else if (a == "--out") out = next();
+		else if (a == "--spp") opt.sample_count = std::atoi(next());
+		else if (a == "--sampler") opt.sampler = std::atoi(next());
+		else if (a == "--accumulate") opt.accumulate = std::atoi(next());
+		else if (a == "--seed") opt.seed = (uint32_t)std::atoi(next());
+		else if (a == "--any-hit") opt.use_any_hit = std::atoi(next());
+		else if (a == "--normal-fp16") opt.normal_fp16 = std::atoi(next());
+		else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
+	}
+	if (!scene_path) { std::fprintf(stderr, "usage: aobake_cli --scene file.aobs --out prefix [--spp N] ...\n"); return 2; }
+	Scene* scene = load_scene(scene_path);
+	if (!scene) return 1;
+
+	BakeEngine::Init();                       // Main.cpp:16
+	if (BakeEngine::LastStatus() != 0) return 1;
+	BakeEngine::Bake(scene);                  // AOBaker.cpp:243
+	const int status = BakeEngine::LastStatus();
+	if (status == 0)
+	{
+		const AobStats& st = BakeEngine::LastStats();
+		std::printf("triangles %llu nodes %llu surfels %llu rays %llu | ms: upload %.3f bvh %.3f raster %.3f trace %.3f resolve %.3f download %.3f\n",
+		            (unsigned long long)st.triangle_count, (unsigned long long)st.node_count, (unsigned long long)st.surfel_count,
+		            (unsigned long long)st.ray_count, st.ms_upload, st.ms_bvh_build, st.ms_rasterize, st.ms_trace, st.ms_resolve, st.ms_download);
+		for (int i = 0; i < scene->GetMaterialCount(); i++)
+		{
+			BakeTexture* tex = scene->GetMaterial(i)->GetAOTexture();
+			std::string path = out + "_" + std::to_string(i) + ".raw";
+			FILE* f = std::fopen(path.c_str(), "wb");
+			if (f) { std::fwrite(tex->GetData(), 1, tex->GetDataLength(), f); std::fclose(f); }
+			if (tex->GetChannelCount() == 1 && tex->GetBytesPerChannel() == 1)
+			{
+				path = out + "_" + std::to_string(i) + ".pgm";
+				f = std::fopen(path.c_str(), "wb");
+				if (f) { std::fprintf(f, "P5\n%d %d\n255\n", tex->GetWidth(), tex->GetHeight()); std::fwrite(tex->GetData(), 1, tex->GetDataLength(), f); std::fclose(f); }
+			}
+		}
+	}
+	BakeEngine::Dispose();                    // Main.cpp:21
+	delete scene;
+	return status == 0 ? 0 : 1;
+}
