@@ -75,6 +75,19 @@ class Baker:
         capi.check(self.lib.aob_bake_copy_nodes(self.handle, out.ctypes.data, n))
         return out[:n]
 
+    def nodes4(self) -> np.ndarray:
+        n = C.c_uint64()
+        capi.check(self.lib.aob_bake_node4_count(self.handle, C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=capi.node4_dtype())
+        capi.check(self.lib.aob_bake_copy_nodes4(self.handle, out.ctypes.data, n.value))
+        return out[:n.value]
+
+    def leaf_tris(self) -> np.ndarray:
+        n = self.stats().triangle_count
+        out = np.zeros(max(n, 1), dtype=capi.leaf_tri_dtype())
+        capi.check(self.lib.aob_bake_copy_leaf_tris(self.handle, out.ctypes.data, n))
+        return out[:n]
+
     def surfel_count(self, material=0) -> int:
         n = C.c_uint64()
         capi.check(self.lib.aob_bake_surfel_count(self.handle, material, C.byref(n)))

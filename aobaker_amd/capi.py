@@ -39,7 +39,8 @@ class AobOptions(C.Structure):
         ("normal_fp16", C.c_int32),
         ("ray_chunk_size", C.c_int32),
         ("clamp_tmax_to_falloff", C.c_int32),
-        ("reserved", C.c_int32 * 4),
+        ("bvh_width", C.c_int32),
+        ("reserved", C.c_int32 * 3),
     ]
 
 
@@ -119,6 +120,16 @@ def node_dtype():
                      ("rmax", "<f4", 3), ("prim_id", "<u4")])
 
 
+def node4_dtype():
+    import numpy as np
+    return np.dtype([("lo", "<f4", (4, 4)), ("hi", "<f4", (4, 4))])
+
+
+def leaf_tri_dtype():
+    import numpy as np
+    return np.dtype([("v0", "<f4", 4), ("v1", "<f4", 4), ("v2", "<f4", 4)])
+
+
 def result_dtype():
     import numpy as np
     return np.dtype([("total_bits", "<u4"), ("weight_bits", "<u4")])
@@ -135,7 +146,7 @@ EXPORTED_SYMBOLS = [
     "aob_bake_node_count", "aob_bake_copy_nodes", "aob_bake_surfel_count",
     "aob_bake_copy_surfels", "aob_bake_copy_results", "aob_bake_results_device_ptr",
     "aob_bake_image_device_ptr", "aob_bake_stream", "aob_bake_last_trace_ms",
-    "aob_bake_surfel_cell_range",
+    "aob_bake_surfel_cell_range", "aob_bake_node4_count", "aob_bake_copy_nodes4", "aob_bake_copy_leaf_tris",
 ]
 
 
@@ -193,6 +204,9 @@ def load() -> C.CDLL:
         "aob_bake_stream": (C.c_int, [vp, P(vp)]),
         "aob_bake_last_trace_ms": (C.c_int, [vp, P(C.c_float)]),
         "aob_bake_surfel_cell_range": (C.c_int, [vp, i32, u64, u64, P(u64), P(u64), P(i32)]),
+        "aob_bake_node4_count": (C.c_int, [vp, P(u64)]),
+        "aob_bake_copy_nodes4": (C.c_int, [vp, vp, u64]),
+        "aob_bake_copy_leaf_tris": (C.c_int, [vp, vp, u64]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -79,6 +79,9 @@ struct AobBake {
     uint32_t* refit_flags = nullptr;
     uint32_t* depth_dev = nullptr;
     AobBvhNode* nodes = nullptr;
+    float4*   nodes4 = nullptr;         // 8 x float4 per 4-ary node (AobBvh4Node), indexed by BVH2 inner index
+    float4*   leaf_tris = nullptr;      // 3 x float4 per triangle in Morton order (AobLeafTri)
+    uint64_t  node4_count = 0;
     uint64_t node_count = 0;
     uint32_t bvh_depth = 0;
     bool bvh_built = false, depth_known = false, bvh_timed = false;
@@ -102,5 +105,6 @@ int build_bvh(AobBake* b);                                   // bvh_build.hip
 int rasterize_material(AobBake* b, int32_t material);        // raster.hip (syncs once per section)
 int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end);   // trace.hip
 int resolve_material(AobBake* b, int32_t material);          // resolve.hip
+int trace4_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end);  // trace4.hip
 uint64_t chunk_texel_max(const AobOptions& opt);             // trace.hip (BakeEngine.cpp:359-364)
 }

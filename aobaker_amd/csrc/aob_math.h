@@ -185,4 +185,20 @@ __device__ __forceinline__ f3 cosine_sample(uint32_t base, int32_t i, const Cosi
     return make_f3(r * c, y, r * s);
 }
 
+// host side of the COSINE sampler: sx = floor(sqrt(spp)), sy = spp / sx; samples beyond sx*sy are unstratified
+inline void cosine_grid(int32_t spp, CosineGrid& g)
+{
+    int32_t a = 1;
+    while ((int64_t)(a + 1) * (a + 1) <= spp) a++;
+    g.sx = a; g.sy = spp / a;
+    g.inv_sx = 1.0f / (float)g.sx; g.inv_sy = 1.0f / (float)g.sy;
+}
+
+inline uint32_t host_pcg(uint32_t v)
+{
+    uint32_t s = v * 747796405u + 2891336453u;
+    uint32_t w = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u;
+    return (w >> 22) ^ w;
+}
+
 } // namespace aob

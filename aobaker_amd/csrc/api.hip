@@ -53,6 +53,7 @@ static int validate_options(const AobOptions* o)
     if (o->accumulate != AOB_ACCUMULATE_QUANTISED && o->accumulate != AOB_ACCUMULATE_FLOAT) { set_error("unknown accumulate mode %d", o->accumulate); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->normal_fp16 < AOB_FP16_OFF || o->normal_fp16 > AOB_FP16_RNE) { set_error("unknown normal_fp16 mode %d", o->normal_fp16); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->bleed_distance < 0 || o->bleed_distance > 64) { set_error("bleed_distance %d out of range", o->bleed_distance); return AOB_ERR_INVALID_ARGUMENT; }
+    if (o->bvh_width != 0 && o->bvh_width != 2 && o->bvh_width != 4) { set_error("bvh_width %d: must be 0, 2 or 4", o->bvh_width); return AOB_ERR_INVALID_ARGUMENT; }
     if (!(o->falloff_distance > 0.0f)) { set_error("falloff_distance must be positive"); return AOB_ERR_INVALID_ARGUMENT; }
     return AOB_OK;
 }
@@ -85,7 +86,7 @@ static void free_bake(AobBake* b)
     hipFree(b->tri_verts); hipFree(b->prim_bounds); hipFree(b->scene_bounds_enc);
     hipFree(b->codes[0]); hipFree(b->codes[1]); hipFree(b->prim_idx[0]); hipFree(b->prim_idx[1]);
     hipFree(b->sort_temp); hipFree(b->child_left); hipFree(b->child_right); hipFree(b->parent);
-    hipFree(b->node_bounds); hipFree(b->refit_flags); hipFree(b->depth_dev); hipFree(b->nodes);
+    hipFree(b->node_bounds); hipFree(b->refit_flags); hipFree(b->depth_dev); hipFree(b->nodes); hipFree(b->nodes4); hipFree(b->leaf_tris);
     hipFree(b->hemisphere); hipFree(b->gstack);
     if (b->pinned) hipHostFree(b->pinned);
     for (auto& e : b->ev) if (e) hipEventDestroy(e);
@@ -253,6 +254,8 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
     AOB_C(dev_alloc(&b->refit_flags, n));
     AOB_C(dev_alloc(&b->depth_dev, 1));
     AOB_C(dev_alloc(&b->nodes, 2 * n));
+    AOB_C(dev_alloc(&b->nodes4, 8 * n));
+    AOB_C(dev_alloc(&b->leaf_tris, 3 * n));
     if (n) {
         size_t temp = 0;
         AOB_CH(rocprim::radix_sort_pairs(nullptr, temp, b->codes[0], b->codes[1], b->prim_idx[0], b->prim_idx[1],
@@ -430,6 +433,33 @@ int aob_bake_copy_nodes(AobBake* b, AobBvhNode* dst, uint64_t capacity)
     AOB_TRY(check_bake(b, 0, false));
     if (capacity < b->node_count || (!dst && b->node_count)) { set_error("node buffer too small"); return AOB_ERR_INVALID_ARGUMENT; }
     if (b->node_count) AOB_HIP(hipMemcpyAsync(dst, b->nodes, sizeof(AobBvhNode) * b->node_count, hipMemcpyDeviceToHost, b->stream));
+    AOB_HIP(hipStreamSynchronize(b->stream));
+    return AOB_OK;
+}
+
+int aob_bake_node4_count(AobBake* b, uint64_t* count)
+{
+    AOB_TRY(check_bake(b, 0, false));
+    if (!count) { set_error("count is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
+    *count = b->node4_count;
+    return AOB_OK;
+}
+
+int aob_bake_copy_nodes4(AobBake* b, AobBvh4Node* dst, uint64_t capacity)
+{
+    AOB_TRY(check_bake(b, 0, false));
+    if (capacity < b->node4_count || (!dst && b->node4_count)) { set_error("node4 buffer too small"); return AOB_ERR_INVALID_ARGUMENT; }
+    if (b->node4_count) AOB_HIP(hipMemcpyAsync(dst, b->nodes4, sizeof(AobBvh4Node) * b->node4_count, hipMemcpyDeviceToHost, b->stream));
+    AOB_HIP(hipStreamSynchronize(b->stream));
+    return AOB_OK;
+}
+
+int aob_bake_copy_leaf_tris(AobBake* b, AobLeafTri* dst, uint64_t capacity)
+{
+    AOB_TRY(check_bake(b, 0, false));
+    const uint64_t n = b->bvh_built ? b->triangle_count : 0;
+    if (capacity < n || (!dst && n)) { set_error("leaf triangle buffer too small"); return AOB_ERR_INVALID_ARGUMENT; }
+    if (n) AOB_HIP(hipMemcpyAsync(dst, b->leaf_tris, sizeof(AobLeafTri) * n, hipMemcpyDeviceToHost, b->stream));
     AOB_HIP(hipStreamSynchronize(b->stream));
     return AOB_OK;
 }

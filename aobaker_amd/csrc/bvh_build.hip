@@ -256,6 +256,71 @@ void k_emit_nodes(uint32_t n, const uint32_t* __restrict__ child_left, const uin
     }
 }
 
+// ---- 4-ary collapse -------------------------------------------------------------------------
+// Every inner node at EVEN depth becomes a 4-ary node whose children are its grandchildren (or
+// a child itself where that child is a leaf); odd levels disappear.  The child boxes are the
+// BVH2 boxes, unchanged, so a ray tests a subset of the boxes the BVH2 walk would test.
+// Layout (AobBvh4Node): lo[j] = {min, ref_j}, hi[j] = {max, 0}; the quad of lanes that traces a
+// ray fetches lo[0..3] with one 64-byte access and hi[0..3] with another.
+__global__ __launch_bounds__(kBlock)
+void k_collapse4(uint32_t n, const uint32_t* __restrict__ parent, const uint32_t* __restrict__ child_left,
+                 const uint32_t* __restrict__ child_right, const Box* __restrict__ node_bounds,
+                 float4* __restrict__ nodes4)
+{
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n - 1) return;
+    uint32_t depth = 0;
+    for (uint32_t a = i; parent[a] != 0xffffffffu; a = parent[a]) depth++;
+    if (depth & 1u) return;
+    const uint32_t leaf_base = n - 1;
+    uint32_t kids[4]; int k = 0;
+    const uint32_t c2[2] = { child_left[i], child_right[i] };
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        uint32_t c = c2[s];
+        if (c < leaf_base) { kids[k++] = child_left[c]; kids[k++] = child_right[c]; }
+        else kids[k++] = c;
+    }
+    float4* out = nodes4 + 8ull * i;
+    for (int j = 0; j < 4; j++) {
+        if (j < k) {
+            const uint32_t c = kids[j];
+            const Box b = node_bounds[c];
+            const uint32_t ref = c < leaf_base ? c : (0x80000000u | (c - leaf_base));
+            out[j] = make_float4(b.pmin[0], b.pmin[1], b.pmin[2], __uint_as_float(ref));
+            out[4 + j] = make_float4(b.pmax[0], b.pmax[1], b.pmax[2], 0.0f);
+        } else {
+            out[j] = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(0xffffffffu));
+            out[4 + j] = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.0f);
+        }
+    }
+}
+
+// n == 1: the tree is a single leaf; give it a 4-ary root with that one child
+__global__ void k_single_leaf4(const Box* __restrict__ prim_bounds, float4* __restrict__ nodes4)
+{
+    if (threadIdx.x != 0) return;
+    const Box b = prim_bounds[0];
+    nodes4[0] = make_float4(b.pmin[0], b.pmin[1], b.pmin[2], __uint_as_float(0x80000000u));
+    nodes4[4] = make_float4(b.pmax[0], b.pmax[1], b.pmax[2], 0.0f);
+    for (int j = 1; j < 4; j++) {
+        nodes4[j] = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(0xffffffffu));
+        nodes4[4 + j] = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.0f);
+    }
+}
+
+__global__ __launch_bounds__(kBlock)
+void k_leaf_tris(uint32_t n, const uint32_t* __restrict__ sorted_idx, const float4* __restrict__ tri_verts,
+                 float4* __restrict__ leaf_tris)
+{
+    uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t t = sorted_idx[p];
+    leaf_tris[3ull * p + 0] = tri_verts[3ull * t + 0];
+    leaf_tris[3ull * p + 1] = tri_verts[3ull * t + 1];
+    leaf_tris[3ull * p + 2] = tri_verts[3ull * t + 2];
+}
+
 // prim ids written by k_world_triangles are mesh-local already (t), shape ids start at 1
 // (RadeonRays/radeon_rays.h:238).
 
@@ -265,7 +330,7 @@ int build_bvh(AobBake* b)
 {
     hipStream_t s = b->stream;
     const uint64_t n = b->triangle_count;
-    b->node_count = 0; b->bvh_depth = 0;
+    b->node_count = 0; b->bvh_depth = 0; b->node4_count = 0;
     if (n == 0) { b->bvh_built = true; return AOB_OK; }
     if (n > 0x7fffffffull) { set_error("too many triangles (%llu)", (unsigned long long)n); return AOB_ERR_UNSUPPORTED; }
 
@@ -299,6 +364,14 @@ int build_bvh(AobBake* b)
     b->node_count = n == 1 ? 1 : 2 * n - 1;
     hipLaunchKernelGGL(k_emit_nodes, dim3(blocks_for(b->node_count)), dim3(kBlock), 0, s, (uint32_t)n, b->child_left,
                        b->child_right, b->node_bounds, b->prim_idx[1], b->tri_verts, (float4*)b->nodes);
+    // the 4-ary structure the quad-per-ray traversal walks (bvh_width 4)
+    b->node4_count = n == 1 ? 1 : n - 1;
+    AOB_HIP(hipMemsetAsync(b->nodes4, 0, sizeof(float4) * 8 * b->node4_count, s));
+    if (n == 1) hipLaunchKernelGGL(k_single_leaf4, dim3(1), dim3(64), 0, s, b->prim_bounds, b->nodes4);
+    else hipLaunchKernelGGL(k_collapse4, dim3(blocks_for(n - 1)), dim3(kBlock), 0, s, (uint32_t)n, b->parent, b->child_left,
+                            b->child_right, b->node_bounds, b->nodes4);
+    hipLaunchKernelGGL(k_leaf_tris, dim3(blocks_for(n)), dim3(kBlock), 0, s, (uint32_t)n, b->prim_idx[1], b->tri_verts,
+                       b->leaf_tris);
     AOB_HIP(hipGetLastError());
     b->bvh_built = true;
     return AOB_OK;

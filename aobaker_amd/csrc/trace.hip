@@ -280,22 +280,6 @@ static void launch_hit(int anyhit, int accum, int lds_n, dim3 grid, hipStream_t 
     else launch_acc<SAMPLER, 0>(accum, lds_n, grid, s, p);
 }
 
-static void cosine_grid(int32_t spp, CosineGrid& g)
-{
-    // sx = floor(sqrt(spp)), sy = spp / sx; samples beyond sx*sy are unstratified
-    int32_t a = 1;
-    while ((int64_t)(a + 1) * (a + 1) <= spp) a++;
-    g.sx = a; g.sy = spp / a;
-    g.inv_sx = 1.0f / (float)g.sx; g.inv_sy = 1.0f / (float)g.sy;
-}
-
-static uint32_t host_pcg(uint32_t v)
-{
-    uint32_t s = v * 747796405u + 2891336453u;
-    uint32_t w = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u;
-    return (w >> 22) ^ w;
-}
-
 uint64_t chunk_texel_max(const AobOptions& opt)
 {
     // BakeEngine.cpp:359-364
@@ -319,7 +303,9 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
     if (end > m.surfel_count) end = m.surfel_count;
     hipStream_t s = b->stream;
     AOB_HIP(hipEventRecord(b->ev_trace[0], s));
-    if (begin < end) {
+    if (begin < end && o.bvh_width != 2) {
+        AOB_TRY(trace4_range(b, material, begin, end));        // default: quad-per-ray, 4-ary nodes (trace4.hip)
+    } else if (begin < end) {
         // a lane's stack holds the sentinel plus at most one deferred sibling per tree level
         const uint32_t need = b->bvh_depth + 2;
         const int lds_n = env_int("AOB_TRACE_LDS_STACK", 24);       // tuning/test hook (16 | 24 | 32)

@@ -61,7 +61,10 @@ typedef struct AobOptions {
     int32_t  normal_fp16;         /* AOB_FP16_*: the RGBA16F NormalV target, :446         */
     int32_t  ray_chunk_size;      /* reference rayChunkSize; bounds the compat table      */
     int32_t  clamp_tmax_to_falloff; /* falloff mode: cast with tmax=min(tmax,falloff)     */
-    int32_t  reserved[4];
+    int32_t  bvh_width;           /* traversal structure: 2 = the reference's BVH2 nodes, one lane
+                                     per ray; 4 = BVH2 collapsed to 4-ary nodes, four lanes per ray
+                                     (one per child box); 0 = library default (4)                */
+    int32_t  reserved[3];
 } AobOptions;
 
 /* ---- scene description ----------------------------------------------------
@@ -146,6 +149,17 @@ typedef struct AobBvhNode {
 } AobBvhNode;
 #define AOB_INVALID_ADDR 0xffffffffu
 
+/* 128 B 4-ary node: every second level of the BVH2 above collapsed away (the reference stack's
+ * own 4-wide kernel is kernels/CL/intersect_bvh2_lds_fp16.cl; boxes stay fp32 here).
+ * lo[j] = {min.x, min.y, min.z, ref_j}, hi[j] = {max.x, max.y, max.z, 0}.  ref < 0x80000000: index
+ * of a 4-ary node (= the BVH2 index of the inner node it was made from); ref = 0x80000000 | p:
+ * leaf triangle p of AobLeafTri[]; empty slot: ref = AOB_INVALID_ADDR and an inverted box.
+ * The two 64-byte halves are what the four lanes of a ray's quad fetch with one access each. */
+typedef struct AobBvh4Node { float lo[4][4]; float hi[4][4]; } AobBvh4Node;
+#define AOB_LEAF_FLAG 0x80000000u
+/* 48 B leaf triangle in Morton order: v0.w = shape id bits, v1.w = prim id bits. */
+typedef struct AobLeafTri { float v0[4], v1[4], v2[4]; } AobLeafTri;
+
 /* 8 B per texel (ResultValue, BakeEngine.cpp:298-309); both fields are int32
  * in QUANTISED mode and float32 in FLOAT mode. */
 typedef struct AobResult { uint32_t total_bits, weight_bits; } AobResult;
@@ -202,6 +216,12 @@ int aob_bake_clear_results(AobBake* bake, int32_t material);
 /* Introspection used by the parity tests and the multi-GPU gather. */
 int aob_bake_node_count(AobBake* bake, uint64_t* count);
 int aob_bake_copy_nodes(AobBake* bake, AobBvhNode* dst, uint64_t capacity);
+/* The 4-ary structure (built by aob_bake_build_bvh when bvh_width is 4): node4_count entries of
+ * AobBvh4Node (indexed by BVH2 inner-node index; entries of collapsed-away levels are zero) and
+ * triangle_count entries of AobLeafTri. */
+int aob_bake_node4_count(AobBake* bake, uint64_t* count);
+int aob_bake_copy_nodes4(AobBake* bake, AobBvh4Node* dst, uint64_t capacity);
+int aob_bake_copy_leaf_tris(AobBake* bake, AobLeafTri* dst, uint64_t capacity);
 int aob_bake_surfel_count(AobBake* bake, int32_t material, uint64_t* count);
 int aob_bake_copy_surfels(AobBake* bake, int32_t material, AobSurfel* dst, uint64_t capacity);
 int aob_bake_copy_results(AobBake* bake, int32_t material, AobResult* dst, uint64_t capacity);

@@ -626,12 +626,147 @@ uint64_t orc_rasterize(const AobSceneDesc* scene, int32_t material, const AobOpt
 }
 
 /* ------------------------------------------------------------------------ */
+/* 4-ary collapse of the BVH2 (the structure the default GPU kernel walks)    */
+
+/* Every inner node at even depth becomes a 4-ary node whose children are its grandchildren
+ * (or a child itself where that child is a leaf); the boxes are the BVH2 boxes, unchanged.
+ * Derived from the 64-byte node array alone.  nodes4 needs max(1, n-1) entries (indexed by the
+ * BVH2 inner index; entries of collapsed-away levels stay zero), tris needs n entries. */
+uint64_t orc_bvh4_build(const AobBvhNode* nodes2, uint64_t node_count2, AobBvh4Node* nodes4, AobLeafTri* tris)
+{
+    if (node_count2 == 0) return 0;
+    const uint64_t n = (node_count2 + 1) / 2;
+    const uint32_t leaf_base = (uint32_t)(n - 1);
+    uint32_t inf_bits = 0x7f800000u, ninf_bits = 0xff800000u;
+    float pinf, ninf; memcpy(&pinf, &inf_bits, 4); memcpy(&ninf, &ninf_bits, 4);
+    const uint32_t invalid = AOB_INVALID_ADDR;
+    for (uint64_t p = 0; p < n; p++) {
+        const AobBvhNode* lf = &nodes2[leaf_base + p];
+        memcpy(tris[p].v0, lf->lmin_or_v0, 12); memcpy(&tris[p].v0[3], &lf->shape_id, 4);
+        memcpy(tris[p].v1, lf->lmax_or_v1, 12); memcpy(&tris[p].v1[3], &lf->prim_id, 4);
+        memcpy(tris[p].v2, lf->rmin_or_v2, 12); tris[p].v2[3] = 0.0f;
+    }
+    const uint64_t count4 = n == 1 ? 1 : n - 1;
+    memset(nodes4, 0, sizeof(AobBvh4Node) * count4);
+#define EMPTY_SLOT(nd, j) do { (nd)->lo[j][0] = (nd)->lo[j][1] = (nd)->lo[j][2] = pinf; memcpy(&(nd)->lo[j][3], &invalid, 4); \
+                               (nd)->hi[j][0] = (nd)->hi[j][1] = (nd)->hi[j][2] = ninf; (nd)->hi[j][3] = 0.0f; } while (0)
+    if (n == 1) {
+        AobBvh4Node* nd = &nodes4[0];
+        const AobBvhNode* lf = &nodes2[0];
+        for (int k = 0; k < 3; k++) {
+            nd->lo[0][k] = fminf(fminf(lf->lmin_or_v0[k], lf->lmax_or_v1[k]), lf->rmin_or_v2[k]);
+            nd->hi[0][k] = fmaxf(fmaxf(lf->lmin_or_v0[k], lf->lmax_or_v1[k]), lf->rmin_or_v2[k]);
+        }
+        uint32_t ref = AOB_LEAF_FLAG; memcpy(&nd->lo[0][3], &ref, 4); nd->hi[0][3] = 0.0f;
+        for (int j = 1; j < 4; j++) EMPTY_SLOT(nd, j);
+        return 1;
+    }
+    /* walk the even levels from the root */
+    uint32_t* todo = (uint32_t*)malloc(sizeof(uint32_t) * n);
+    uint64_t top = 0;
+    todo[top++] = 0;
+    while (top) {
+        const uint32_t i = todo[--top];
+        const AobBvhNode* me = &nodes2[i];
+        AobBvh4Node* nd = &nodes4[i];
+        int k = 0;
+        const uint32_t c2[2] = { me->addr_left, me->addr_right };
+        const float* cmin[2] = { me->lmin_or_v0, me->rmin_or_v2 };
+        const float* cmax[2] = { me->lmax_or_v1, me->rmax };
+        for (int s2 = 0; s2 < 2; s2++) {
+            const uint32_t c = c2[s2];
+            if (c < leaf_base) {
+                const AobBvhNode* ch = &nodes2[c];
+                const uint32_t g[2] = { ch->addr_left, ch->addr_right };
+                const float* gmin[2] = { ch->lmin_or_v0, ch->rmin_or_v2 };
+                const float* gmax[2] = { ch->lmax_or_v1, ch->rmax };
+                for (int t = 0; t < 2; t++, k++) {
+                    uint32_t ref = g[t] < leaf_base ? g[t] : (AOB_LEAF_FLAG | (g[t] - leaf_base));
+                    memcpy(nd->lo[k], gmin[t], 12); memcpy(&nd->lo[k][3], &ref, 4);
+                    memcpy(nd->hi[k], gmax[t], 12); nd->hi[k][3] = 0.0f;
+                    if (g[t] < leaf_base) todo[top++] = g[t];
+                }
+            } else {
+                uint32_t ref = AOB_LEAF_FLAG | (c - leaf_base);
+                memcpy(nd->lo[k], cmin[s2], 12); memcpy(&nd->lo[k][3], &ref, 4);
+                memcpy(nd->hi[k], cmax[s2], 12); nd->hi[k][3] = 0.0f;
+                k++;
+            }
+        }
+        for (; k < 4; k++) EMPTY_SLOT(nd, k);
+    }
+#undef EMPTY_SLOT
+    free(todo);
+    return count4;
+}
+
+#define ORC_STACK4 512
+
+/* The 4-ary walk of the GPU's quad-per-ray kernel, one ray at a time: slab-test the four child
+ * boxes (intersect_bvh2_lds.cl:54-63), follow the nearest hit child and defer the others
+ * farthest first (the 4-ary form of the near-child-first order of :123-153); leaves are single
+ * triangles (common.cl:177-218). */
+static inline int traverse4(const AobBvh4Node* nodes4, uint64_t count4, const AobLeafTri* tris, f3 o, f3 d, float t_max,
+                            int any_hit, float* t_out, OrcTraceStats* st, int* error)
+{
+    if (count4 == 0) { *t_out = t_max; return 0; }
+    f3 invdir = safe_invdir(d);
+    f3 oxinvdir = f3_make(-o.x * invdir.x, -o.y * invdir.y, -o.z * invdir.z);
+    float closest_t = t_max;
+    int hit = 0;
+    uint32_t stack[ORC_STACK4];
+    int sp = 0;
+    stack[sp++] = AOB_INVALID_ADDR;
+    uint32_t node = 0;
+    while (node != AOB_INVALID_ADDR) {
+        if (!(node & AOB_LEAF_FLAG)) {
+            const AobBvh4Node* nd = &nodes4[node];
+            st->inner_visits++;
+            float key[4]; uint32_t ref[4]; int chit[4], nhit = 0;
+            for (int j = 0; j < 4; j++) {
+                float t0, t1;
+                intersect_bbox(nd->lo[j], nd->hi[j], invdir, oxinvdir, closest_t, &t0, &t1);
+                memcpy(&ref[j], &nd->lo[j][3], 4);
+                chit[j] = t0 <= t1 && ref[j] != AOB_INVALID_ADDR;
+                key[j] = chit[j] ? t0 : INFINITY;
+                nhit += chit[j];
+            }
+            if (nhit == 0) { node = stack[--sp]; continue; }
+            if (sp + nhit - 1 > ORC_STACK4) { *error = AOB_ERR_BVH_TOO_DEEP; *t_out = t_max; return 0; }
+            uint32_t first = AOB_INVALID_ADDR;
+            for (int j = 0; j < 4; j++) {
+                if (!chit[j]) continue;
+                int rank = 0;
+                for (int k = 0; k < 4; k++) rank += (key[k] < key[j]) || (key[k] == key[j] && k < j);
+                if (rank == 0) first = ref[j];
+                else stack[sp + (nhit - 1) - rank] = ref[j];
+            }
+            sp += nhit - 1;
+            node = first;
+        } else {
+            const AobLeafTri* tr = &tris[node & ~AOB_LEAF_FLAG];
+            st->leaf_visits++;
+            float t = intersect_triangle(o, d, f3_make(tr->v0[0], tr->v0[1], tr->v0[2]), f3_make(tr->v1[0], tr->v1[1], tr->v1[2]),
+                                         f3_make(tr->v2[0], tr->v2[1], tr->v2[2]), closest_t);
+            if (t < closest_t) {
+                closest_t = t; hit = 1;
+                if (any_hit) break;
+            }
+            node = stack[--sp];
+        }
+    }
+    *t_out = closest_t;
+    return hit;
+}
+
+/* ------------------------------------------------------------------------ */
 /* trace                                                                     */
 
 #define ORC_STACK 128
 
 typedef struct {
     const AobBvhNode* nodes; uint64_t node_count;
+    const AobBvh4Node* nodes4; uint64_t node4_count; const AobLeafTri* tris;   /* bvh_width != 2 */
     const AobSurfel* surfels; const uint32_t* section_index;
     const AobOptions* opt; const float* hemisphere;
     int32_t width, height; AobResult* results;
@@ -749,7 +884,8 @@ static void trace_surfel(const TraceJob* job, uint64_t k, OrcTraceStats* st, int
         f3 org = f3_make(fmaf(dir.x, opt->ray_bias, P.x), fmaf(dir.y, opt->ray_bias, P.y), fmaf(dir.z, opt->ray_bias, P.z));
         float t;
         st->rays++;
-        int hit = traverse(job->nodes, job->node_count, org, dir, t_max, any_hit, &t, st, error);
+        int hit = job->nodes4 ? traverse4(job->nodes4, job->node4_count, job->tris, org, dir, t_max, any_hit, &t, st, error)
+                              : traverse(job->nodes, job->node_count, org, dir, t_max, any_hit, &t, st, error);
         st->hits += (uint64_t)hit;
         /* ProcessIntersectionsComputeShader.hlsl:52-85 */
         float w = compat ? f3_dot(N, dir) : 1.0f;
@@ -813,6 +949,14 @@ int orc_trace(const AobBvhNode* nodes, uint64_t node_count,
     job.nodes = nodes; job.node_count = node_count; job.surfels = surfels; job.section_index = section_index;
     job.opt = opt; job.hemisphere = hemisphere; job.width = width; job.height = height; job.results = results;
     job.begin = begin; job.end = end; job.next = begin;
+    AobBvh4Node* nodes4 = NULL; AobLeafTri* tris = NULL;
+    if (opt->bvh_width != 2 && node_count) {
+        const uint64_t n = (node_count + 1) / 2;
+        nodes4 = (AobBvh4Node*)malloc(sizeof(AobBvh4Node) * (n > 1 ? n - 1 : 1));
+        tris = (AobLeafTri*)malloc(sizeof(AobLeafTri) * n);
+        job.node4_count = orc_bvh4_build(nodes, node_count, nodes4, tris);
+        job.nodes4 = nodes4; job.tris = tris;
+    }
     pthread_mutex_init(&job.lock, NULL);
     if (threads <= 1) trace_worker(&job);
     else {
@@ -822,6 +966,7 @@ int orc_trace(const AobBvhNode* nodes, uint64_t node_count,
         for (int i = 0; i < threads; i++) pthread_join(th[i], NULL);
     }
     pthread_mutex_destroy(&job.lock);
+    free(nodes4); free(tris);
     if (stats) {
         stats->rays += job.stats.rays; stats->inner_visits += job.stats.inner_visits;
         stats->leaf_visits += job.stats.leaf_visits; stats->hits += job.stats.hits;

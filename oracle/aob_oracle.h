@@ -72,6 +72,11 @@ void orc_scene_triangles(const AobSceneDesc* scene, OrcTriangle* out);
  * (root = depth 0). */
 uint64_t orc_bvh_build(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes, uint32_t* depth);
 
+/* The 4-ary collapse of that BVH2 (every second level removed, boxes unchanged) which the
+ * default GPU kernel walks with four lanes per ray; orc_trace uses it unless
+ * AobOptions::bvh_width == 2.  nodes4: max(1, n-1) entries, tris: n entries. */
+uint64_t orc_bvh4_build(const AobBvhNode* nodes2, uint64_t node_count2, AobBvh4Node* nodes4, AobLeafTri* tris);
+
 /* UV rasterisation + texel extraction for one material
  * (Rasterize{Vertex,Pixel}Shader.hlsl, BakeEngine.cpp:130-145,531-588).
  * Writes up to `capacity` surfels (row-major per section, sections
@@ -83,8 +88,8 @@ uint64_t orc_rasterize(const AobSceneDesc* scene, int32_t material, const AobOpt
 
 typedef struct OrcTraceStats {
     uint64_t rays;
-    uint64_t inner_visits;    /* inner-node fetches */
-    uint64_t leaf_visits;     /* leaf-node fetches (triangle tests) */
+    uint64_t inner_visits;    /* inner-node fetches (64 B BVH2 nodes, or 128 B 4-ary nodes) */
+    uint64_t leaf_visits;     /* leaf fetches = triangle tests (64 B BVH2 leaf, or 48 B AobLeafTri) */
     uint64_t hits;
 } OrcTraceStats;
 

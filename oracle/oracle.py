@@ -55,6 +55,7 @@ def load():
         "orc_scene_triangle_count": (u64, [P(capi.AobSceneDesc)]),
         "orc_scene_triangles": (None, [P(capi.AobSceneDesc), vp]),
         "orc_bvh_build": (u64, [vp, u64, vp, P(u32)]),
+        "orc_bvh4_build": (u64, [vp, u64, vp, vp]),
         "orc_rasterize": (u64, [P(capi.AobSceneDesc), i32, P(capi.AobOptions), vp, vp, u64]),
         "orc_trace": (C.c_int, [vp, u64, vp, vp, u64, u64, P(capi.AobOptions), vp, i32, i32, vp, i32,
                                 P(OrcTraceStats)]),
@@ -146,6 +147,16 @@ def bvh_build(tris):
     return nodes[:cnt], depth.value
 
 
+def bvh4_build(nodes2):
+    lib = load()
+    nodes2 = np.ascontiguousarray(nodes2)
+    n = (len(nodes2) + 1) // 2
+    nodes4 = np.zeros(max(1, n - 1), dtype=capi.node4_dtype())
+    tris = np.zeros(max(1, n), dtype=capi.leaf_tri_dtype())
+    cnt = int(lib.orc_bvh4_build(nodes2.ctypes.data if len(nodes2) else None, len(nodes2), nodes4.ctypes.data, tris.ctypes.data))
+    return nodes4[:cnt], tris[:n]
+
+
 def rasterize(desc, material, opt):
     lib = load()
     n = int(lib.orc_rasterize(C.byref(desc), material, C.byref(opt), None, None, 0))
@@ -207,4 +218,5 @@ def default_options():
     o.normal_fp16 = capi.FP16_RNE
     o.ray_chunk_size = 0xFFFFFF
     o.clamp_tmax_to_falloff = 0
+    o.bvh_width = 0
     return o

@@ -52,6 +52,20 @@ def test_bvh_nodes_bit_exact(engine, orc, name):
     assert bits(nodes).tobytes() == bits(ref_nodes).tobytes()
 
 
+@pytest.mark.parametrize("name", ["cube", "two_section", "sphere", "terrain", "floor_wall", "plane"])
+def test_bvh4_nodes_bit_exact(engine, orc, name):
+    """The 4-ary collapse (AobBvh4Node[]) and the Morton-ordered leaf triangles (AobLeafTri[])."""
+    flat = FlatScene(SCENES[name]())
+    ref2, _ = orc.bvh_build(orc.scene_triangles(flat.desc))
+    ref4, ref_tris = orc.bvh4_build(ref2)
+    with Baker(flat, make_options(orc)) as b:
+        b.build_bvh()
+        got4, got_tris = b.nodes4(), b.leaf_tris()
+    assert len(got4) == len(ref4) and len(got_tris) == len(ref_tris)
+    assert bits(got_tris).tobytes() == bits(ref_tris).tobytes()
+    assert bits(got4).tobytes() == bits(ref4).tobytes()
+
+
 @pytest.mark.parametrize("fp16", [capi.FP16_OFF, capi.FP16_RTZ, capi.FP16_RNE])
 @pytest.mark.parametrize("name", ["cube", "two_section", "sphere", "terrain"])
 def test_surfels_bit_exact(engine, orc, name, fp16):
@@ -76,11 +90,14 @@ MODES = [
 ]
 
 
+@pytest.mark.parametrize("width", [4, 2])
 @pytest.mark.parametrize("mode", range(len(MODES)))
 @pytest.mark.parametrize("name", ["cube", "two_section", "sphere", "terrain", "cube_inward"])
-def test_trace_results_match_oracle(engine, orc, name, mode):
+def test_trace_results_match_oracle(engine, orc, name, mode, width):
+    """width 4: quad-per-ray kernel on the 4-ary nodes (the default); width 2: lane-per-ray kernel
+    on the reference's 64-byte BVH2 nodes.  Each against the oracle walking the same structure."""
     flat = FlatScene(SCENES[name]())
-    opt = make_options(orc, sample_count=24, **MODES[mode])
+    opt = make_options(orc, sample_count=24, bvh_width=width, **MODES[mode])
     m = flat.material_array[0]
     nodes, _ = orc.bvh_build(orc.scene_triangles(flat.desc))
     surfels, sidx = orc.rasterize(flat.desc, 0, opt)

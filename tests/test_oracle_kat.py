@@ -305,3 +305,62 @@ def test_two_sections_sum_into_the_same_cells(orc):
     assert sidx[0] == 0 and sidx[n_a] == 0 and n_a == 24 * 24
     cells = surfels["texel_y"] * 32 + surfels["texel_x"]
     assert len(set(cells[:n_a].tolist()) & set(cells[n_a:].tolist())) == 16 * 16
+
+
+# ---- the 4-ary collapse --------------------------------------------------------------------
+@pytest.mark.parametrize("make", [lambda: scenes.terrain_scene(grid=48, atlas=64), lambda: scenes.sphere_scene(n=24, atlas=64),
+                                  lambda: scenes.cube_scene(64), lambda: scenes.plane_scene(8)])
+def test_bvh4_is_a_collapse_of_the_bvh2(orc, make):
+    flat = FlatScene(make())
+    nodes2, depth = orc.bvh_build(orc.scene_triangles(flat.desc))
+    nodes4, tris = orc.bvh4_build(nodes2)
+    n = (len(nodes2) + 1) // 2
+    assert len(tris) == n and len(nodes4) == max(1, n - 1)
+    refs = nodes4["lo"][:, :, 3].view(np.uint32)
+    # walk from the root: every triangle is reached exactly once, every visited node is non-empty
+    seen, stack, visited = [], [0], 0
+    while stack:
+        i = stack.pop(); visited += 1
+        for j in range(4):
+            r = int(refs[i, j])
+            if r == capi.INVALID_ADDR:
+                continue
+            lo, hi = nodes4["lo"][i, j, :3], nodes4["hi"][i, j, :3]
+            assert (lo <= hi).all()
+            if r & 0x80000000:
+                p = r & 0x7fffffff
+                seen.append(p)
+                v = np.stack([tris["v0"][p, :3], tris["v1"][p, :3], tris["v2"][p, :3]])
+                assert np.array_equal(lo, v.min(axis=0)) and np.array_equal(hi, v.max(axis=0))
+            else:
+                stack.append(r)
+    assert sorted(seen) == list(range(n))
+    if n > 1:
+        # the boxes are BVH2 boxes: the root's four children are the root's grandchildren
+        root2 = nodes2[0]
+        kids = []
+        for a, lo, hi in ((root2["addr_left"], root2["lmin_or_v0"], root2["lmax_or_v1"]), (root2["addr_right"], root2["rmin_or_v2"], root2["rmax"])):
+            if a < n - 1:
+                c = nodes2[a]
+                kids += [(c["lmin_or_v0"], c["lmax_or_v1"]), (c["rmin_or_v2"], c["rmax"])]
+            else:
+                kids.append((lo, hi))
+        for j, (lo, hi) in enumerate(kids):
+            assert np.array_equal(nodes4["lo"][0, j, :3], lo) and np.array_equal(nodes4["hi"][0, j, :3], hi)
+
+
+@pytest.mark.parametrize("any_hit", [1, 0])
+def test_bvh4_and_bvh2_walks_agree(orc, any_hit):
+    """The 4-ary walk tests a subset of the BVH2 boxes against the same triangles: same answer."""
+    flat = FlatScene(scenes.terrain_scene(grid=48, atlas=64))
+    nodes, _ = orc.bvh_build(orc.scene_triangles(flat.desc))
+    out = {}
+    for width in (2, 4):
+        o = opts(orc, sample_count=32, sampler=capi.SAMPLER_COSINE, accumulate=capi.ACCUMULATE_FLOAT, use_any_hit=any_hit,
+                 bvh_width=width, seed=9)
+        surfels, sidx = orc.rasterize(flat.desc, 0, o)
+        out[width], st = orc.trace(nodes, surfels, sidx, o, 64, 64, threads=4)
+        out[(width, "visits")] = (st.inner_visits + st.leaf_visits) / st.rays
+    assert np.array_equal(out[2]["total_bits"], out[4]["total_bits"])
+    assert np.array_equal(out[2]["weight_bits"], out[4]["weight_bits"])
+    assert out[(4, "visits")] < 0.7 * out[(2, "visits")]      # and it fetches far fewer nodes
