@@ -88,6 +88,15 @@ class Baker:
         capi.check(self.lib.aob_bake_copy_leaf_tris(self.handle, out.ctypes.data, n))
         return out[:n]
 
+    def nodes2q(self):
+        """(AobBvh2QNode words [n-1, 8] uint32, frame [6] float32)."""
+        n = max(0, int(self.stats().triangle_count) - 1)
+        out = np.zeros((max(n, 1), 8), dtype=np.uint32)
+        capi.check(self.lib.aob_bake_copy_nodes2q(self.handle, out.ctypes.data, n))
+        frame = np.zeros(6, dtype=np.float32)
+        capi.check(self.lib.aob_bake_quant_frame(self.handle, frame.ctypes.data))
+        return out[:n], frame
+
     def surfel_count(self, material=0) -> int:
         n = C.c_uint64()
         capi.check(self.lib.aob_bake_surfel_count(self.handle, material, C.byref(n)))

@@ -40,7 +40,8 @@ class AobOptions(C.Structure):
         ("ray_chunk_size", C.c_int32),
         ("clamp_tmax_to_falloff", C.c_int32),
         ("bvh_width", C.c_int32),
-        ("reserved", C.c_int32 * 3),
+        ("bvh_quantised", C.c_int32),
+        ("reserved", C.c_int32 * 2),
     ]
 
 
@@ -147,6 +148,7 @@ EXPORTED_SYMBOLS = [
     "aob_bake_copy_surfels", "aob_bake_copy_results", "aob_bake_results_device_ptr",
     "aob_bake_image_device_ptr", "aob_bake_stream", "aob_bake_last_trace_ms",
     "aob_bake_surfel_cell_range", "aob_bake_node4_count", "aob_bake_copy_nodes4", "aob_bake_copy_leaf_tris",
+    "aob_bake_copy_nodes2q", "aob_bake_quant_frame",
 ]
 
 
@@ -207,6 +209,8 @@ def load() -> C.CDLL:
         "aob_bake_node4_count": (C.c_int, [vp, P(u64)]),
         "aob_bake_copy_nodes4": (C.c_int, [vp, vp, u64]),
         "aob_bake_copy_leaf_tris": (C.c_int, [vp, vp, u64]),
+        "aob_bake_copy_nodes2q": (C.c_int, [vp, vp, u64]),
+        "aob_bake_quant_frame": (C.c_int, [vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

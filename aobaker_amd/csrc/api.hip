@@ -86,7 +86,7 @@ static void free_bake(AobBake* b)
     hipFree(b->tri_verts); hipFree(b->prim_bounds); hipFree(b->scene_bounds_enc);
     hipFree(b->codes[0]); hipFree(b->codes[1]); hipFree(b->prim_idx[0]); hipFree(b->prim_idx[1]);
     hipFree(b->sort_temp); hipFree(b->child_left); hipFree(b->child_right); hipFree(b->parent);
-    hipFree(b->node_bounds); hipFree(b->refit_flags); hipFree(b->depth_dev); hipFree(b->nodes); hipFree(b->nodes4); hipFree(b->leaf_tris);
+    hipFree(b->node_bounds); hipFree(b->refit_flags); hipFree(b->depth_dev); hipFree(b->nodes); hipFree(b->nodes4); hipFree(b->leaf_tris); hipFree(b->nodes2q); hipFree(b->quant_frame);
     hipFree(b->hemisphere); hipFree(b->gstack);
     if (b->pinned) hipHostFree(b->pinned);
     for (auto& e : b->ev) if (e) hipEventDestroy(e);
@@ -141,6 +141,9 @@ void aob_default_options(AobOptions* o)
     o->normal_fp16 = AOB_FP16_RNE;
     o->ray_chunk_size = 0xFFFFFF;
     o->clamp_tmax_to_falloff = 0;
+    // measured fastest on MI355X (profiles/): lane-per-ray walk of the 32-byte quantised BVH2 nodes
+    o->bvh_width = 2;
+    o->bvh_quantised = 1;
 }
 
 int aob_init(const AobDeviceConfig* config)
@@ -256,6 +259,8 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
     AOB_C(dev_alloc(&b->nodes, 2 * n));
     AOB_C(dev_alloc(&b->nodes4, 8 * n));
     AOB_C(dev_alloc(&b->leaf_tris, 3 * n));
+    AOB_C(dev_alloc(&b->nodes2q, 2 * n));
+    AOB_C(dev_alloc(&b->quant_frame, 8));
     if (n) {
         size_t temp = 0;
         AOB_CH(rocprim::radix_sort_pairs(nullptr, temp, b->codes[0], b->codes[1], b->prim_idx[0], b->prim_idx[1],
@@ -460,6 +465,25 @@ int aob_bake_copy_leaf_tris(AobBake* b, AobLeafTri* dst, uint64_t capacity)
     const uint64_t n = b->bvh_built ? b->triangle_count : 0;
     if (capacity < n || (!dst && n)) { set_error("leaf triangle buffer too small"); return AOB_ERR_INVALID_ARGUMENT; }
     if (n) AOB_HIP(hipMemcpyAsync(dst, b->leaf_tris, sizeof(AobLeafTri) * n, hipMemcpyDeviceToHost, b->stream));
+    AOB_HIP(hipStreamSynchronize(b->stream));
+    return AOB_OK;
+}
+
+int aob_bake_copy_nodes2q(AobBake* b, AobBvh2QNode* dst, uint64_t capacity)
+{
+    AOB_TRY(check_bake(b, 0, false));
+    const uint64_t n = b->bvh_built && b->triangle_count ? b->triangle_count - 1 : 0;
+    if (capacity < n || (!dst && n)) { set_error("quantised node buffer too small"); return AOB_ERR_INVALID_ARGUMENT; }
+    if (n) AOB_HIP(hipMemcpyAsync(dst, b->nodes2q, sizeof(AobBvh2QNode) * n, hipMemcpyDeviceToHost, b->stream));
+    AOB_HIP(hipStreamSynchronize(b->stream));
+    return AOB_OK;
+}
+
+int aob_bake_quant_frame(AobBake* b, AobQuantFrame* frame)
+{
+    AOB_TRY(check_bake(b, 0, false));
+    if (!frame) { set_error("frame is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
+    AOB_HIP(hipMemcpyAsync(frame, b->quant_frame, sizeof(AobQuantFrame), hipMemcpyDeviceToHost, b->stream));
     AOB_HIP(hipStreamSynchronize(b->stream));
     return AOB_OK;
 }

@@ -296,6 +296,54 @@ void k_collapse4(uint32_t n, const uint32_t* __restrict__ parent, const uint32_t
     }
 }
 
+// ---- 16-bit quantised BVH2 nodes ------------------------------------------------------------
+// frame: origin = scene min, scale = extent / 65535 nudged up until origin + 65535*scale >= scene max
+__global__ void k_quant_frame(const uint32_t* __restrict__ scene_enc, float* __restrict__ frame)
+{
+    const int k = threadIdx.x;
+    if (k >= 3) return;
+    const float smin = dec_float(scene_enc[k]), smax = dec_float(scene_enc[3 + k]);
+    const float extent = smax - smin;
+    float scale = extent > 0.0f ? extent / 65535.0f : 0.0f;
+    if (scale > 0.0f) while (fmaf(65535.0f, scale, smin) < smax) scale = __uint_as_float(__float_as_uint(scale) + 1u);
+    frame[k] = smin; frame[3 + k] = scale;
+}
+
+// largest q with origin + q*scale <= v  /  smallest q with origin + q*scale >= v
+__device__ __forceinline__ uint32_t quant_down(float v, float origin, float scale)
+{
+    if (!(scale > 0.0f)) return 0u;
+    float q = fminf(fmaxf(floorf((v - origin) / scale), 0.0f), 65535.0f);
+    while (q > 0.0f && fmaf(q, scale, origin) > v) q -= 1.0f;
+    return (uint32_t)q;
+}
+__device__ __forceinline__ uint32_t quant_up(float v, float origin, float scale)
+{
+    if (!(scale > 0.0f)) return 0u;
+    float q = fminf(fmaxf(ceilf((v - origin) / scale), 0.0f), 65535.0f);
+    while (q < 65535.0f && fmaf(q, scale, origin) < v) q += 1.0f;
+    return (uint32_t)q;
+}
+
+__global__ __launch_bounds__(kBlock)
+void k_emit_nodes_q(uint32_t n, const uint32_t* __restrict__ child_left, const uint32_t* __restrict__ child_right,
+                    const Box* __restrict__ node_bounds, const float* __restrict__ frame, uint4* __restrict__ nodesq)
+{
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n - 1) return;
+    const uint32_t l = child_left[i], r = child_right[i];
+    const Box bl = node_bounds[l], br = node_bounds[r];
+    uint32_t q[12];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float o = frame[k], sc = frame[3 + k];
+        q[k] = quant_down(bl.pmin[k], o, sc); q[3 + k] = quant_up(bl.pmax[k], o, sc);
+        q[6 + k] = quant_down(br.pmin[k], o, sc); q[9 + k] = quant_up(br.pmax[k], o, sc);
+    }
+    nodesq[2ull * i + 0] = make_uint4(q[0] | q[1] << 16, q[2] | q[3] << 16, q[4] | q[5] << 16, q[6] | q[7] << 16);
+    nodesq[2ull * i + 1] = make_uint4(q[8] | q[9] << 16, q[10] | q[11] << 16, l, r);
+}
+
 // n == 1: the tree is a single leaf; give it a 4-ary root with that one child
 __global__ void k_single_leaf4(const Box* __restrict__ prim_bounds, float4* __restrict__ nodes4)
 {
@@ -370,6 +418,9 @@ int build_bvh(AobBake* b)
     if (n == 1) hipLaunchKernelGGL(k_single_leaf4, dim3(1), dim3(64), 0, s, b->prim_bounds, b->nodes4);
     else hipLaunchKernelGGL(k_collapse4, dim3(blocks_for(n - 1)), dim3(kBlock), 0, s, (uint32_t)n, b->parent, b->child_left,
                             b->child_right, b->node_bounds, b->nodes4);
+    hipLaunchKernelGGL(k_quant_frame, dim3(1), dim3(64), 0, s, b->scene_bounds_enc, b->quant_frame);
+    if (n > 1) hipLaunchKernelGGL(k_emit_nodes_q, dim3(blocks_for(n - 1)), dim3(kBlock), 0, s, (uint32_t)n, b->child_left,
+                                  b->child_right, b->node_bounds, b->quant_frame, b->nodes2q);
     hipLaunchKernelGGL(k_leaf_tris, dim3(blocks_for(n)), dim3(kBlock), 0, s, (uint32_t)n, b->prim_idx[1], b->tri_verts,
                        b->leaf_tris);
     AOB_HIP(hipGetLastError());

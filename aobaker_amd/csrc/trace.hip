@@ -41,10 +41,14 @@ namespace aob {
 
 static constexpr int kBlock = 256;
 static constexpr int kBlocksPerSurfel = 16;       // sample blocks per surfel
+static constexpr int kLdsStack = 16;              // traversal stack entries per lane kept in LDS
 static constexpr uint32_t kInvalid = 0xffffffffu;
 
 struct TraceParams {
     const float4* nodes;
+    const uint4* nodesq;           // QUANT: 2 x uint4 per node (AobBvh2QNode)
+    const float4* leaf_tris;       // QUANT: 3 x float4 per triangle
+    const float* quant_frame;      // QUANT: origin[3], scale[3]
     const float4* frames;          // 4 x float4 per surfel (k_surfel_frames)
     AobResult* results;
     const float* hemisphere;
@@ -72,8 +76,14 @@ __device__ __forceinline__ long long f2fix(float v)
 }
 
 // LDS_N: stack entries per lane kept in LDS; deeper entries spill to p.gstack.
-template <int SAMPLER, int ANYHIT, int ACCUM, int LDS_N>
-__global__ __launch_bounds__(kBlock)
+// QUANT: walk the 32-byte nodes with 16-bit quantised child boxes (two 16-byte fetches per visit
+// instead of four — the kernel is bound by L1 accesses, profiles/r01) and the 48-byte leaf triangles.
+#ifndef AOB_TRACE_WAVES
+#define AOB_TRACE_WAVES 8          // waves per SIMD the register allocator must leave room for (<= 64 VGPRs):
+                                   // measured 4.98 / 5.14 / 5.55 Grays/s at 6 / 7 / 8 — latency hiding beats the few spills
+#endif
+template <int SAMPLER, int ANYHIT, int ACCUM, int LDS_N, int QUANT>
+__global__ __launch_bounds__(kBlock, AOB_TRACE_WAVES)
 void k_trace(TraceParams p)
 {
     __shared__ uint32_t lds_stack[LDS_N * kBlock];
@@ -91,6 +101,12 @@ void k_trace(TraceParams p)
     const uint32_t total_items = nsurf ? 64u * kBlocksPerSurfel : 0u;      // item = block * 64 + surfel slot
     uint32_t item_next = 0;                                                // wave-uniform
 
+    f3 q_origin = make_f3(0.f, 0.f, 0.f), q_scale = make_f3(0.f, 0.f, 0.f);
+    if (QUANT) {
+        q_origin = make_f3(p.quant_frame[0], p.quant_frame[1], p.quant_frame[2]);
+        q_scale = make_f3(p.quant_frame[3], p.quant_frame[4], p.quant_frame[5]);
+    }
+
     acc[tid][0] = 0ull; acc[tid][1] = 0ull;
     lds_stack[tid] = kInvalid;       // entry 0: the INVALID sentinel (intersect_bvh2_lds.cl:103): a pop is one read
     uint32_t* gs = p.gstack + ((uint64_t)blockIdx.x * kBlock + tid);       // overflow entry e at gs[e * gstride]
@@ -100,7 +116,7 @@ void k_trace(TraceParams p)
     int32_t cur = 0, blk_end = 0;
     uint32_t slot = 0;
     bool has_partial = false;
-    long long pT = 0, pW = 0;                // partial sums of the current block
+    long long pT = 0, pW = 0, cW = 0;        // block sums; this ray's weight contribution                // partial sums of the current block
     f3 P, N, X, Z;
     P = N = X = Z = make_f3(0.f, 0.f, 0.f);
     uint32_t hash_base = 0;
@@ -128,11 +144,17 @@ void k_trace(TraceParams p)
     };
     // ProcessIntersectionsComputeShader.hlsl:69-90
     auto finish = [&]() {
-        float r;
-        if (ANYHIT) r = hit ? 0.0f : 1.0f;
-        else r = (hit && closest_t < p.falloff) ? closest_t / p.falloff : 1.0f;
-        if (ACCUM == AOB_ACCUMULATE_QUANTISED) { pT += ftoi(r * w * 255.0f); pW += ftoi(w * 255.0f); }
-        else { pT += f2fix(r * w); pW += f2fix(w); }
+        if (ANYHIT) {
+            // r is 0 or 1: the sample adds cW to the weight and, if unoccluded, cW to the total
+            // ((1.0f * w) * 255.0f == w * 255.0f exactly).  cW was converted when the ray was made,
+            // with the whole refill group active; this path runs with one or two lanes.
+            pW += cW;
+            if (!hit) pT += cW;
+        } else {
+            const float r = (hit && closest_t < p.falloff) ? closest_t / p.falloff : 1.0f;
+            if (ACCUM == AOB_ACCUMULATE_QUANTISED) { pT += ftoi(r * w * 255.0f); pW += cW; }
+            else { pT += f2fix(r * w); pW += cW; }
+        }
         active = false;
     };
 
@@ -187,8 +209,14 @@ void k_trace(TraceParams p)
                               fmaf(h.z, Z.z, fmaf(h.y, N.z, h.x * X.z)));                       // GenerateRays:46
                 org = make_f3(fmaf(dir.x, p.bias, P.x), fmaf(dir.y, p.bias, P.y), fmaf(dir.z, p.bias, P.z)); // :47
                 w = SAMPLER == AOB_SAMPLER_REFERENCE_COMPAT ? dot(N, dir) : 1.0f;
+                cW = ACCUM == AOB_ACCUMULATE_QUANTISED ? (long long)ftoi(w * 255.0f) : f2fix(w);
                 invdir = make_f3(safe_inv1(dir.x), safe_inv1(dir.y), safe_inv1(dir.z));
                 oxinvdir = make_f3(-org.x * invdir.x, -org.y * invdir.y, -org.z * invdir.z);
+                if (QUANT) {
+                    // fold the de-quantisation into the ray: (origin + q*scale - o) * invdir = q*(scale*invdir) + (origin*invdir + oxinvdir)
+                    oxinvdir = make_f3(fmaf(q_origin.x, invdir.x, oxinvdir.x), fmaf(q_origin.y, invdir.y, oxinvdir.y), fmaf(q_origin.z, invdir.z, oxinvdir.z));
+                    invdir = make_f3(q_scale.x * invdir.x, q_scale.y * invdir.y, q_scale.z * invdir.z);
+                }
                 closest_t = p.tmax; hit = false; sp = 1;
                 active = true;
                 addr = 0;
@@ -202,7 +230,7 @@ void k_trace(TraceParams p)
         const uint64_t inner_m = __ballot(inner);
         if (__popcll(__ballot(at_leaf)) >= p.leaf_wait || inner_m == 0ull) {
             if (at_leaf) {
-                const float4* np = p.nodes + 4ull * addr;
+                const float4* np = QUANT ? p.leaf_tris + 3ull * (addr - p.leaf_base) : p.nodes + 4ull * addr;
                 const float4 n0 = np[0], n1 = np[1], n2 = np[2];
                 const float t = intersect_triangle(org, dir, make_f3(n0.x, n0.y, n0.z), make_f3(n1.x, n1.y, n1.z),
                                                    make_f3(n2.x, n2.y, n2.z), closest_t);
@@ -215,14 +243,26 @@ void k_trace(TraceParams p)
 
         // ---- inner section: intersect_bvh2_lds.cl:108-160 ----
         if (inner) {
-            const float4* np = p.nodes + 4ull * addr;
-            const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
             float s0x, s0y, s1x, s1y;
-            intersect_bbox(make_f3(n0.x, n0.y, n0.z), make_f3(n1.x, n1.y, n1.z), invdir, oxinvdir, closest_t, s0x, s0y);
-            intersect_bbox(make_f3(n2.x, n2.y, n2.z), make_f3(n3.x, n3.y, n3.z), invdir, oxinvdir, closest_t, s1x, s1y);
+            uint32_t al, ar;
+            if (QUANT) {
+                const uint4* np = p.nodesq + 2ull * addr;
+                const uint4 a = np[0], b = np[1];
+                // invdir/oxinvdir hold the folded frame here, so the slab test runs on the raw 16-bit grid values
+                intersect_bbox(make_f3((float)(a.x & 0xffffu), (float)(a.x >> 16), (float)(a.y & 0xffffu)),
+                               make_f3((float)(a.y >> 16), (float)(a.z & 0xffffu), (float)(a.z >> 16)), invdir, oxinvdir, closest_t, s0x, s0y);
+                intersect_bbox(make_f3((float)(a.w & 0xffffu), (float)(a.w >> 16), (float)(b.x & 0xffffu)),
+                               make_f3((float)(b.x >> 16), (float)(b.y & 0xffffu), (float)(b.y >> 16)), invdir, oxinvdir, closest_t, s1x, s1y);
+                al = b.z; ar = b.w;
+            } else {
+                const float4* np = p.nodes + 4ull * addr;
+                const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                intersect_bbox(make_f3(n0.x, n0.y, n0.z), make_f3(n1.x, n1.y, n1.z), invdir, oxinvdir, closest_t, s0x, s0y);
+                intersect_bbox(make_f3(n2.x, n2.y, n2.z), make_f3(n3.x, n3.y, n3.z), invdir, oxinvdir, closest_t, s1x, s1y);
+                al = __float_as_uint(n0.w); ar = __float_as_uint(n2.w);
+            }
             const bool c0 = s0x <= s0y, c1 = s1x <= s1y;
             const bool right_first = (c1 && (s0x > s1x)) || !c0;
-            const uint32_t al = __float_as_uint(n0.w), ar = __float_as_uint(n2.w);
             if (c0 && c1) push(right_first ? al : ar);
             addr = right_first ? ar : al;
             if (!(c0 || c1)) {
@@ -261,23 +301,22 @@ void k_trace(TraceParams p)
 }
 
 template <int SAMPLER, int ANYHIT, int ACCUM>
-static void launch_stack(int lds_n, dim3 grid, hipStream_t s, const TraceParams& p)
+static void launch_stack(bool quant, dim3 grid, hipStream_t s, const TraceParams& p)
 {
-    if (lds_n <= 16) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, 16>), grid, dim3(kBlock), 0, s, p);
-    else if (lds_n <= 24) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, 24>), grid, dim3(kBlock), 0, s, p);
-    else hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, 32>), grid, dim3(kBlock), 0, s, p);
+    if (quant) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, kLdsStack, 1>), grid, dim3(kBlock), 0, s, p);
+    else hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, kLdsStack, 0>), grid, dim3(kBlock), 0, s, p);
 }
 template <int SAMPLER, int ANYHIT>
-static void launch_acc(int accum, int lds_n, dim3 grid, hipStream_t s, const TraceParams& p)
+static void launch_acc(int accum, bool quant, dim3 grid, hipStream_t s, const TraceParams& p)
 {
-    if (accum == AOB_ACCUMULATE_QUANTISED) launch_stack<SAMPLER, ANYHIT, AOB_ACCUMULATE_QUANTISED>(lds_n, grid, s, p);
-    else launch_stack<SAMPLER, ANYHIT, AOB_ACCUMULATE_FLOAT>(lds_n, grid, s, p);
+    if (accum == AOB_ACCUMULATE_QUANTISED) launch_stack<SAMPLER, ANYHIT, AOB_ACCUMULATE_QUANTISED>(quant, grid, s, p);
+    else launch_stack<SAMPLER, ANYHIT, AOB_ACCUMULATE_FLOAT>(quant, grid, s, p);
 }
 template <int SAMPLER>
-static void launch_hit(int anyhit, int accum, int lds_n, dim3 grid, hipStream_t s, const TraceParams& p)
+static void launch_hit(int anyhit, int accum, bool quant, dim3 grid, hipStream_t s, const TraceParams& p)
 {
-    if (anyhit) launch_acc<SAMPLER, 1>(accum, lds_n, grid, s, p);
-    else launch_acc<SAMPLER, 0>(accum, lds_n, grid, s, p);
+    if (anyhit) launch_acc<SAMPLER, 1>(accum, quant, grid, s, p);
+    else launch_acc<SAMPLER, 0>(accum, quant, grid, s, p);
 }
 
 uint64_t chunk_texel_max(const AobOptions& opt)
@@ -303,16 +342,19 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
     if (end > m.surfel_count) end = m.surfel_count;
     hipStream_t s = b->stream;
     AOB_HIP(hipEventRecord(b->ev_trace[0], s));
-    if (begin < end && o.bvh_width != 2) {
-        AOB_TRY(trace4_range(b, material, begin, end));        // default: quad-per-ray, 4-ary nodes (trace4.hip)
+    if (begin < end && o.bvh_width == 4) {
+        AOB_TRY(trace4_range(b, material, begin, end));        // quad-per-ray, 4-ary nodes (trace4.hip)
     } else if (begin < end) {
         // a lane's stack holds the sentinel plus at most one deferred sibling per tree level
         const uint32_t need = b->bvh_depth + 2;
-        const int lds_n = env_int("AOB_TRACE_LDS_STACK", 24);       // tuning/test hook (16 | 24 | 32)
-        const int lds_eff = lds_n <= 16 ? 16 : (lds_n <= 24 ? 24 : 32);
+        // 16 stack entries per lane live in LDS (16 KB + 4 KB of sums per block = 8 blocks per CU);
+        // deeper entries — rare — go to an HBM array.  24 and 32 entries measured 11 % and 23 % slower.
+        const int lds_eff = kLdsStack;
         const uint32_t overflow = need > (uint32_t)lds_eff ? need - (uint32_t)lds_eff : 0u;
         TraceParams p;
         p.nodes = (const float4*)b->nodes;
+        p.nodesq = b->nodes2q; p.leaf_tris = b->leaf_tris; p.quant_frame = b->quant_frame;
+        const bool quant = o.bvh_quantised != 0;
         p.frames = m.frames; p.results = m.results;
         p.hemisphere = b->hemisphere;
         p.node_count = (uint32_t)b->node_count;
@@ -323,8 +365,8 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
         p.tmax = o.ray_tmax;
         if (!o.use_any_hit && o.clamp_tmax_to_falloff && o.falloff_distance < p.tmax) p.tmax = o.falloff_distance;
         p.bias = o.ray_bias; p.falloff = o.falloff_distance;
-        p.refill_idle = max(1, env_int("AOB_TRACE_REFILL_IDLE", 16));
-        p.leaf_wait = max(1, env_int("AOB_TRACE_LEAF_WAIT", 16));
+        p.refill_idle = max(1, env_int("AOB_TRACE_REFILL_IDLE", 12));
+        p.leaf_wait = max(1, env_int("AOB_TRACE_LEAF_WAIT", 12));
         cosine_grid(o.sample_count, p.grid);
         // one launch per section: two sections of a material may cover the same texel, and
         // their contributions are added in section order (BakeEngine.cpp:473,659)
@@ -345,8 +387,8 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
                 b->gstack_words = words;
             }
             p.gstack = b->gstack;
-            if (o.sampler == AOB_SAMPLER_REFERENCE_COMPAT) launch_hit<AOB_SAMPLER_REFERENCE_COMPAT>(o.use_any_hit, o.accumulate, lds_eff, grid, s, p);
-            else launch_hit<AOB_SAMPLER_COSINE>(o.use_any_hit, o.accumulate, lds_eff, grid, s, p);
+            if (o.sampler == AOB_SAMPLER_REFERENCE_COMPAT) launch_hit<AOB_SAMPLER_REFERENCE_COMPAT>(o.use_any_hit, o.accumulate, quant, grid, s, p);
+            else launch_hit<AOB_SAMPLER_COSINE>(o.use_any_hit, o.accumulate, quant, grid, s, p);
         }
         AOB_HIP(hipGetLastError());
     }

@@ -92,7 +92,7 @@ void k_trace4(Trace4Params p)
     int32_t cur = 0, blk_end = 0;
     uint32_t slot = 0;
     bool has_partial = false;
-    long long pT = 0, pW = 0;
+    long long pT = 0, pW = 0, cW = 0;        // block sums; this ray's weight contribution
     f3 P, N, X, Z;
     P = N = X = Z = make_f3(0.f, 0.f, 0.f);
     uint32_t hash_base = 0;
@@ -114,11 +114,17 @@ void k_trace4(Trace4Params p)
         return v;
     };
     auto finish = [&]() {
-        float r;
-        if (ANYHIT) r = hit ? 0.0f : 1.0f;
-        else r = (hit && closest_t < p.falloff) ? closest_t / p.falloff : 1.0f;
-        if (ACCUM == AOB_ACCUMULATE_QUANTISED) { pT += ftoi(r * w * 255.0f); pW += ftoi(w * 255.0f); }
-        else { pT += f2fix4(r * w); pW += f2fix4(w); }
+        if (ANYHIT) {
+            // r is 0 or 1: the sample adds cW to the weight and, if unoccluded, cW to the total
+            // ((1.0f * w) * 255.0f == w * 255.0f exactly).  cW was converted when the ray was made,
+            // with the whole refill group active; this path runs with one or two lanes.
+            pW += cW;
+            if (!hit) pT += cW;
+        } else {
+            const float r = (hit && closest_t < p.falloff) ? closest_t / p.falloff : 1.0f;
+            if (ACCUM == AOB_ACCUMULATE_QUANTISED) { pT += ftoi(r * w * 255.0f); pW += cW; }
+            else { pT += f2fix4(r * w); pW += cW; }
+        }
         active = false;
     };
 
@@ -174,6 +180,7 @@ void k_trace4(Trace4Params p)
                               fmaf(h.z, Z.z, fmaf(h.y, N.z, h.x * X.z)));                       // GenerateRays:46
                 org = make_f3(fmaf(dir.x, p.bias, P.x), fmaf(dir.y, p.bias, P.y), fmaf(dir.z, p.bias, P.z)); // :47
                 w = SAMPLER == AOB_SAMPLER_REFERENCE_COMPAT ? dot(N, dir) : 1.0f;
+                cW = ACCUM == AOB_ACCUMULATE_QUANTISED ? (long long)ftoi(w * 255.0f) : f2fix4(w);
                 invdir = make_f3(safe_inv1(dir.x), safe_inv1(dir.y), safe_inv1(dir.z));
                 oxinvdir = make_f3(-org.x * invdir.x, -org.y * invdir.y, -org.z * invdir.z);
                 closest_t = p.tmax; hit = false; sp = 1;

@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--atlas", type=int, default=2048)
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--grid", type=int, default=708, help="terrain grid (708 -> 999 698 triangles)")
+    ap.add_argument("--bvh-width", type=int, default=0, help="0 = library default, 2 = lane-per-ray BVH2, 4 = quad-per-ray 4-ary")
+    ap.add_argument("--bvh-quantised", type=int, default=-1, help="-1 = library default; 1 = 32-byte 16-bit nodes (width 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -73,6 +75,10 @@ def main():
     opts.use_any_hit = 1
     opts.accumulate = capi.ACCUMULATE_FLOAT
     opts.normal_fp16 = capi.FP16_OFF
+    if args.bvh_width:
+        opts.bvh_width = args.bvh_width
+    if args.bvh_quantised >= 0:
+        opts.bvh_quantised = args.bvh_quantised
 
     baker = Baker(flat, opts)           # uploads the scene: inputs resident in HBM from here on
     cells = aod.alias_results(baker, 0, as_float=True) if world > 1 else None

@@ -63,8 +63,11 @@ typedef struct AobOptions {
     int32_t  clamp_tmax_to_falloff; /* falloff mode: cast with tmax=min(tmax,falloff)     */
     int32_t  bvh_width;           /* traversal structure: 2 = the reference's BVH2 nodes, one lane
                                      per ray; 4 = BVH2 collapsed to 4-ary nodes, four lanes per ray
-                                     (one per child box); 0 = library default (4)                */
-    int32_t  reserved[3];
+                                     (one per child box); 0 = 2.  Default 2 (fastest measured)    */
+    int32_t  bvh_quantised;       /* bvh_width 2 only (default 1).  0: 64-byte fp32 nodes (the reference layout);
+                                     1: 32-byte nodes, child boxes as 16-bit fixed point on the scene
+                                     box, rounded outward (AobBvh2QNode)                            */
+    int32_t  reserved[2];
 } AobOptions;
 
 /* ---- scene description ----------------------------------------------------
@@ -157,6 +160,14 @@ typedef struct AobBvhNode {
  * The two 64-byte halves are what the four lanes of a ray's quad fetch with one access each. */
 typedef struct AobBvh4Node { float lo[4][4]; float hi[4][4]; } AobBvh4Node;
 #define AOB_LEAF_FLAG 0x80000000u
+/* 32 B BVH2 node with quantised child boxes: q = 16-bit fixed point on the scene box,
+ * box.min rounded down, box.max rounded up; decode: frame.origin + q * frame.scale.
+ * w0 = lmin.x | lmin.y<<16, w1 = lmin.z | lmax.x<<16, w2 = lmax.y | lmax.z<<16,
+ * w3 = rmin.x | rmin.y<<16, w4 = rmin.z | rmax.x<<16, w5 = rmax.y | rmax.z<<16,
+ * w6 = addr_left, w7 = addr_right.  Inner nodes only ([0, n-1)); a child address >= n-1 is leaf
+ * triangle (address - (n-1)) of AobLeafTri[].  Two 16-byte fetches per visit instead of four. */
+typedef struct AobBvh2QNode { uint32_t w[8]; } AobBvh2QNode;
+typedef struct AobQuantFrame { float origin[3]; float scale[3]; } AobQuantFrame;
 /* 48 B leaf triangle in Morton order: v0.w = shape id bits, v1.w = prim id bits. */
 typedef struct AobLeafTri { float v0[4], v1[4], v2[4]; } AobLeafTri;
 
@@ -222,6 +233,9 @@ int aob_bake_copy_nodes(AobBake* bake, AobBvhNode* dst, uint64_t capacity);
 int aob_bake_node4_count(AobBake* bake, uint64_t* count);
 int aob_bake_copy_nodes4(AobBake* bake, AobBvh4Node* dst, uint64_t capacity);
 int aob_bake_copy_leaf_tris(AobBake* bake, AobLeafTri* dst, uint64_t capacity);
+/* The quantised BVH2 (max(0, n-1) AobBvh2QNode entries) and its frame. */
+int aob_bake_copy_nodes2q(AobBake* bake, AobBvh2QNode* dst, uint64_t capacity);
+int aob_bake_quant_frame(AobBake* bake, AobQuantFrame* frame);
 int aob_bake_surfel_count(AobBake* bake, int32_t material, uint64_t* count);
 int aob_bake_copy_surfels(AobBake* bake, int32_t material, AobSurfel* dst, uint64_t capacity);
 int aob_bake_copy_results(AobBake* bake, int32_t material, AobResult* dst, uint64_t capacity);

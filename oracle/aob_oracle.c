@@ -700,6 +700,119 @@ uint64_t orc_bvh4_build(const AobBvhNode* nodes2, uint64_t node_count2, AobBvh4N
     return count4;
 }
 
+#define ORC_STACK 128
+
+/* ---- 16-bit quantised BVH2 nodes (AobBvh2QNode) ----------------------------------------- */
+/* frame: origin = scene min, scale = extent/65535 nudged up until origin + 65535*scale >= max;
+ * child box min rounded down, max rounded up on that grid (so the decoded box contains the fp32
+ * box).  The scene box is the union of the root's two child boxes. */
+static inline uint32_t quant_down(float v, float origin, float scale)
+{
+    if (!(scale > 0.0f)) return 0u;
+    float q = fminf(fmaxf(floorf((v - origin) / scale), 0.0f), 65535.0f);
+    while (q > 0.0f && fmaf(q, scale, origin) > v) q -= 1.0f;
+    return (uint32_t)q;
+}
+static inline uint32_t quant_up(float v, float origin, float scale)
+{
+    if (!(scale > 0.0f)) return 0u;
+    float q = fminf(fmaxf(ceilf((v - origin) / scale), 0.0f), 65535.0f);
+    while (q < 65535.0f && fmaf(q, scale, origin) < v) q += 1.0f;
+    return (uint32_t)q;
+}
+
+uint64_t orc_bvh2q_build(const AobBvhNode* nodes2, uint64_t node_count2, AobBvh2QNode* out, AobQuantFrame* frame)
+{
+    memset(frame, 0, sizeof *frame);
+    if (node_count2 == 0) return 0;
+    const uint64_t n = (node_count2 + 1) / 2;
+    float smin[3], smax[3];
+    const AobBvhNode* root = &nodes2[0];
+    for (int k = 0; k < 3; k++) {
+        if (n == 1) {
+            smin[k] = fminf(fminf(root->lmin_or_v0[k], root->lmax_or_v1[k]), root->rmin_or_v2[k]);
+            smax[k] = fmaxf(fmaxf(root->lmin_or_v0[k], root->lmax_or_v1[k]), root->rmin_or_v2[k]);
+        } else {
+            smin[k] = fminf(root->lmin_or_v0[k], root->rmin_or_v2[k]);
+            smax[k] = fmaxf(root->lmax_or_v1[k], root->rmax[k]);
+        }
+        float extent = smax[k] - smin[k];
+        float scale = extent > 0.0f ? extent / 65535.0f : 0.0f;
+        if (scale > 0.0f) while (fmaf(65535.0f, scale, smin[k]) < smax[k]) { uint32_t u; memcpy(&u, &scale, 4); u++; memcpy(&scale, &u, 4); }
+        frame->origin[k] = smin[k]; frame->scale[k] = scale;
+    }
+    for (uint64_t i = 0; i + 1 < n; i++) {
+        const AobBvhNode* nd = &nodes2[i];
+        uint32_t q[12];
+        for (int k = 0; k < 3; k++) {
+            const float o = frame->origin[k], sc = frame->scale[k];
+            q[k] = quant_down(nd->lmin_or_v0[k], o, sc); q[3 + k] = quant_up(nd->lmax_or_v1[k], o, sc);
+            q[6 + k] = quant_down(nd->rmin_or_v2[k], o, sc); q[9 + k] = quant_up(nd->rmax[k], o, sc);
+        }
+        uint32_t* w = out[i].w;
+        w[0] = q[0] | q[1] << 16; w[1] = q[2] | q[3] << 16; w[2] = q[4] | q[5] << 16; w[3] = q[6] | q[7] << 16;
+        w[4] = q[8] | q[9] << 16; w[5] = q[10] | q[11] << 16; w[6] = nd->addr_left; w[7] = nd->addr_right;
+    }
+    return n - 1;
+}
+
+/* intersect_bvh2_lds.cl's walk on the quantised nodes: the de-quantisation is folded into the ray,
+ * (origin + q*scale - o)*invdir = q*(scale*invdir) + (origin*invdir + oxinvdir), so the slab test of
+ * :54-63 runs on the raw grid values. */
+static inline int traverse2q(const AobBvh2QNode* nq, uint64_t n, const AobQuantFrame* fr, const AobLeafTri* tris,
+                             f3 o, f3 d, float t_max, int any_hit, float* t_out, OrcTraceStats* st, int* error)
+{
+    if (n == 0) { *t_out = t_max; return 0; }
+    f3 invdir = safe_invdir(d);
+    f3 oxinvdir = f3_make(-o.x * invdir.x, -o.y * invdir.y, -o.z * invdir.z);
+    f3 fb = f3_make(fmaf(fr->origin[0], invdir.x, oxinvdir.x), fmaf(fr->origin[1], invdir.y, oxinvdir.y), fmaf(fr->origin[2], invdir.z, oxinvdir.z));
+    f3 fa = f3_make(fr->scale[0] * invdir.x, fr->scale[1] * invdir.y, fr->scale[2] * invdir.z);
+    const uint32_t leaf_base = (uint32_t)(n - 1);
+    float closest_t = t_max;
+    int hit = 0;
+    uint32_t stack[ORC_STACK];
+    int sp = 0;
+    stack[sp++] = AOB_INVALID_ADDR;
+    uint32_t addr = 0;
+    while (addr != AOB_INVALID_ADDR) {
+        if (addr < leaf_base) {
+            const uint32_t* w = nq[addr].w;
+            st->inner_visits++;
+            const float lmin[3] = { (float)(w[0] & 0xffffu), (float)(w[0] >> 16), (float)(w[1] & 0xffffu) };
+            const float lmax[3] = { (float)(w[1] >> 16), (float)(w[2] & 0xffffu), (float)(w[2] >> 16) };
+            const float rmin[3] = { (float)(w[3] & 0xffffu), (float)(w[3] >> 16), (float)(w[4] & 0xffffu) };
+            const float rmax[3] = { (float)(w[4] >> 16), (float)(w[5] & 0xffffu), (float)(w[5] >> 16) };
+            float s0x, s0y, s1x, s1y;
+            intersect_bbox(lmin, lmax, fa, fb, closest_t, &s0x, &s0y);
+            intersect_bbox(rmin, rmax, fa, fb, closest_t, &s1x, &s1y);
+            int c0 = s0x <= s0y, c1 = s1x <= s1y;
+            int c1first = c1 && (s0x > s1x);
+            if (c0 || c1) {
+                uint32_t deferred;
+                if (c1first || !c0) { addr = w[7]; deferred = w[6]; }
+                else { addr = w[6]; deferred = w[7]; }
+                if (c0 && c1) {
+                    if (sp >= ORC_STACK) { *error = AOB_ERR_BVH_TOO_DEEP; *t_out = t_max; return 0; }
+                    stack[sp++] = deferred;
+                }
+                continue;
+            }
+        } else {
+            const AobLeafTri* tr = &tris[addr - leaf_base];
+            st->leaf_visits++;
+            float t = intersect_triangle(o, d, f3_make(tr->v0[0], tr->v0[1], tr->v0[2]), f3_make(tr->v1[0], tr->v1[1], tr->v1[2]),
+                                         f3_make(tr->v2[0], tr->v2[1], tr->v2[2]), closest_t);
+            if (t < closest_t) {
+                closest_t = t; hit = 1;
+                if (any_hit) break;
+            }
+        }
+        addr = stack[--sp];
+    }
+    *t_out = closest_t;
+    return hit;
+}
+
 #define ORC_STACK4 512
 
 /* The 4-ary walk of the GPU's quad-per-ray kernel, one ray at a time: slab-test the four child
@@ -762,11 +875,11 @@ static inline int traverse4(const AobBvh4Node* nodes4, uint64_t count4, const Ao
 /* ------------------------------------------------------------------------ */
 /* trace                                                                     */
 
-#define ORC_STACK 128
 
 typedef struct {
     const AobBvhNode* nodes; uint64_t node_count;
     const AobBvh4Node* nodes4; uint64_t node4_count; const AobLeafTri* tris;   /* bvh_width != 2 */
+    const AobBvh2QNode* nodes2q; AobQuantFrame frame; uint64_t tri_count;        /* bvh_width 2, bvh_quantised */
     const AobSurfel* surfels; const uint32_t* section_index;
     const AobOptions* opt; const float* hemisphere;
     int32_t width, height; AobResult* results;
@@ -884,7 +997,8 @@ static void trace_surfel(const TraceJob* job, uint64_t k, OrcTraceStats* st, int
         f3 org = f3_make(fmaf(dir.x, opt->ray_bias, P.x), fmaf(dir.y, opt->ray_bias, P.y), fmaf(dir.z, opt->ray_bias, P.z));
         float t;
         st->rays++;
-        int hit = job->nodes4 ? traverse4(job->nodes4, job->node4_count, job->tris, org, dir, t_max, any_hit, &t, st, error)
+        int hit = job->nodes2q ? traverse2q(job->nodes2q, job->tri_count, &job->frame, job->tris, org, dir, t_max, any_hit, &t, st, error)
+                : job->nodes4 ? traverse4(job->nodes4, job->node4_count, job->tris, org, dir, t_max, any_hit, &t, st, error)
                               : traverse(job->nodes, job->node_count, org, dir, t_max, any_hit, &t, st, error);
         st->hits += (uint64_t)hit;
         /* ProcessIntersectionsComputeShader.hlsl:52-85 */
@@ -950,12 +1064,23 @@ int orc_trace(const AobBvhNode* nodes, uint64_t node_count,
     job.opt = opt; job.hemisphere = hemisphere; job.width = width; job.height = height; job.results = results;
     job.begin = begin; job.end = end; job.next = begin;
     AobBvh4Node* nodes4 = NULL; AobLeafTri* tris = NULL;
-    if (opt->bvh_width != 2 && node_count) {
+    if (opt->bvh_width == 4 && node_count) {
         const uint64_t n = (node_count + 1) / 2;
         nodes4 = (AobBvh4Node*)malloc(sizeof(AobBvh4Node) * (n > 1 ? n - 1 : 1));
         tris = (AobLeafTri*)malloc(sizeof(AobLeafTri) * n);
         job.node4_count = orc_bvh4_build(nodes, node_count, nodes4, tris);
         job.nodes4 = nodes4; job.tris = tris;
+    }
+    AobBvh2QNode* nodes2q = NULL;
+    if (opt->bvh_width != 4 && opt->bvh_quantised && node_count) {
+        const uint64_t n = (node_count + 1) / 2;
+        AobBvh4Node* scratch4 = (AobBvh4Node*)malloc(sizeof(AobBvh4Node) * (n > 1 ? n - 1 : 1));
+        tris = (AobLeafTri*)malloc(sizeof(AobLeafTri) * n);
+        orc_bvh4_build(nodes, node_count, scratch4, tris);          /* for the Morton-ordered triangle array */
+        free(scratch4);
+        nodes2q = (AobBvh2QNode*)malloc(sizeof(AobBvh2QNode) * (n > 1 ? n - 1 : 1));
+        orc_bvh2q_build(nodes, node_count, nodes2q, &job.frame);
+        job.nodes2q = nodes2q; job.tris = tris; job.tri_count = n;
     }
     pthread_mutex_init(&job.lock, NULL);
     if (threads <= 1) trace_worker(&job);
@@ -966,7 +1091,7 @@ int orc_trace(const AobBvhNode* nodes, uint64_t node_count,
         for (int i = 0; i < threads; i++) pthread_join(th[i], NULL);
     }
     pthread_mutex_destroy(&job.lock);
-    free(nodes4); free(tris);
+    free(nodes4); free(tris); free(nodes2q);
     if (stats) {
         stats->rays += job.stats.rays; stats->inner_visits += job.stats.inner_visits;
         stats->leaf_visits += job.stats.leaf_visits; stats->hits += job.stats.hits;

@@ -77,6 +77,10 @@ uint64_t orc_bvh_build(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes, u
  * AobOptions::bvh_width == 2.  nodes4: max(1, n-1) entries, tris: n entries. */
 uint64_t orc_bvh4_build(const AobBvhNode* nodes2, uint64_t node_count2, AobBvh4Node* nodes4, AobLeafTri* tris);
 
+/* The same BVH2 with 16-bit quantised child boxes (AobBvh2QNode, 32 B) that the lane-per-ray GPU
+ * kernel walks when AobOptions::bvh_quantised is set (bvh_width 2).  out: max(1, n-1) entries. */
+uint64_t orc_bvh2q_build(const AobBvhNode* nodes2, uint64_t node_count2, AobBvh2QNode* out, AobQuantFrame* frame);
+
 /* UV rasterisation + texel extraction for one material
  * (Rasterize{Vertex,Pixel}Shader.hlsl, BakeEngine.cpp:130-145,531-588).
  * Writes up to `capacity` surfels (row-major per section, sections

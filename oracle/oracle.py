@@ -56,6 +56,7 @@ def load():
         "orc_scene_triangles": (None, [P(capi.AobSceneDesc), vp]),
         "orc_bvh_build": (u64, [vp, u64, vp, P(u32)]),
         "orc_bvh4_build": (u64, [vp, u64, vp, vp]),
+        "orc_bvh2q_build": (u64, [vp, u64, vp, vp]),
         "orc_rasterize": (u64, [P(capi.AobSceneDesc), i32, P(capi.AobOptions), vp, vp, u64]),
         "orc_trace": (C.c_int, [vp, u64, vp, vp, u64, u64, P(capi.AobOptions), vp, i32, i32, vp, i32,
                                 P(OrcTraceStats)]),
@@ -157,6 +158,17 @@ def bvh4_build(nodes2):
     return nodes4[:cnt], tris[:n]
 
 
+def bvh2q_build(nodes2):
+    """(words [n-1, 8] uint32, frame [6] float32)"""
+    lib = load()
+    nodes2 = np.ascontiguousarray(nodes2)
+    n = (len(nodes2) + 1) // 2
+    out = np.zeros((max(1, n - 1), 8), dtype=np.uint32)
+    frame = np.zeros(6, dtype=np.float32)
+    cnt = int(lib.orc_bvh2q_build(nodes2.ctypes.data if len(nodes2) else None, len(nodes2), out.ctypes.data, frame.ctypes.data))
+    return out[:cnt], frame
+
+
 def rasterize(desc, material, opt):
     lib = load()
     n = int(lib.orc_rasterize(C.byref(desc), material, C.byref(opt), None, None, 0))
@@ -218,5 +230,6 @@ def default_options():
     o.normal_fp16 = capi.FP16_RNE
     o.ray_chunk_size = 0xFFFFFF
     o.clamp_tmax_to_falloff = 0
-    o.bvh_width = 0
+    o.bvh_width = 2
+    o.bvh_quantised = 1
     return o

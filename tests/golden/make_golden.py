@@ -29,6 +29,7 @@ def options(mode):
     o = orc.default_options()
     o.sample_count = 16
     o.seed = 1
+    o.bvh_width, o.bvh_quantised = 2, 0      # the reference's own node layout (intersect_bvh2_lds.cl:40-52)
     if mode == "cosine":
         o.sampler, o.accumulate, o.normal_fp16 = capi.SAMPLER_COSINE, capi.ACCUMULATE_FLOAT, capi.FP16_OFF
     return o

@@ -35,12 +35,26 @@ def test_oracle_reproduces_golden(orc, mode, bpc, case):
     sc = make(bpc)
     flat = FlatScene(sc)
     o = options(orc.default_options(), mode)
+    o.bvh_width, o.bvh_quantised = 2, 0          # the vectors were made on the reference's node layout
     nodes, depth = orc.bvh_build(orc.scene_triangles(flat.desc))
     surfels, sidx = orc.rasterize(flat.desc, 0, o)
     assert digest(nodes) == str(GOLD[f"{mode}_nodes_sha256"])
     assert digest(surfels) == str(GOLD[f"{mode}_surfels_sha256"])
     st = orc.bake(flat.desc, o, threads=os.cpu_count() or 1)
     assert [len(nodes), depth, len(surfels), st.rays, st.hits] == GOLD[f"{mode}_counts"].tolist()
+    assert np.array_equal(sc.GetMaterial(0).GetAOTexture().GetData(), GOLD[f"{mode}_image"])
+
+
+@pytest.mark.parametrize("structure", [(2, 1), (4, 0)])
+@pytest.mark.parametrize("case", sorted(CASES))
+@pytest.mark.parametrize("mode,bpc", [("compat", 1), ("cosine", 4)])
+def test_other_traversal_structures_give_the_golden_image(orc, mode, bpc, case, structure):
+    """The quantised BVH2 (the GPU default) and the 4-ary collapse bake the same image."""
+    make, GOLD = CASES[case]
+    sc = make(bpc)
+    o = options(orc.default_options(), mode)
+    o.bvh_width, o.bvh_quantised = structure
+    orc.bake(FlatScene(sc).desc, o, threads=os.cpu_count() or 1)
     assert np.array_equal(sc.GetMaterial(0).GetAOTexture().GetData(), GOLD[f"{mode}_image"])
 
 

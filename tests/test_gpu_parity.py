@@ -66,6 +66,27 @@ def test_bvh4_nodes_bit_exact(engine, orc, name):
     assert bits(got4).tobytes() == bits(ref4).tobytes()
 
 
+@pytest.mark.parametrize("name", ["cube", "two_section", "sphere", "terrain", "floor_wall", "plane"])
+def test_quantised_bvh2_nodes_bit_exact(engine, orc, name):
+    """AobBvh2QNode[]: 16-bit child boxes on the scene grid, rounded outward, plus the frame."""
+    flat = FlatScene(SCENES[name]())
+    ref2, _ = orc.bvh_build(orc.scene_triangles(flat.desc))
+    refq, ref_frame = orc.bvh2q_build(ref2)
+    with Baker(flat, make_options(orc)) as b:
+        b.build_bvh()
+        gotq, frame = b.nodes2q()
+    assert bits(frame).tobytes() == bits(ref_frame).tobytes()
+    assert gotq.shape == refq.shape and np.array_equal(gotq, refq)
+    # decoded boxes contain the fp32 boxes
+    if len(refq):
+        q = np.stack([refq[:, 0] & 0xffff, refq[:, 0] >> 16, refq[:, 1] & 0xffff, refq[:, 1] >> 16, refq[:, 2] & 0xffff, refq[:, 2] >> 16], axis=1).astype(np.float64)
+        # decode = fmaf(q, scale, origin): exact in float64, then one rounding to float32
+        lo = (frame[:3].astype(np.float64) + q[:, :3] * frame[3:].astype(np.float64)).astype(np.float32)
+        hi = (frame[:3].astype(np.float64) + q[:, 3:] * frame[3:].astype(np.float64)).astype(np.float32)
+        inner = ref2[:len(refq)]
+        assert (lo <= inner["lmin_or_v0"]).all() and (hi >= inner["lmax_or_v1"]).all()
+
+
 @pytest.mark.parametrize("fp16", [capi.FP16_OFF, capi.FP16_RTZ, capi.FP16_RNE])
 @pytest.mark.parametrize("name", ["cube", "two_section", "sphere", "terrain"])
 def test_surfels_bit_exact(engine, orc, name, fp16):
@@ -90,14 +111,14 @@ MODES = [
 ]
 
 
-@pytest.mark.parametrize("width", [4, 2])
+@pytest.mark.parametrize("width", [4, 2, "2q"])
 @pytest.mark.parametrize("mode", range(len(MODES)))
 @pytest.mark.parametrize("name", ["cube", "two_section", "sphere", "terrain", "cube_inward"])
 def test_trace_results_match_oracle(engine, orc, name, mode, width):
     """width 4: quad-per-ray kernel on the 4-ary nodes (the default); width 2: lane-per-ray kernel
     on the reference's 64-byte BVH2 nodes.  Each against the oracle walking the same structure."""
     flat = FlatScene(SCENES[name]())
-    opt = make_options(orc, sample_count=24, bvh_width=width, **MODES[mode])
+    opt = make_options(orc, sample_count=24, bvh_width=2 if width == "2q" else width, bvh_quantised=int(width == "2q"), **MODES[mode])
     m = flat.material_array[0]
     nodes, _ = orc.bvh_build(orc.scene_triangles(flat.desc))
     surfels, sidx = orc.rasterize(flat.desc, 0, opt)
