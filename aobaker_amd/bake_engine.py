@@ -125,12 +125,14 @@ class Baker:
         capi.check(self.lib.aob_bake_image_device_ptr(self.handle, material, C.byref(p), C.byref(n)))
         return p.value, n.value
 
-    def surfel_cell_range(self, material, begin, end):
-        """(first_cell, last_cell, overlapping) of surfels [begin,end); first > last when empty."""
-        c0, c1, ov = C.c_uint64(), C.c_uint64(), C.c_int32()
-        capi.check(self.lib.aob_bake_surfel_cell_range(self.handle, material, begin, end, C.byref(c0),
-                                                       C.byref(c1), C.byref(ov)))
-        return c0.value, c1.value, bool(ov.value)
+    def shard_bounds(self, material, parts):
+        """(bounds[parts+1], [(first_cell, last_cell)] per part, overlapping): tile-row aligned balanced
+        split of the trace-order surfel list; first > last marks an empty part."""
+        bounds = (C.c_uint64 * (parts + 1))()
+        c0, c1 = (C.c_uint64 * parts)(), (C.c_uint64 * parts)()
+        ov = C.c_int32()
+        capi.check(self.lib.aob_bake_shard_bounds(self.handle, material, parts, bounds, c0, c1, C.byref(ov)))
+        return list(bounds), list(zip(c0, c1)), bool(ov.value)
 
     def stream(self):
         p = C.c_void_p()

@@ -147,7 +147,7 @@ EXPORTED_SYMBOLS = [
     "aob_bake_node_count", "aob_bake_copy_nodes", "aob_bake_surfel_count",
     "aob_bake_copy_surfels", "aob_bake_copy_results", "aob_bake_results_device_ptr",
     "aob_bake_image_device_ptr", "aob_bake_stream", "aob_bake_last_trace_ms",
-    "aob_bake_surfel_cell_range", "aob_bake_node4_count", "aob_bake_copy_nodes4", "aob_bake_copy_leaf_tris",
+    "aob_bake_shard_bounds", "aob_bake_node4_count", "aob_bake_copy_nodes4", "aob_bake_copy_leaf_tris",
     "aob_bake_copy_nodes2q", "aob_bake_quant_frame",
 ]
 
@@ -205,7 +205,7 @@ def load() -> C.CDLL:
         "aob_bake_image_device_ptr": (C.c_int, [vp, i32, P(vp), P(u64)]),
         "aob_bake_stream": (C.c_int, [vp, P(vp)]),
         "aob_bake_last_trace_ms": (C.c_int, [vp, P(C.c_float)]),
-        "aob_bake_surfel_cell_range": (C.c_int, [vp, i32, u64, u64, P(u64), P(u64), P(i32)]),
+        "aob_bake_shard_bounds": (C.c_int, [vp, i32, C.c_uint32, P(u64), P(u64), P(u64), P(i32)]),
         "aob_bake_node4_count": (C.c_int, [vp, P(u64)]),
         "aob_bake_copy_nodes4": (C.c_int, [vp, vp, u64]),
         "aob_bake_copy_leaf_tris": (C.c_int, [vp, vp, u64]),

@@ -49,7 +49,11 @@ struct DeviceMaterial {
     uint32_t  scan_blocks = 0;
     AobSurfel* surfels = nullptr;         // concatenated, row-major per section
     uint32_t* section_index = nullptr;    // surfel -> index inside its section's list
-    float4*   frames = nullptr;           // 64 B per surfel: P, N, tangent frame X/Z, texel, sample-table base, valid
+    float4*   frames = nullptr;           // 64 B per surfel IN TRACE (8x8 tile) ORDER: P, N, tangent X/Z, cell, table base, valid
+    uint32_t* perm = nullptr;             // trace order -> row-major rank (per section)
+    uint32_t* tile_sums = nullptr;        // scan partials of the tile-order pass
+    uint32_t* tile_row_prefix = nullptr;  // covered texels before each 8-texel tile row (first section)
+    uint32_t* tile_row_prefix_host = nullptr;   // pinned copy
     uint64_t  surfel_capacity = 0, surfel_count = 0;
     std::vector<uint64_t> section_offsets; // prefix offsets per contributing mesh (+ total)
     std::vector<uint32_t> section_mesh;

@@ -3,6 +3,7 @@
 // bvh_build.hip, raster.hip, trace.hip and resolve.hip.
 #include "aob_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -80,7 +81,8 @@ static void free_bake(AobBake* b)
     if (!b) return;
     for (auto& m : b->meshes) { hipFree(m.positions); hipFree(m.normals); hipFree(m.uvs); hipFree(m.indices); }
     for (auto& m : b->materials) {
-        hipFree(m.cover); hipFree(m.block_sums); hipFree(m.surfels); hipFree(m.section_index); hipFree(m.frames);
+        hipFree(m.cover); hipFree(m.block_sums); hipFree(m.surfels); hipFree(m.section_index); hipFree(m.frames); hipFree(m.perm); hipFree(m.tile_sums); hipFree(m.tile_row_prefix);
+        if (m.tile_row_prefix_host) hipHostFree(m.tile_row_prefix_host);
         hipFree(m.results); hipFree(m.image);
     }
     hipFree(b->tri_verts); hipFree(b->prim_bounds); hipFree(b->scene_bounds_enc);
@@ -284,6 +286,13 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
         AOB_C(dev_alloc(&d.surfels, cells));
         AOB_C(dev_alloc(&d.section_index, cells));
         AOB_C(dev_alloc(&d.frames, 4 * cells));
+        AOB_C(dev_alloc(&d.perm, cells));
+        {
+            const uint64_t tiles_x = (uint64_t)(d.width + 7) / 8, tiles_y = (uint64_t)(d.height + 7) / 8;
+            AOB_C(dev_alloc(&d.tile_sums, (tiles_x * tiles_y * 64 + 2047) / 2048 + 1));
+            AOB_C(dev_alloc(&d.tile_row_prefix, tiles_y + 1));
+            AOB_CH(hipHostMalloc((void**)&d.tile_row_prefix_host, sizeof(uint32_t) * (tiles_y + 1)));
+        }
         d.surfel_capacity = cells;
         AOB_CH(hipMemsetAsync(d.results, 0, sizeof(AobResult) * cells, b->stream));
         d.section_offsets.push_back(0);
@@ -517,21 +526,42 @@ int aob_bake_copy_results(AobBake* b, int32_t material, AobResult* dst, uint64_t
     return AOB_OK;
 }
 
-int aob_bake_surfel_cell_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end,
-                               uint64_t* first_cell, uint64_t* last_cell, int32_t* overlapping)
+int aob_bake_shard_bounds(AobBake* b, int32_t material, uint32_t parts, uint64_t* bounds,
+                          uint64_t* first_cell, uint64_t* last_cell, int32_t* overlapping)
 {
     AOB_TRY(check_bake(b, material, true));
     DeviceMaterial& m = b->materials[material];
-    if (end > m.surfel_count) end = m.surfel_count;
-    if (!first_cell || !last_cell) { set_error("first_cell/last_cell is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
-    if (overlapping) *overlapping = m.section_offsets.size() > 2 ? 1 : 0;
-    if (begin >= end) { *first_cell = 1; *last_cell = 0; return AOB_OK; }      // empty range
-    AobSurfel ends[2];
-    AOB_HIP(hipMemcpyAsync(&ends[0], m.surfels + begin, sizeof(AobSurfel), hipMemcpyDeviceToHost, b->stream));
-    AOB_HIP(hipMemcpyAsync(&ends[1], m.surfels + (end - 1), sizeof(AobSurfel), hipMemcpyDeviceToHost, b->stream));
+    if (!parts || !bounds) { set_error("parts is 0 or bounds is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
+    if (!m.rasterized) { set_error("material %d has not been rasterised", material); return AOB_ERR_INVALID_ARGUMENT; }
     AOB_HIP(hipStreamSynchronize(b->stream));
-    *first_cell = (uint64_t)ends[0].texel_y * m.width + ends[0].texel_x;
-    *last_cell = (uint64_t)ends[1].texel_y * m.width + ends[1].texel_x;
+    const uint64_t n = m.surfel_count, cells = (uint64_t)m.width * m.height;
+    const bool single = m.section_offsets.size() == 2;
+    if (overlapping) *overlapping = single ? 0 : 1;
+    const uint32_t tiles_y = (uint32_t)(m.height + 7) / 8;
+    std::vector<uint32_t> row_of(parts + 1, 0);
+    bounds[0] = 0; bounds[parts] = n; row_of[parts] = tiles_y;
+    for (uint32_t r = 1; r < parts; r++) {
+        const uint64_t want = n * r / parts;
+        if (!single) { bounds[r] = want; continue; }
+        // nearest tile-row boundary (prefix is non-decreasing), never before the previous bound
+        uint32_t lo = row_of[r - 1], best = lo;
+        for (uint32_t ty = lo; ty <= tiles_y; ty++) {
+            const uint64_t pv = m.tile_row_prefix_host[ty];
+            const uint64_t pb = m.tile_row_prefix_host[best];
+            if ((pv > want ? pv - want : want - pv) <= (pb > want ? pb - want : want - pb)) best = ty;
+            if (pv > want) break;
+        }
+        row_of[r] = best; bounds[r] = m.tile_row_prefix_host[best];
+    }
+    for (uint32_t r = 0; r < parts; r++) {
+        uint64_t c0 = 1, c1 = 0;                      // empty: first > last
+        if (bounds[r + 1] > bounds[r]) {
+            if (single) { c0 = (uint64_t)row_of[r] * 8u * m.width; c1 = std::min<uint64_t>((uint64_t)row_of[r + 1] * 8u, (uint64_t)m.height) * m.width - 1; }
+            else { c0 = 0; c1 = cells - 1; }
+        }
+        if (first_cell) first_cell[r] = c0;
+        if (last_cell) last_cell[r] = c1;
+    }
     return AOB_OK;
 }
 

@@ -150,7 +150,7 @@ __device__ __forceinline__ f3 xform(const MeshXform& x, const float* p, bool poi
 struct RasterVertex { f3 wpos, wnrm; float u, v; };
 
 __global__ __launch_bounds__(kBlock)
-void k_emit_surfels(const uint32_t* __restrict__ cover, uint64_t cells, const uint32_t* __restrict__ block_offsets,
+void k_emit_surfels(uint32_t* __restrict__ cover, uint64_t cells, const uint32_t* __restrict__ block_offsets,
                     const float* __restrict__ positions, const float* __restrict__ normals,
                     const float* __restrict__ uvs, const uint32_t* __restrict__ indices,
                     MeshXform xf, int32_t W, int32_t H, int fp16_mode,
@@ -206,8 +206,77 @@ void k_emit_surfels(const uint32_t* __restrict__ cover, uint64_t cells, const ui
 #undef AOB_LERP
         surfels[local] = s;
         section_index[local] = local;
+        cover[cell] = local + 1;            // from here on: row-major rank + 1 (read by the tile-order pass)
         local++;
     }
+}
+
+// ---- trace order: 8x8 texel tiles -------------------------------------------------------------
+// The extraction order above is the reference's (row-major; its chunk-local sample indexing
+// depends on it).  The trace kernel instead wants the 64 surfels of a wavefront to be spatial
+// neighbours — an 8x8 texel tile rather than a 64x1 strip (+11 % rays/s, better L1 reuse) — so a
+// second scan enumerates the atlas tile by tile (tiles row-major, texels row-major inside a tile)
+// and emits perm[j] = row-major rank of the j-th covered texel in that order.
+__device__ __forceinline__ bool tile_cell(uint64_t e, int32_t W, int32_t H, uint32_t tiles_x, uint64_t& cell)
+{
+    const uint64_t tile = e >> 6; const uint32_t in = (uint32_t)e & 63u;
+    const uint32_t ty = (uint32_t)(tile / tiles_x), tx = (uint32_t)(tile - (uint64_t)ty * tiles_x);
+    const uint32_t y = ty * 8u + (in >> 3), x = tx * 8u + (in & 7u);
+    cell = (uint64_t)y * (uint32_t)W + x;
+    return x < (uint32_t)W && y < (uint32_t)H;
+}
+
+__global__ __launch_bounds__(kBlock)
+void k_tile_count(const uint32_t* __restrict__ rank, int32_t W, int32_t H, uint32_t tiles_x, uint64_t total_e,
+                  uint32_t* __restrict__ block_sums)
+{
+    uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; k++) {
+        uint64_t cell;
+        if (base + k < total_e && tile_cell(base + k, W, H, tiles_x, cell)) c += rank[cell] != 0u;
+    }
+    uint32_t total;
+    block_exclusive_scan(c, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kBlock)
+void k_tile_emit(const uint32_t* __restrict__ rank, int32_t W, int32_t H, uint32_t tiles_x, uint64_t total_e,
+                 const uint32_t* __restrict__ block_offsets, uint32_t* __restrict__ perm)
+{
+    uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+    uint32_t rv[kScanItems];
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; k++) {
+        uint64_t cell;
+        rv[k] = (base + k < total_e && tile_cell(base + k, W, H, tiles_x, cell)) ? rank[cell] : 0u;
+        c += rv[k] != 0u;
+    }
+    uint32_t total;
+    uint32_t j = block_exclusive_scan(c, &total) + block_offsets[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < kScanItems; k++) if (rv[k]) perm[j++] = rv[k] - 1u;
+}
+
+// number of covered texels before each tile row (for tile-row aligned multi-GPU shards)
+__global__ __launch_bounds__(kBlock)
+void k_tile_row_prefix(const uint32_t* __restrict__ rank, int32_t W, int32_t H, uint32_t tiles_x, uint32_t tiles_y,
+                       const uint32_t* __restrict__ block_offsets, uint32_t total, uint32_t* __restrict__ row_prefix)
+{
+    uint32_t ty = blockIdx.x * kBlock + threadIdx.x;
+    if (ty > tiles_y) return;
+    if (ty == tiles_y) { row_prefix[ty] = total; return; }
+    const uint64_t e0 = (uint64_t)ty * tiles_x * 64u;
+    const uint64_t blk = e0 / kScanTile;
+    uint32_t c = block_offsets[blk];
+    for (uint64_t e = blk * kScanTile; e < e0; e++) {
+        uint64_t cell;
+        if (tile_cell(e, W, H, tiles_x, cell)) c += rank[cell] != 0u;
+    }
+    row_prefix[ty] = c;
 }
 
 // Per-surfel trace record: everything the trace kernel needs when a lane picks up a block of
@@ -217,11 +286,13 @@ void k_emit_surfels(const uint32_t* __restrict__ cover, uint64_t cells, const ui
 // A surfel with a non-finite frame or an out-of-range texel is flagged invalid: all its weights
 // would be NaN, and (int)NaN == 0 in HLSL, so it contributes nothing.
 __global__ __launch_bounds__(kBlock)
-void k_surfel_frames(const AobSurfel* __restrict__ surfels, const uint32_t* __restrict__ section_index, uint64_t count,
+void k_surfel_frames(const AobSurfel* __restrict__ surfels, const uint32_t* __restrict__ section_index,
+                     const uint32_t* __restrict__ perm, uint64_t count,
                      int32_t W, int32_t H, uint32_t chunk_max, uint32_t spp, float4* __restrict__ frames)
 {
-    uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (k >= count) return;
+    uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;      // position in trace (tile) order
+    if (j >= count) return;
+    const uint64_t k = perm[j];                                    // row-major rank of that surfel
     AobSurfel sf = surfels[k];
     const f3 P = make_f3(sf.position[0], sf.position[1], sf.position[2]);
     const f3 N = make_f3(sf.normal[0], sf.normal[1], sf.normal[2]);
@@ -234,7 +305,7 @@ void k_surfel_frames(const AobSurfel* __restrict__ surfels, const uint32_t* __re
                  finite3(P) && finite3(N) && finite3(X) && finite3(Z);
     uint32_t texel = (uint32_t)sf.texel_y * (uint32_t)W + (uint32_t)sf.texel_x;
     uint32_t table_base = (section_index[k] % chunk_max) * spp;
-    float4* out = frames + 4ull * k;
+    float4* out = frames + 4ull * j;
     out[0] = make_float4(P.x, P.y, P.z, N.x);
     out[1] = make_float4(N.y, N.z, X.x, X.y);
     out[2] = make_float4(X.z, Z.x, Z.y, Z.z);
@@ -246,10 +317,11 @@ static int ensure_surfel_capacity(AobBake* b, DeviceMaterial& m, uint64_t need)
     if (need <= m.surfel_capacity) return AOB_OK;
     uint64_t cap = m.surfel_capacity ? m.surfel_capacity : (uint64_t)m.width * m.height;
     while (cap < need) cap *= 2;
-    AobSurfel* ns = nullptr; uint32_t* ni = nullptr; float4* nf = nullptr;
+    AobSurfel* ns = nullptr; uint32_t* ni = nullptr; float4* nf = nullptr; uint32_t* np = nullptr;
     AOB_HIP(hipMalloc((void**)&ns, sizeof(AobSurfel) * cap));
     AOB_HIP(hipMalloc((void**)&ni, sizeof(uint32_t) * cap));
     AOB_HIP(hipMalloc((void**)&nf, sizeof(float4) * 4 * cap));
+    AOB_HIP(hipMalloc((void**)&np, sizeof(uint32_t) * cap));
     if (m.surfel_count) {
         AOB_HIP(hipMemcpyAsync(ns, m.surfels, sizeof(AobSurfel) * m.surfel_count, hipMemcpyDeviceToDevice, b->stream));
         AOB_HIP(hipMemcpyAsync(ni, m.section_index, sizeof(uint32_t) * m.surfel_count, hipMemcpyDeviceToDevice, b->stream));
@@ -259,7 +331,8 @@ static int ensure_surfel_capacity(AobBake* b, DeviceMaterial& m, uint64_t need)
     if (m.surfels) AOB_HIP(hipFree(m.surfels));
     if (m.section_index) AOB_HIP(hipFree(m.section_index));
     if (m.frames) AOB_HIP(hipFree(m.frames));
-    m.surfels = ns; m.section_index = ni; m.frames = nf; m.surfel_capacity = cap;
+    if (m.perm) AOB_HIP(hipFree(m.perm));
+    m.surfels = ns; m.section_index = ni; m.frames = nf; m.perm = np; m.surfel_capacity = cap;
     return AOB_OK;
 }
 
@@ -295,8 +368,21 @@ int rasterize_material(AobBake* b, int32_t material)
             hipLaunchKernelGGL(k_emit_surfels, dim3(nblocks), dim3(kBlock), 0, s, m.cover, cells, m.block_sums,
                                mesh.positions, mesh.normals, mesh.uvs, mesh.indices, xf, m.width, m.height,
                                b->opt.normal_fp16, m.surfels + m.surfel_count, m.section_index + m.surfel_count);
+            // trace order: 8x8 tiles (perm), then the per-surfel trace records in that order
+            const uint32_t tiles_x = (uint32_t)(m.width + 7) / 8, tiles_y = (uint32_t)(m.height + 7) / 8;
+            const uint64_t total_e = (uint64_t)tiles_x * tiles_y * 64u;
+            const uint32_t tblocks = (uint32_t)((total_e + kScanTile - 1) / kScanTile);
+            hipLaunchKernelGGL(k_tile_count, dim3(tblocks), dim3(kBlock), 0, s, m.cover, m.width, m.height, tiles_x, total_e, m.tile_sums);
+            hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(kBlock), 0, s, m.tile_sums, tblocks);
+            hipLaunchKernelGGL(k_tile_emit, dim3(tblocks), dim3(kBlock), 0, s, m.cover, m.width, m.height, tiles_x, total_e, m.tile_sums,
+                               m.perm + m.surfel_count);
+            if (m.section_offsets.size() == 1) {
+                hipLaunchKernelGGL(k_tile_row_prefix, dim3((tiles_y + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, m.cover, m.width, m.height,
+                                   tiles_x, tiles_y, m.tile_sums, (uint32_t)count, m.tile_row_prefix);
+                AOB_HIP(hipMemcpyAsync(m.tile_row_prefix_host, m.tile_row_prefix, sizeof(uint32_t) * (tiles_y + 1), hipMemcpyDeviceToHost, s));
+            }
             hipLaunchKernelGGL(k_surfel_frames, dim3((uint32_t)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-                               m.surfels + m.surfel_count, m.section_index + m.surfel_count, count, m.width, m.height,
+                               m.surfels + m.surfel_count, m.section_index + m.surfel_count, m.perm + m.surfel_count, count, m.width, m.height,
                                (uint32_t)chunk_texel_max(b->opt), (uint32_t)b->opt.sample_count,
                                m.frames + 4ull * m.surfel_count);
         }

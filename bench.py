@@ -89,11 +89,12 @@ def main():
         baker.build_bvh()
         baker.rasterize(0)
         n = baker.surfel_count(0)
-        begin, end = aod.shard_range(n, rank, world)
+        bounds, strips, overlapping = baker.shard_bounds(0, world)       # tile-row aligned; syncs the stream
+        begin, end = bounds[rank], bounds[rank + 1]
         baker.trace(0, begin, end)
         if world > 1:
-            c0, c1, overlapping = baker.surfel_cell_range(0, begin, end)   # syncs the stream
-            aod.gather_strips(cells, (c0, c1), rank, world, 0, overlapping)
+            baker.sync()
+            aod.gather_strips(cells, strips[rank], rank, world, 0, overlapping)
             torch.cuda.synchronize()
         if rank == 0:
             baker.resolve(0)

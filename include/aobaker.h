@@ -207,7 +207,8 @@ int aob_bake_build_bvh(AobBake* bake);
 /* S2 + S2': UV rasterisation, last-fragment-wins, row-major compaction into
  * the surfel list of `material` (BakeEngine.cpp:531-588). */
 int aob_bake_rasterize(AobBake* bake, int32_t material);
-/* S3..S5 for surfels [begin,end) of the material's concatenated surfel list:
+/* S3..S5 for surfels [begin,end) of the material's surfel list IN TRACE ORDER (sections
+ * concatenated in scene order; inside a section 8x8 texel tiles, see aob_bake_shard_bounds):
  * ray generation, traversal, scoring, accumulation into the material's
  * W*H result buffer (BakeEngine.cpp:598-675).  end = UINT64_MAX means all. */
 int aob_bake_trace(AobBake* bake, int32_t material, uint64_t begin, uint64_t end);
@@ -239,12 +240,14 @@ int aob_bake_quant_frame(AobBake* bake, AobQuantFrame* frame);
 int aob_bake_surfel_count(AobBake* bake, int32_t material, uint64_t* count);
 int aob_bake_copy_surfels(AobBake* bake, int32_t material, AobSurfel* dst, uint64_t capacity);
 int aob_bake_copy_results(AobBake* bake, int32_t material, AobResult* dst, uint64_t capacity);
-/* First and last result cell (y*W+x) touched by surfels [begin,end): with a single section the
- * surfel list is row-major, so disjoint surfel ranges own disjoint, ordered cell ranges — the
- * "texel tiles" a multi-GPU bake gathers.  *overlapping is set when the material has several
- * sections (their cell ranges may interleave; the caller must then reduce instead of gather). */
-int aob_bake_surfel_cell_range(AobBake* bake, int32_t material, uint64_t begin, uint64_t end,
-                               uint64_t* first_cell, uint64_t* last_cell, int32_t* overlapping);
+/* Balanced split of the material's trace-order surfel list into `parts` contiguous ranges
+ * [bounds[r], bounds[r+1]) for a multi-GPU bake (bounds has parts+1 entries).  The trace order is
+ * 8x8 texel tiles, tile rows top to bottom, so with a single section the boundaries are placed on
+ * tile rows and part r owns the disjoint strip of result cells [first_cell[r], last_cell[r]] — the
+ * "texel tiles" rank 0 gathers (first > last: empty part).  With several sections the strips of
+ * different parts may overlap: *overlapping is set and the caller must sum-reduce instead. */
+int aob_bake_shard_bounds(AobBake* bake, int32_t material, uint32_t parts, uint64_t* bounds,
+                          uint64_t* first_cell, uint64_t* last_cell, int32_t* overlapping);
 /* Device address of the material's W*H AobResult buffer (for an RCCL
  * collective issued by the caller) and of its resolved image. */
 int aob_bake_results_device_ptr(AobBake* bake, int32_t material, void** ptr, uint64_t* bytes);

@@ -242,3 +242,39 @@ def test_invalid_arguments_are_reported(engine, orc):
             b.trace(0)                      # BVH not built yet
         with pytest.raises(capi.AobError):
             b.rasterize(3)                  # no such material
+
+
+@pytest.mark.parametrize("name,parts", [("terrain", 3), ("cube", 2), ("sphere", 5), ("two_section", 2)])
+def test_sharded_trace_equals_full_trace(engine, orc, name, parts):
+    """aob_bake_shard_bounds + aob_bake_trace(begin, end): the multi-GPU decomposition on one GPU.
+    Parts are traced one after the other into the same result buffer; single-section materials get
+    tile-row aligned parts that own disjoint strips of cells."""
+    flat = FlatScene(SCENES[name]())
+    opt = make_options(orc, sample_count=16, sampler=capi.SAMPLER_COSINE, accumulate=capi.ACCUMULATE_FLOAT, seed=11)
+    m = flat.material_array[0]
+    with Baker(flat, opt) as b:
+        b.build_bvh(); b.rasterize(0)
+        b.trace(0)
+        full = b.results(0)
+        n = b.surfel_count(0)
+        bounds, strips, overlapping = b.shard_bounds(0, parts)
+        assert bounds[0] == 0 and bounds[-1] == n and all(bounds[i] <= bounds[i + 1] for i in range(parts))
+        assert overlapping == (name == "two_section")
+        b.clear_results(0)
+        owned = np.zeros(m.width * m.height, dtype=np.int32)
+        for r in range(parts):
+            b.clear_results(0)
+            b.trace(0, bounds[r], bounds[r + 1])
+            part = b.results(0)
+            touched = (part["weight_bits"] != 0)
+            if not overlapping and bounds[r + 1] > bounds[r]:
+                c0, c1 = strips[r]
+                assert c0 % (8 * m.width) == 0                       # starts on a tile row
+                assert not touched[:c0].any() and not touched[c1 + 1:].any()
+                assert np.array_equal(part[c0:c1 + 1], full[c0:c1 + 1])
+            owned += touched
+        if not overlapping:
+            assert owned.max() == 1 and np.array_equal(owned > 0, full["weight_bits"] != 0)
+        sizes = [bounds[i + 1] - bounds[i] for i in range(parts)]
+        if name in ("terrain", "sphere"):
+            assert max(sizes) - min(sizes) <= 8 * m.width        # balanced to within one tile row
