@@ -8,7 +8,9 @@ library's own `aob_last_error()` text when a call fails.
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 ABI_VERSION = 1
 
@@ -175,6 +177,18 @@ def load() -> C.CDLL:
         raise ImportError(
             f"{path} is missing: the HIP extension is the product and there is no fallback. "
             "Build it with `python __graft_entry__.py` (or `make -C aobaker_amd/csrc`).")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 with the same
+    # soname as /opt/rocm's.  Whichever is loaded first serves both, and torch cannot see the GPU
+    # through the system copy, so when torch is installed (multi-GPU driver, bench) its copy is
+    # pre-loaded here.  Without torch the library simply uses the system runtime.
+    if "torch" not in sys.modules:
+        try:
+            spec = importlib.util.find_spec("torch")
+            cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so") if spec and spec.origin else None
+            if cand and os.path.exists(cand):
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except (ImportError, OSError, ValueError):
+            pass
     lib = C.CDLL(path)
     vp, i32, u64 = C.c_void_p, C.c_int32, C.c_uint64
     P = C.POINTER

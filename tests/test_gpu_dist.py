@@ -1,0 +1,50 @@
+"""GPU side of the multi-GPU path that one box can check: the raw result buffer aliased as a torch
+tensor (zero-copy), and an RCCL collective running on that foreign allocation."""
+import os
+
+import numpy as np
+import pytest
+
+from aobaker_amd import Baker, capi, scenes
+from aobaker_amd.scene import FlatScene
+
+pytestmark = pytest.mark.gpu
+
+
+def test_results_alias_and_rccl_on_library_memory(engine):
+    import torch
+    import torch.distributed as dist
+    from aobaker_amd import dist as aod
+
+    flat = FlatScene(scenes.terrain_scene(grid=64, atlas=128, bpc=4))
+    opt = capi.default_options()
+    opt.sample_count = 8
+    opt.sampler, opt.accumulate, opt.seed = capi.SAMPLER_COSINE, capi.ACCUMULATE_FLOAT, 2
+    with Baker(flat, opt) as b:
+        b.build_bvh(); b.rasterize(0); b.trace(0); b.sync()
+        host = b.results(0)
+        cells = aod.alias_results(b, 0, as_float=True)
+        assert cells.shape == (128 * 128, 2) and cells.is_cuda
+        assert np.array_equal(cells.cpu().numpy().view(np.uint32), host.view(np.uint32).reshape(-1, 2))
+        # writes through the alias land in the library's buffer
+        before = cells[5].clone()
+        cells[5] = torch.tensor([3.0, 4.0], device="cuda")
+        torch.cuda.synchronize()
+        assert b.results(0).view(np.float32).reshape(-1, 2)[5].tolist() == [3.0, 4.0]
+        cells[5] = before
+        torch.cuda.synchronize()
+        # an RCCL collective on it (world of one: the transport is exercised, the data unchanged)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29631")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        try:
+            dist.all_reduce(cells)
+            aod.gather_strips(cells, (0, 10), 0, 1)
+            torch.cuda.synchronize()
+        finally:
+            dist.destroy_process_group()
+        assert np.array_equal(b.results(0).view(np.uint32), host.view(np.uint32))
+        b.resolve(0)
+        img = np.zeros(128 * 128 * 4, dtype=np.uint8)
+        b.download(0, img)
+        assert 0.3 < img.view(np.float32).mean() < 1.0
