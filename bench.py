@@ -11,7 +11,7 @@ N x 2048^2 texels (N=4 is configs[3]'s 4096^2) and each rank traces an equal str
 
 The JSON line also carries
   roofline     the trace kernel against HBM peak, ALGORITHMIC bytes:
-               B_ray = 64*(n_inner+n_leaf) + 40/spp, node visits counted by the CPU oracle on
+               B_ray = node_packet*n_inner + 48*n_leaf + 1032/spp, node visits counted by the CPU oracle on
                a texel subsample of the same rays; kernel time from HIP events on the library's
                own stream.  frac can exceed 1: every node visit is counted as memory traffic
                although most are served by L1/L2/Infinity Cache — `traffic` is what reaches HBM.
@@ -133,17 +133,25 @@ def main():
     cpu = None
     roofline = None
     if rank == 0:
-        n_visits = None
+        visits = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu, n_visits = cpu_baseline(flat, opts, W, H, args.cpu_seconds)
-        if n_visits is None:
-            n_visits = visits_per_ray(flat, opts, W, H)
-        b_ray = 64.0 * n_visits + 40.0 / args.spp
+            cpu, visits = cpu_baseline(flat, opts, W, H, args.cpu_seconds)
+        if visits is None:
+            visits = visits_per_ray(flat, opts, W, H)
+        n_inner, n_leaf = visits
+        n_visits = n_inner + n_leaf
+        # bytes one ray asks of the memory system (with this build's packet sizes):
+        # inner-node packet (64 B fp32 BVH2 / 32 B quantised BVH2 / 128 B 4-ary), 48 B per leaf
+        # triangle, plus per surfel 16 sample blocks x 64 B trace record and the 8 B result cell
+        inner_bytes = 128.0 if opts.bvh_width == 4 else (32.0 if opts.bvh_quantised else 64.0)
+        b_ray = inner_bytes * n_inner + 48.0 * n_leaf + (16 * 64.0 + 8.0) / args.spp
         achieved = my_rays * b_ray / (kernel_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(),
                     "kernel": "k_trace", "kernel_ms": round(kernel_ms, 3),
                     "bytes_per_ray": round(b_ray, 1), "node_visits_per_ray": round(n_visits, 3),
+                    "inner_visits_per_ray": round(n_inner, 3), "leaf_visits_per_ray": round(n_leaf, 3),
+                    "inner_packet_bytes": inner_bytes,
                     "rays_per_launch": my_rays}
         line = {
             "metric": "AO rays/sec", "value": value, "unit": "rays/s", "n_gpus": world,
@@ -151,7 +159,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"terrain {flat.triangle_count()} tris, {W}x{H} atlas, {args.spp} spp, "
-                                   f"cosine sampler, any-hit, float accumulate (BASELINE configs[2]"
+                                   f"cosine sampler, any-hit, float accumulate, bvh_width {opts.bvh_width or 2}"
+                                   f"{' quantised' if opts.bvh_quantised else ''} (BASELINE configs[2]"
                                    f"{' scaled: N x 2048^2 texels' if world > 1 else ''})",
                        "triangles": flat.triangle_count(), "atlas": [W, H], "spp": args.spp,
                        "surfels": counts["surfels"], "rays": total_rays, "sharding": f"texel strips x{world}",
@@ -187,26 +196,26 @@ def visits_per_ray(flat, opts, W, H):
     orc, nodes, surfels = _oracle_inputs(flat, opts)
     sub = _subsample(surfels, 32)
     _, st = orc.trace(nodes, sub, None, opts, W, H, threads=os.cpu_count() or 1)
-    return (st.inner_visits + st.leaf_visits) / max(1, st.rays)
+    return st.inner_visits / max(1, st.rays), st.leaf_visits / max(1, st.rays)
 
 
 def cpu_baseline(flat, opts, W, H, seconds):
     """The CPU oracle on the same BVH, sampler and rays, on a bounded texel subsample."""
     cores = os.cpu_count() or 1
     orc, nodes, surfels = _oracle_inputs(flat, opts)
-    probe = _subsample(surfels, 64)
+    probe = _subsample(surfels, 32)
     t = time.perf_counter()
     _, st = orc.trace(nodes, probe, None, opts, W, H, threads=cores)
     rate = st.rays / max(1e-9, time.perf_counter() - t)
-    want = rate * seconds
-    stride = 64
-    while stride > 1 and len(surfels) / (stride // 2) ** 2 * opts.sample_count <= want:
+    # the largest power-of-two texel stride whose sample stays within the time budget (at least ~10 s of work)
+    stride = 32
+    while stride > 1 and len(surfels) / (stride // 2) ** 2 * opts.sample_count / rate <= 2.0 * seconds:
         stride //= 2
     sub = _subsample(surfels, stride)
     t = time.perf_counter()
     _, st = orc.trace(nodes, sub, None, opts, W, H, threads=cores)
     dt = time.perf_counter() - t
-    visits = (st.inner_visits + st.leaf_visits) / max(1, st.rays)
+    visits = (st.inner_visits / max(1, st.rays), st.leaf_visits / max(1, st.rays))
     return ({"value": st.rays / dt, "unit": "rays/s", "cores": cores, "kind": "port",
              "sample": f"every {stride}th texel in x and y of the same atlas ({len(sub)} surfels, {st.rays} rays, "
                        f"{dt:.1f} s); trace stage only, same BVH/sampler/rays as the GPU",
