@@ -176,7 +176,7 @@ def sphere_mesh(n=187, seed=2, displacement=0.08):
     # normals from the displaced surface (finite differences in parameter space)
     dpu = np.gradient(p, axis=1)
     dpv = np.gradient(p, axis=0)
-    nrm = np.cross(dpv, dpu)
+    nrm = np.cross(dpu, dpv)                     # outward: d(theta) x d(phi) points along -d
     ln = np.linalg.norm(nrm, axis=-1, keepdims=True)
     nrm = np.where(ln > 1e-12, nrm / np.maximum(ln, 1e-12), d)
     uv = np.stack([uu, vv], axis=-1)
