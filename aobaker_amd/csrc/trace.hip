@@ -18,7 +18,7 @@
 // exact Q32.32 sums in float mode), which makes the result independent of which lane
 // traced which block, and bit-identical to the oracle's sequential loop.
 //
-// Wave scheduling (the kernel is VALU-issue bound, not HBM bound — see profiles/): one
+// Wave scheduling (the kernel is VALU-issue bound, not HBM bound — profiles/r01): one
 // loop whose three sections are entered on wave-wide votes:
 //   refill   idle lanes pick their next ray (and, at block ends, their next item) once
 //            `refill_idle` of them are waiting;

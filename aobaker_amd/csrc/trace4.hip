@@ -1,11 +1,14 @@
-// trace4.hip — quad-per-ray traversal of the 4-ary BVH (gfx950), the default trace kernel.
+// trace4.hip — quad-per-ray traversal of the 4-ary BVH (gfx950); selected with bvh_width = 4.
+// An experiment kept in the tree: parity-green, but slower than trace.hip (2.35 vs 6.4 Grays/s on
+// BASELINE configs[2]) because 16 rays per wave cost 2.3x the VALU instructions per ray, and VALU
+// issue — not L1 — is what bounds the lane-per-ray kernel once its nodes are quantised.
 //
 // Same fused stage as trace.hip (ray generation + traversal + scoring + accumulation, replacing
 // BakeEngine.cpp:598-675 / GenerateRaysComputeShader.hlsl / QueryIntersection /
-// ProcessIntersectionsComputeShader.hlsl), re-shaped around what profiling showed to be the
-// limiter of the lane-per-ray kernel: the vector memory pipe.  rocprofv3 (profiles/r01): TD busy
-// 89 %, TCP active 91 %, VALU 32 % — every lane's 16-byte load is its own L1 access, so a 64-byte
-// BVH2 node costs a ray four L1 accesses that each return a quarter line.
+// ProcessIntersectionsComputeShader.hlsl), re-shaped around the L1 access count: in the
+// lane-per-ray kernel every lane's 16-byte load is its own L1 access (0.93 accesses/clk/CU with
+// fp32 nodes, profiles/r01), so a 64-byte BVH2 node costs a ray four accesses that each return a
+// quarter line.
 //
 // Here FOUR lanes (a DPP quad) trace one ray through the 4-ary node array built by k_collapse4:
 //   * lane j of the quad fetches child j's {min, ref} and {max} — the quad's four 16-byte
