@@ -199,3 +199,38 @@ def two_section_scene(atlas=32, **kw):
     obj.AddSection(Section("A", RenderMesh(make_vertices(*a[:3]), a[3]), mat))
     obj.AddSection(Section("B", RenderMesh(make_vertices(*b[:3]), b[3]), mat))
     return sc
+
+
+def instanced_scene(instances=100, rock_n=224, atlas=8192, seed=5, **kw):
+    """BASELINE cfg5: `instances` copies of one displaced-sphere "rock" (2*rock_n^2 triangles; 224 -> 100 352)
+    scattered over a ground plane with seeded yaw/pitch/roll, non-uniform scale and translation —
+    every copy its own BakeObject with its own transform (TransformObject.cpp:16-24), all sections
+    sharing one material whose atlas is a grid of per-instance charts.  The reference has no
+    instancing either (it never calls CreateInstance): each copy is a full shape."""
+    rng = np.random.default_rng(seed)
+    p, n, uv, idx = sphere_mesh(rock_n, seed)
+    cols = int(np.ceil(np.sqrt(instances + 1)))
+    rows = int(np.ceil((instances + 1) / cols))
+    sc = Scene()
+    if isinstance(atlas, int):
+        atlas = (atlas, atlas)
+    mat = sc.AddMaterial(MaterialObject("AO", atlas[0], atlas[1], kw.get("channels", 1), kw.get("bpc", 1)))
+
+    def chart(k, uv_in):
+        cx, cy = k % cols, k // cols
+        pad = 0.02
+        out = np.empty_like(uv_in)
+        out[:, 0] = (cx + pad + uv_in[:, 0] * (1 - 2 * pad)) / cols
+        out[:, 1] = (cy + pad + uv_in[:, 1] * (1 - 2 * pad)) / rows
+        return out.astype(np.float32)
+
+    ground = quad((-6, 0, -6), (6, 0, -6), (6, 0, 6), (-6, 0, 6), (0, 1, 0))
+    g = sc.AddObject(BakeObject("Ground"))
+    g.AddSection(Section("Geometry", RenderMesh(make_vertices(ground[0], ground[1], chart(0, ground[2])), ground[3]), mat))
+    for i in range(instances):
+        o = sc.AddObject(BakeObject(f"Rock{i}",
+                                    position=(rng.uniform(-5, 5), rng.uniform(0.1, 0.6), rng.uniform(-5, 5)),
+                                    rotation=tuple(rng.uniform(-np.pi, np.pi, 3)),
+                                    scale=tuple(rng.uniform(0.5, 1.5, 3))))
+        o.AddSection(Section("Geometry", RenderMesh(make_vertices(p, n, chart(i + 1, uv)), idx), mat))
+    return sc

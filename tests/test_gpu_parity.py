@@ -278,3 +278,32 @@ def test_sharded_trace_equals_full_trace(engine, orc, name, parts):
         sizes = [bounds[i + 1] - bounds[i] for i in range(parts)]
         if name in ("terrain", "sphere"):
             assert max(sizes) - min(sizes) <= 8 * m.width        # balanced to within one tile row
+
+
+@pytest.mark.parametrize("mode", [3, 0])
+def test_instanced_scene_with_transforms(engine, orc, mode):
+    """BASELINE cfg5 in miniature: many objects with their own yaw/pitch/roll + non-uniform scale +
+    translation (world = [p 1] * model, normals through the model matrix itself —
+    RasterizeVertexShader.hlsl:30-32), one shared material, falloff scoring with the ray clamped to
+    the falloff distance (mode 3) or the reference's defaults (mode 0)."""
+    mk = lambda bpc: scenes.instanced_scene(instances=12, rock_n=20, atlas=256, seed=5, bpc=bpc)
+    opt = make_options(orc, sample_count=16, **MODES[mode])
+    bpc = 1 if opt.accumulate == capi.ACCUMULATE_QUANTISED else 4
+    gpu, cpu = mk(bpc), mk(bpc)
+    flat = FlatScene(gpu)
+    assert flat.desc.mesh_count == 13
+    ref_nodes, _ = orc.bvh_build(orc.scene_triangles(flat.desc))
+    with Baker(flat, opt) as b:
+        b.build_bvh()
+        assert bits(b.nodes()).tobytes() == bits(ref_nodes).tobytes()      # 13 shapes, 13 transforms
+        b.rasterize(0)
+        ref_surfels, _ = orc.rasterize(flat.desc, 0, opt)
+        got = b.surfels(0)
+        assert len(got) == len(ref_surfels) and bits(got).tobytes() == bits(ref_surfels).tobytes()
+    engine.Options = opt
+    engine.Bake(gpu)
+    orc.bake(FlatScene(cpu).desc, opt, threads=8)
+    g, c = gpu.GetMaterial(0).GetAOTexture(), cpu.GetMaterial(0).GetAOTexture()
+    assert np.array_equal(g.GetData(), c.GetData())
+    ao = g.ao()
+    assert ao.max() > 0.9 and 0.02 < (ao < 0.9).mean() < 0.97         # rocks darken the ground and each other; gutters are black
