@@ -109,14 +109,20 @@ void k_trace(TraceParams p)
 
     acc[tid][0] = 0ull; acc[tid][1] = 0ull;
     lds_stack[tid] = kInvalid;       // entry 0: the INVALID sentinel (intersect_bvh2_lds.cl:103): a pop is one read
-    uint32_t* gs = p.gstack + ((uint64_t)blockIdx.x * kBlock + tid);       // overflow entry e at gs[e * gstride]
-    const uint64_t gstride = (uint64_t)gridDim.x * kBlock;
+    // overflow stack entry e of this lane lives at gstack[e * (gridDim.x*256) + blockIdx.x*256 + tid] (computed on use:
+    // the path is cold and the registers are better spent on occupancy)
+    auto gs_slot = [&](int e) -> uint32_t* { return p.gstack + ((uint64_t)e * gridDim.x + blockIdx.x) * kBlock + tid; };
 
     // current block of samples: [cur, blk_end) of surfel slot `slot`
     int32_t cur = 0, blk_end = 0;
     uint32_t slot = 0;
     bool has_partial = false;
-    long long pT = 0, pW = 0, cW = 0;        // block sums; this ray's weight contribution                // partial sums of the current block
+    // block sums.  COSINE sampler: every weight is exactly 1, so the sums are counters (UNITW);
+    // REFERENCE_COMPAT: 64-bit sums of the per-ray weight cW converted at ray generation.
+    constexpr bool UNITW = SAMPLER == AOB_SAMPLER_COSINE;
+    constexpr long long kUnit = ACCUM == AOB_ACCUMULATE_QUANTISED ? 255ll : (1ll << 32);   // ftoi(1*255) / f2fix(1)
+    long long pT = 0, pW = 0, cW = 0;
+    int32_t nW = 0, nMiss = 0;
     f3 P, N, X, Z;
     P = N = X = Z = make_f3(0.f, 0.f, 0.f);
     uint32_t hash_base = 0;
@@ -132,28 +138,33 @@ void k_trace(TraceParams p)
 
     auto push = [&](uint32_t v) {
         if (sp < LDS_N) lds_stack[sp * kBlock + tid] = v;
-        else gs[(uint64_t)(sp - LDS_N) * gstride] = v;
+        else *gs_slot(sp - LDS_N) = v;
         sp++;
     };
     auto pop = [&]() -> uint32_t {
         sp--;
         uint32_t v;
         if (sp < LDS_N) { v = lds_stack[sp * kBlock + tid]; asm volatile("" : "+v"(v)); }
-        else { v = gs[(uint64_t)(sp - LDS_N) * gstride]; asm volatile("" : "+v"(v)); }
+        else { v = *gs_slot(sp - LDS_N); asm volatile("" : "+v"(v)); }
         return v;
     };
     // ProcessIntersectionsComputeShader.hlsl:69-90
     auto finish = [&]() {
         if (ANYHIT) {
-            // r is 0 or 1: the sample adds cW to the weight and, if unoccluded, cW to the total
-            // ((1.0f * w) * 255.0f == w * 255.0f exactly).  cW was converted when the ray was made,
-            // with the whole refill group active; this path runs with one or two lanes.
-            pW += cW;
-            if (!hit) pT += cW;
+            // r is 0 or 1: the sample adds its weight to the weight sum and, if unoccluded, to the total
+            // ((1.0f * w) * 255.0f == w * 255.0f exactly).  cW was converted when the ray was made, with the
+            // whole refill group active; this path runs with one or two lanes.
+            if (UNITW) { nW++; if (!hit) nMiss++; }
+            else { pW += cW; if (!hit) pT += cW; }
         } else {
             const float r = (hit && closest_t < p.falloff) ? closest_t / p.falloff : 1.0f;
-            if (ACCUM == AOB_ACCUMULATE_QUANTISED) { pT += ftoi(r * w * 255.0f); pW += cW; }
-            else { pT += f2fix(r * w); pW += cW; }
+            if (UNITW) {
+                nW++;
+                pT += ACCUM == AOB_ACCUMULATE_QUANTISED ? (long long)ftoi(r * 1.0f * 255.0f) : f2fix(r * 1.0f);
+            } else {
+                if (ACCUM == AOB_ACCUMULATE_QUANTISED) { pT += ftoi(r * w * 255.0f); pW += cW; }
+                else { pT += f2fix(r * w); pW += cW; }
+            }
         }
         active = false;
     };
@@ -170,8 +181,8 @@ void k_trace(TraceParams p)
             const bool need_item = !active && cur >= blk_end;
             if (need_item && has_partial) {
                 // block finished: fold its sums into the surfel's accumulators
-                atomicAdd(&acc[wave * 64u + slot][0], (unsigned long long)pT);
-                atomicAdd(&acc[wave * 64u + slot][1], (unsigned long long)pW);
+                atomicAdd(&acc[wave * 64u + slot][0], (unsigned long long)(UNITW && ANYHIT ? nMiss * kUnit : pT));
+                atomicAdd(&acc[wave * 64u + slot][1], (unsigned long long)(UNITW ? nW * kUnit : pW));
                 has_partial = false;
             }
             const uint64_t want_m = __ballot(need_item && !pool_empty);
@@ -190,7 +201,7 @@ void k_trace(TraceParams p)
                             slot = s;
                             cur = (int32_t)blk * p.block_samples;
                             blk_end = min(p.spp, cur + p.block_samples);
-                            pT = 0; pW = 0;
+                            pT = 0; pW = 0; nW = 0; nMiss = 0;
                             has_partial = cur < blk_end;
                             hash_base = pcg_hash(__float_as_uint(d.x) + p.seed_hash);
                             if (SAMPLER == AOB_SAMPLER_REFERENCE_COMPAT)
@@ -209,7 +220,7 @@ void k_trace(TraceParams p)
                               fmaf(h.z, Z.z, fmaf(h.y, N.z, h.x * X.z)));                       // GenerateRays:46
                 org = make_f3(fmaf(dir.x, p.bias, P.x), fmaf(dir.y, p.bias, P.y), fmaf(dir.z, p.bias, P.z)); // :47
                 w = SAMPLER == AOB_SAMPLER_REFERENCE_COMPAT ? dot(N, dir) : 1.0f;
-                cW = ACCUM == AOB_ACCUMULATE_QUANTISED ? (long long)ftoi(w * 255.0f) : f2fix(w);
+                if (!UNITW) cW = ACCUM == AOB_ACCUMULATE_QUANTISED ? (long long)ftoi(w * 255.0f) : f2fix(w);
                 invdir = make_f3(safe_inv1(dir.x), safe_inv1(dir.y), safe_inv1(dir.z));
                 oxinvdir = make_f3(-org.x * invdir.x, -org.y * invdir.y, -org.z * invdir.z);
                 if (QUANT) {
@@ -274,8 +285,8 @@ void k_trace(TraceParams p)
 
     // blocks still held by lanes when the pool ran dry
     if (has_partial) {
-        atomicAdd(&acc[wave * 64u + slot][0], (unsigned long long)pT);
-        atomicAdd(&acc[wave * 64u + slot][1], (unsigned long long)pW);
+        atomicAdd(&acc[wave * 64u + slot][0], (unsigned long long)(UNITW && ANYHIT ? nMiss * kUnit : pT));
+        atomicAdd(&acc[wave * 64u + slot][1], (unsigned long long)(UNITW ? nW * kUnit : pW));
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS atomics have landed
 
