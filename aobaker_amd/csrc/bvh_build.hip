@@ -344,8 +344,10 @@ void k_emit_nodes_q(uint32_t n, const uint32_t* __restrict__ child_left, const u
         q[k] = quant_down(bl.pmin[k], o, sc); q[3 + k] = quant_up(bl.pmax[k], o, sc);
         q[6 + k] = quant_down(br.pmin[k], o, sc); q[9 + k] = quant_up(br.pmax[k], o, sc);
     }
-    nodesq[2ull * i + 0] = make_uint4(q[0] | q[1] << 16, q[2] | q[3] << 16, q[4] | q[5] << 16, q[6] | q[7] << 16);
-    nodesq[2ull * i + 1] = make_uint4(q[8] | q[9] << 16, q[10] | q[11] << 16, l, r);
+    // one word per axis and box: min | max << 16 (the trace kernel rotates the word by 16 for rays that
+    // travel down that axis, so that the low half is always the near plane)
+    nodesq[2ull * i + 0] = make_uint4(q[0] | q[3] << 16, q[1] | q[4] << 16, q[2] | q[5] << 16, q[6] | q[9] << 16);
+    nodesq[2ull * i + 1] = make_uint4(q[7] | q[10] << 16, q[8] | q[11] << 16, l, r);
 }
 
 // n == 1: the tree is a single leaf; give it a 4-ary root with that one child

@@ -132,6 +132,7 @@ void k_trace(TraceParams p)
     f3 org, dir, invdir, oxinvdir;
     org = dir = invdir = oxinvdir = make_f3(0.f, 0.f, 0.f);
     float w = 0.0f, closest_t = 0.0f;
+    uint3 rot = make_uint3(0u, 0u, 0u);        // QUANT: 16 for axes the ray travels down, else 0
     bool hit = false;
     uint32_t addr = kInvalid;
     int sp = 1;
@@ -224,6 +225,7 @@ void k_trace(TraceParams p)
                 invdir = make_f3(safe_inv1(dir.x), safe_inv1(dir.y), safe_inv1(dir.z));
                 oxinvdir = make_f3(-org.x * invdir.x, -org.y * invdir.y, -org.z * invdir.z);
                 if (QUANT) {
+                    rot = make_uint3((__float_as_uint(invdir.x) >> 31) << 4, (__float_as_uint(invdir.y) >> 31) << 4, (__float_as_uint(invdir.z) >> 31) << 4);
                     // fold the de-quantisation into the ray: (origin + q*scale - o) * invdir = q*(scale*invdir) + (origin*invdir + oxinvdir)
                     oxinvdir = make_f3(fmaf(q_origin.x, invdir.x, oxinvdir.x), fmaf(q_origin.y, invdir.y, oxinvdir.y), fmaf(q_origin.z, invdir.z, oxinvdir.z));
                     invdir = make_f3(q_scale.x * invdir.x, q_scale.y * invdir.y, q_scale.z * invdir.z);
@@ -259,11 +261,21 @@ void k_trace(TraceParams p)
             if (QUANT) {
                 const uint4* np = p.nodesq + 2ull * addr;
                 const uint4 a = np[0], b = np[1];
-                // invdir/oxinvdir hold the folded frame here, so the slab test runs on the raw 16-bit grid values
-                intersect_bbox(make_f3((float)(a.x & 0xffffu), (float)(a.x >> 16), (float)(a.y & 0xffffu)),
-                               make_f3((float)(a.y >> 16), (float)(a.z & 0xffffu), (float)(a.z >> 16)), invdir, oxinvdir, closest_t, s0x, s0y);
-                intersect_bbox(make_f3((float)(a.w & 0xffffu), (float)(a.w >> 16), (float)(b.x & 0xffffu)),
-                               make_f3((float)(b.x >> 16), (float)(b.y & 0xffffu), (float)(b.y >> 16)), invdir, oxinvdir, closest_t, s1x, s1y);
+                // one word per axis: min | max << 16.  Rotating it by 16 for rays that travel down the axis puts the
+                // NEAR plane in the low half, so min(t(min), t(max)) == t(low half) and max(..) == t(high half) —
+                // exactly (t is monotonic in q) — without the six min/max per box.  invdir/oxinvdir hold the folded
+                // frame here, so the slab test runs on the raw 16-bit grid values (intersect_bvh2_lds.cl:54-63).
+                const uint32_t lx = __builtin_amdgcn_alignbit(a.x, a.x, rot.x), ly = __builtin_amdgcn_alignbit(a.y, a.y, rot.y),
+                               lz = __builtin_amdgcn_alignbit(a.z, a.z, rot.z), rx = __builtin_amdgcn_alignbit(a.w, a.w, rot.x),
+                               ry = __builtin_amdgcn_alignbit(b.x, b.x, rot.y), rz = __builtin_amdgcn_alignbit(b.y, b.y, rot.z);
+                s0x = fmaxf(fmaxf(fmaxf(fmaf((float)(lx & 0xffffu), invdir.x, oxinvdir.x), fmaf((float)(ly & 0xffffu), invdir.y, oxinvdir.y)),
+                                  fmaf((float)(lz & 0xffffu), invdir.z, oxinvdir.z)), 0.0f);
+                s0y = fminf(fminf(fminf(fmaf((float)(lx >> 16), invdir.x, oxinvdir.x), fmaf((float)(ly >> 16), invdir.y, oxinvdir.y)),
+                                  fmaf((float)(lz >> 16), invdir.z, oxinvdir.z)), closest_t);
+                s1x = fmaxf(fmaxf(fmaxf(fmaf((float)(rx & 0xffffu), invdir.x, oxinvdir.x), fmaf((float)(ry & 0xffffu), invdir.y, oxinvdir.y)),
+                                  fmaf((float)(rz & 0xffffu), invdir.z, oxinvdir.z)), 0.0f);
+                s1y = fminf(fminf(fminf(fmaf((float)(rx >> 16), invdir.x, oxinvdir.x), fmaf((float)(ry >> 16), invdir.y, oxinvdir.y)),
+                                  fmaf((float)(rz >> 16), invdir.z, oxinvdir.z)), closest_t);
                 al = b.z; ar = b.w;
             } else {
                 const float4* np = p.nodes + 4ull * addr;

@@ -162,9 +162,8 @@ typedef struct AobBvh4Node { float lo[4][4]; float hi[4][4]; } AobBvh4Node;
 #define AOB_LEAF_FLAG 0x80000000u
 /* 32 B BVH2 node with quantised child boxes: q = 16-bit fixed point on the scene box,
  * box.min rounded down, box.max rounded up; decode: frame.origin + q * frame.scale.
- * w0 = lmin.x | lmin.y<<16, w1 = lmin.z | lmax.x<<16, w2 = lmax.y | lmax.z<<16,
- * w3 = rmin.x | rmin.y<<16, w4 = rmin.z | rmax.x<<16, w5 = rmax.y | rmax.z<<16,
- * w6 = addr_left, w7 = addr_right.  Inner nodes only ([0, n-1)); a child address >= n-1 is leaf
+ * One word per axis and box, min in the low half: w0 = lmin.x | lmax.x<<16, w1 = lmin.y | lmax.y<<16,
+ * w2 = lmin.z | lmax.z<<16, w3..w5 the same for the right child, w6 = addr_left, w7 = addr_right.  Inner nodes only ([0, n-1)); a child address >= n-1 is leaf
  * triangle (address - (n-1)) of AobLeafTri[].  Two 16-byte fetches per visit instead of four. */
 typedef struct AobBvh2QNode { uint32_t w[8]; } AobBvh2QNode;
 typedef struct AobQuantFrame { float origin[3]; float scale[3]; } AobQuantFrame;

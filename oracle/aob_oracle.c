@@ -750,8 +750,9 @@ uint64_t orc_bvh2q_build(const AobBvhNode* nodes2, uint64_t node_count2, AobBvh2
             q[6 + k] = quant_down(nd->rmin_or_v2[k], o, sc); q[9 + k] = quant_up(nd->rmax[k], o, sc);
         }
         uint32_t* w = out[i].w;
-        w[0] = q[0] | q[1] << 16; w[1] = q[2] | q[3] << 16; w[2] = q[4] | q[5] << 16; w[3] = q[6] | q[7] << 16;
-        w[4] = q[8] | q[9] << 16; w[5] = q[10] | q[11] << 16; w[6] = nd->addr_left; w[7] = nd->addr_right;
+        /* one word per axis and box: min | max << 16 */
+        w[0] = q[0] | q[3] << 16; w[1] = q[1] | q[4] << 16; w[2] = q[2] | q[5] << 16; w[3] = q[6] | q[9] << 16;
+        w[4] = q[7] | q[10] << 16; w[5] = q[8] | q[11] << 16; w[6] = nd->addr_left; w[7] = nd->addr_right;
     }
     return n - 1;
 }
@@ -778,10 +779,10 @@ static inline int traverse2q(const AobBvh2QNode* nq, uint64_t n, const AobQuantF
         if (addr < leaf_base) {
             const uint32_t* w = nq[addr].w;
             st->inner_visits++;
-            const float lmin[3] = { (float)(w[0] & 0xffffu), (float)(w[0] >> 16), (float)(w[1] & 0xffffu) };
-            const float lmax[3] = { (float)(w[1] >> 16), (float)(w[2] & 0xffffu), (float)(w[2] >> 16) };
-            const float rmin[3] = { (float)(w[3] & 0xffffu), (float)(w[3] >> 16), (float)(w[4] & 0xffffu) };
-            const float rmax[3] = { (float)(w[4] >> 16), (float)(w[5] & 0xffffu), (float)(w[5] >> 16) };
+            const float lmin[3] = { (float)(w[0] & 0xffffu), (float)(w[1] & 0xffffu), (float)(w[2] & 0xffffu) };
+            const float lmax[3] = { (float)(w[0] >> 16), (float)(w[1] >> 16), (float)(w[2] >> 16) };
+            const float rmin[3] = { (float)(w[3] & 0xffffu), (float)(w[4] & 0xffffu), (float)(w[5] & 0xffffu) };
+            const float rmax[3] = { (float)(w[3] >> 16), (float)(w[4] >> 16), (float)(w[5] >> 16) };
             float s0x, s0y, s1x, s1y;
             intersect_bbox(lmin, lmax, fa, fb, closest_t, &s0x, &s0y);
             intersect_bbox(rmin, rmax, fa, fb, closest_t, &s1x, &s1y);

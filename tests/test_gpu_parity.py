@@ -79,7 +79,7 @@ def test_quantised_bvh2_nodes_bit_exact(engine, orc, name):
     assert gotq.shape == refq.shape and np.array_equal(gotq, refq)
     # decoded boxes contain the fp32 boxes
     if len(refq):
-        q = np.stack([refq[:, 0] & 0xffff, refq[:, 0] >> 16, refq[:, 1] & 0xffff, refq[:, 1] >> 16, refq[:, 2] & 0xffff, refq[:, 2] >> 16], axis=1).astype(np.float64)
+        q = np.stack([refq[:, 0] & 0xffff, refq[:, 1] & 0xffff, refq[:, 2] & 0xffff, refq[:, 0] >> 16, refq[:, 1] >> 16, refq[:, 2] >> 16], axis=1).astype(np.float64)
         # decode = fmaf(q, scale, origin): exact in float64, then one rounding to float32
         lo = (frame[:3].astype(np.float64) + q[:, :3] * frame[3:].astype(np.float64)).astype(np.float32)
         hi = (frame[:3].astype(np.float64) + q[:, 3:] * frame[3:].astype(np.float64)).astype(np.float32)
