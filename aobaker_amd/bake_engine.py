@@ -97,6 +97,13 @@ class Baker:
         capi.check(self.lib.aob_bake_quant_frame(self.handle, frame.ctypes.data))
         return out[:n], frame
 
+    def nodes4q(self) -> np.ndarray:
+        n = C.c_uint64()
+        capi.check(self.lib.aob_bake_node4_count(self.handle, C.byref(n)))
+        out = np.zeros((max(n.value, 1), 16), dtype=np.uint32)
+        capi.check(self.lib.aob_bake_copy_nodes4q(self.handle, out.ctypes.data, n.value))
+        return out[:n.value]
+
     def surfel_count(self, material=0) -> int:
         n = C.c_uint64()
         capi.check(self.lib.aob_bake_surfel_count(self.handle, material, C.byref(n)))

@@ -88,7 +88,7 @@ static void free_bake(AobBake* b)
     hipFree(b->tri_verts); hipFree(b->prim_bounds); hipFree(b->scene_bounds_enc);
     hipFree(b->codes[0]); hipFree(b->codes[1]); hipFree(b->prim_idx[0]); hipFree(b->prim_idx[1]);
     hipFree(b->sort_temp); hipFree(b->child_left); hipFree(b->child_right); hipFree(b->parent);
-    hipFree(b->node_bounds); hipFree(b->refit_flags); hipFree(b->depth_dev); hipFree(b->nodes); hipFree(b->nodes4); hipFree(b->leaf_tris); hipFree(b->nodes2q); hipFree(b->quant_frame);
+    hipFree(b->node_bounds); hipFree(b->refit_flags); hipFree(b->depth_dev); hipFree(b->nodes); hipFree(b->nodes4); hipFree(b->leaf_tris); hipFree(b->nodes2q); hipFree(b->nodes4q); hipFree(b->quant_frame);
     hipFree(b->hemisphere); hipFree(b->gstack);
     if (b->pinned) hipHostFree(b->pinned);
     for (auto& e : b->ev) if (e) hipEventDestroy(e);
@@ -143,8 +143,8 @@ void aob_default_options(AobOptions* o)
     o->normal_fp16 = AOB_FP16_RNE;
     o->ray_chunk_size = 0xFFFFFF;
     o->clamp_tmax_to_falloff = 0;
-    // measured fastest on MI355X (profiles/): lane-per-ray walk of the 32-byte quantised BVH2 nodes
-    o->bvh_width = 2;
+    // measured fastest on MI355X (profiles/): lane-per-ray walk of the 64-byte quantised 4-ary nodes
+    o->bvh_width = 4;
     o->bvh_quantised = 1;
 }
 
@@ -262,6 +262,7 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
     AOB_C(dev_alloc(&b->nodes4, 8 * n));
     AOB_C(dev_alloc(&b->leaf_tris, 3 * n));
     AOB_C(dev_alloc(&b->nodes2q, 2 * n));
+    AOB_C(dev_alloc(&b->nodes4q, 4 * n));
     AOB_C(dev_alloc(&b->quant_frame, 8));
     if (n) {
         size_t temp = 0;
@@ -484,6 +485,15 @@ int aob_bake_copy_nodes2q(AobBake* b, AobBvh2QNode* dst, uint64_t capacity)
     const uint64_t n = b->bvh_built && b->triangle_count ? b->triangle_count - 1 : 0;
     if (capacity < n || (!dst && n)) { set_error("quantised node buffer too small"); return AOB_ERR_INVALID_ARGUMENT; }
     if (n) AOB_HIP(hipMemcpyAsync(dst, b->nodes2q, sizeof(AobBvh2QNode) * n, hipMemcpyDeviceToHost, b->stream));
+    AOB_HIP(hipStreamSynchronize(b->stream));
+    return AOB_OK;
+}
+
+int aob_bake_copy_nodes4q(AobBake* b, AobBvh4QNode* dst, uint64_t capacity)
+{
+    AOB_TRY(check_bake(b, 0, false));
+    if (capacity < b->node4_count || (!dst && b->node4_count)) { set_error("node4q buffer too small"); return AOB_ERR_INVALID_ARGUMENT; }
+    if (b->node4_count) AOB_HIP(hipMemcpyAsync(dst, b->nodes4q, sizeof(AobBvh4QNode) * b->node4_count, hipMemcpyDeviceToHost, b->stream));
     AOB_HIP(hipStreamSynchronize(b->stream));
     return AOB_OK;
 }

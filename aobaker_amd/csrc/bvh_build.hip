@@ -350,6 +350,27 @@ void k_emit_nodes_q(uint32_t n, const uint32_t* __restrict__ child_left, const u
     nodesq[2ull * i + 1] = make_uint4(q[7] | q[10] << 16, q[8] | q[11] << 16, l, r);
 }
 
+// quantised form of the 4-ary nodes: child j = {x, y, z words (min | max << 16), ref}
+__global__ __launch_bounds__(kBlock)
+void k_emit_nodes4q(uint32_t count4, const float4* __restrict__ nodes4, const float* __restrict__ frame, uint4* __restrict__ nodes4q)
+{
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= count4) return;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const float4 lo = nodes4[8ull * i + j], hi = nodes4[8ull * i + 4 + j];
+        const uint32_t ref = __float_as_uint(lo.w);
+        uint4 o = make_uint4(0u, 0u, 0u, ref);
+        // collapsed-away levels keep all-zero records (ref 0 with a zero box is never reached)
+        if (ref != 0xffffffffu && !(ref == 0u && lo.x == 0.0f && hi.x == 0.0f && lo.y == 0.0f && hi.y == 0.0f && lo.z == 0.0f && hi.z == 0.0f)) {
+            o.x = quant_down(lo.x, frame[0], frame[3]) | quant_up(hi.x, frame[0], frame[3]) << 16;
+            o.y = quant_down(lo.y, frame[1], frame[4]) | quant_up(hi.y, frame[1], frame[4]) << 16;
+            o.z = quant_down(lo.z, frame[2], frame[5]) | quant_up(hi.z, frame[2], frame[5]) << 16;
+        }
+        nodes4q[4ull * i + j] = o;
+    }
+}
+
 // n == 1: the tree is a single leaf; give it a 4-ary root with that one child
 __global__ void k_single_leaf4(const Box* __restrict__ prim_bounds, float4* __restrict__ nodes4)
 {
@@ -427,6 +448,8 @@ int build_bvh(AobBake* b)
     hipLaunchKernelGGL(k_quant_frame, dim3(1), dim3(64), 0, s, b->scene_bounds_enc, b->quant_frame);
     if (n > 1) hipLaunchKernelGGL(k_emit_nodes_q, dim3(blocks_for(n - 1)), dim3(kBlock), 0, s, (uint32_t)n, b->child_left,
                                   b->child_right, b->node_bounds, b->quant_frame, b->nodes2q);
+    hipLaunchKernelGGL(k_emit_nodes4q, dim3(blocks_for(b->node4_count)), dim3(kBlock), 0, s, (uint32_t)b->node4_count, b->nodes4,
+                       b->quant_frame, b->nodes4q);
     hipLaunchKernelGGL(k_leaf_tris, dim3(blocks_for(n)), dim3(kBlock), 0, s, (uint32_t)n, b->prim_idx[1], b->tri_verts,
                        b->leaf_tris);
     AOB_HIP(hipGetLastError());

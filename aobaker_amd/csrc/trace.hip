@@ -46,7 +46,8 @@ static constexpr uint32_t kInvalid = 0xffffffffu;
 
 struct TraceParams {
     const float4* nodes;
-    const uint4* nodesq;           // QUANT: 2 x uint4 per node (AobBvh2QNode)
+    const uint4* nodesq;           // QUANT 1: 2 x uint4 per node (AobBvh2QNode)
+    const uint4* nodes4q;          // QUANT 2: 4 x uint4 per node (AobBvh4QNode)
     const float4* leaf_tris;       // QUANT: 3 x float4 per triangle
     const float* quant_frame;      // QUANT: origin[3], scale[3]
     const float4* frames;          // 4 x float4 per surfel (k_surfel_frames)
@@ -76,8 +77,9 @@ __device__ __forceinline__ long long f2fix(float v)
 }
 
 // LDS_N: stack entries per lane kept in LDS; deeper entries spill to p.gstack.
-// QUANT: walk the 32-byte nodes with 16-bit quantised child boxes (two 16-byte fetches per visit
-// instead of four — the kernel is bound by L1 accesses, profiles/r01) and the 48-byte leaf triangles.
+// QUANT 1: walk the 32-byte BVH2 nodes with 16-bit quantised child boxes (two 16-byte fetches per visit
+// instead of four) and the 48-byte leaf triangles.  QUANT 2: the same boxes in 4-ary nodes (AobBvh4QNode,
+// every second level collapsed): 68 instead of 76 slab tests per ray and half the loop iterations.
 #ifndef AOB_TRACE_WAVES
 #define AOB_TRACE_WAVES 8          // waves per SIMD the register allocator must leave room for (<= 64 VGPRs):
                                    // measured 4.98 / 5.14 / 5.55 Grays/s at 6 / 7 / 8 — latency hiding beats the few spills
@@ -256,9 +258,52 @@ void k_trace(TraceParams p)
 
         // ---- inner section: intersect_bvh2_lds.cl:108-160 ----
         if (inner) {
+          if (QUANT == 2) {
+            // ---- 4-ary node: four slab tests per visit, children ranked only when the order matters ----
+            const uint4* np = p.nodes4q + 4ull * addr;
+            const uint4 c0 = np[0], c1 = np[1], c2 = np[2], c3 = np[3];
+            auto slab = [&](const uint4& c, float& tn) -> bool {
+                const uint32_t wx = __builtin_amdgcn_alignbit(c.x, c.x, rot.x), wy = __builtin_amdgcn_alignbit(c.y, c.y, rot.y),
+                               wz = __builtin_amdgcn_alignbit(c.z, c.z, rot.z);
+                tn = fmaxf(fmaxf(fmaxf(fmaf((float)(wx & 0xffffu), invdir.x, oxinvdir.x), fmaf((float)(wy & 0xffffu), invdir.y, oxinvdir.y)),
+                                 fmaf((float)(wz & 0xffffu), invdir.z, oxinvdir.z)), 0.0f);
+                const float tf = fminf(fminf(fminf(fmaf((float)(wx >> 16), invdir.x, oxinvdir.x), fmaf((float)(wy >> 16), invdir.y, oxinvdir.y)),
+                                             fmaf((float)(wz >> 16), invdir.z, oxinvdir.z)), closest_t);
+                return tn <= tf && c.w != kInvalid;            // an empty slot is excluded by its ref
+            };
+            float k0, k1, k2, k3;
+            const bool h0 = slab(c0, k0), h1 = slab(c1, k1), h2 = slab(c2, k2), h3 = slab(c3, k3);
+            if (!(h0 || h1 || h2 || h3)) {
+                addr = pop();
+                if (addr == kInvalid) finish();
+            } else if (ANYHIT) {
+                // any-hit: the answer does not depend on the visiting order — follow the first hit child, defer the rest
+                if (h3 && (h0 || h1 || h2)) push(c3.w);
+                if (h2 && (h0 || h1)) push(c2.w);
+                if (h1 && h0) push(c1.w);
+                addr = h0 ? c0.w : (h1 ? c1.w : (h2 ? c2.w : c3.w));
+            } else {
+                // closest hit: nearest child first, the others deferred farthest first, ties by child index
+                // (the 4-ary form of intersect_bvh2_lds.cl:123-153; the oracle's traverse4q order)
+                const float e0 = h0 ? k0 : INFINITY, e1 = h1 ? k1 : INFINITY, e2 = h2 ? k2 : INFINITY, e3 = h3 ? k3 : INFINITY;
+                const int b01 = e0 <= e1, b02 = e0 <= e2, b03 = e0 <= e3, b12 = e1 <= e2, b13 = e1 <= e3, b23 = e2 <= e3;
+                const int r0 = (1 - b01) + (1 - b02) + (1 - b03), r1 = b01 + (1 - b12) + (1 - b13);
+                const int r2 = b02 + b12 + (1 - b23), r3 = b03 + b13 + b23;
+                const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+                auto place = [&](bool h, int r, uint32_t ref) {
+                    if (h && r > 0) {
+                        const int e = sp + (nh - 1) - r;
+                        if (e < LDS_N) lds_stack[e * kBlock + tid] = ref; else *gs_slot(e - LDS_N) = ref;
+                    }
+                };
+                place(h0, r0, c0.w); place(h1, r1, c1.w); place(h2, r2, c2.w); place(h3, r3, c3.w);
+                sp += nh - 1;
+                addr = (h0 && r0 == 0) ? c0.w : ((h1 && r1 == 0) ? c1.w : ((h2 && r2 == 0) ? c2.w : c3.w));
+            }
+          } else {
             float s0x, s0y, s1x, s1y;
             uint32_t al, ar;
-            if (QUANT) {
+            if (QUANT == 1) {
                 const uint4* np = p.nodesq + 2ull * addr;
                 const uint4 a = np[0], b = np[1];
                 // one word per axis: min | max << 16.  Rotating it by 16 for rays that travel down the axis puts the
@@ -292,6 +337,7 @@ void k_trace(TraceParams p)
                 addr = pop();
                 if (addr == kInvalid) finish();
             }
+          }
         }
     }
 
@@ -324,19 +370,20 @@ void k_trace(TraceParams p)
 }
 
 template <int SAMPLER, int ANYHIT, int ACCUM>
-static void launch_stack(bool quant, dim3 grid, hipStream_t s, const TraceParams& p)
+static void launch_stack(int quant, dim3 grid, hipStream_t s, const TraceParams& p)
 {
-    if (quant) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, kLdsStack, 1>), grid, dim3(kBlock), 0, s, p);
+    if (quant == 2) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, kLdsStack, 2>), grid, dim3(kBlock), 0, s, p);
+    else if (quant == 1) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, kLdsStack, 1>), grid, dim3(kBlock), 0, s, p);
     else hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, kLdsStack, 0>), grid, dim3(kBlock), 0, s, p);
 }
 template <int SAMPLER, int ANYHIT>
-static void launch_acc(int accum, bool quant, dim3 grid, hipStream_t s, const TraceParams& p)
+static void launch_acc(int accum, int quant, dim3 grid, hipStream_t s, const TraceParams& p)
 {
     if (accum == AOB_ACCUMULATE_QUANTISED) launch_stack<SAMPLER, ANYHIT, AOB_ACCUMULATE_QUANTISED>(quant, grid, s, p);
     else launch_stack<SAMPLER, ANYHIT, AOB_ACCUMULATE_FLOAT>(quant, grid, s, p);
 }
 template <int SAMPLER>
-static void launch_hit(int anyhit, int accum, bool quant, dim3 grid, hipStream_t s, const TraceParams& p)
+static void launch_hit(int anyhit, int accum, int quant, dim3 grid, hipStream_t s, const TraceParams& p)
 {
     if (anyhit) launch_acc<SAMPLER, 1>(accum, quant, grid, s, p);
     else launch_acc<SAMPLER, 0>(accum, quant, grid, s, p);
@@ -365,23 +412,25 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
     if (end > m.surfel_count) end = m.surfel_count;
     hipStream_t s = b->stream;
     AOB_HIP(hipEventRecord(b->ev_trace[0], s));
-    if (begin < end && o.bvh_width == 4) {
+    if (begin < end && o.bvh_width == 4 && !o.bvh_quantised) {
         AOB_TRY(trace4_range(b, material, begin, end));        // quad-per-ray, 4-ary nodes (trace4.hip)
     } else if (begin < end) {
         // a lane's stack holds the sentinel plus at most one deferred sibling per tree level
-        const uint32_t need = b->bvh_depth + 2;
+        // (the 4-ary walk defers up to three children per 4-ary level)
+        const uint32_t need = (o.bvh_quantised && o.bvh_width == 4) ? 3u * ((b->bvh_depth + 2) / 2) + 2u : b->bvh_depth + 2;
         // 16 stack entries per lane live in LDS (16 KB + 4 KB of sums per block = 8 blocks per CU);
         // deeper entries — rare — go to an HBM array.  24 and 32 entries measured 11 % and 23 % slower.
         const int lds_eff = kLdsStack;
         const uint32_t overflow = need > (uint32_t)lds_eff ? need - (uint32_t)lds_eff : 0u;
         TraceParams p;
         p.nodes = (const float4*)b->nodes;
-        p.nodesq = b->nodes2q; p.leaf_tris = b->leaf_tris; p.quant_frame = b->quant_frame;
-        const bool quant = o.bvh_quantised != 0;
+        p.nodesq = b->nodes2q; p.nodes4q = b->nodes4q; p.leaf_tris = b->leaf_tris; p.quant_frame = b->quant_frame;
+        const int quant = o.bvh_quantised ? (o.bvh_width == 4 ? 2 : 1) : 0;
         p.frames = m.frames; p.results = m.results;
         p.hemisphere = b->hemisphere;
         p.node_count = (uint32_t)b->node_count;
         p.leaf_base = b->triangle_count ? (uint32_t)(b->triangle_count - 1) : 0u;
+        if (quant == 2) p.leaf_base = 0x80000000u;          // 4-ary refs: leaf = 0x80000000 | triangle, inner = node index
         p.spp = o.sample_count;
         p.block_samples = (o.sample_count + kBlocksPerSurfel - 1) / kBlocksPerSurfel;
         p.seed_hash = host_pcg(o.seed);

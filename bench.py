@@ -141,9 +141,10 @@ def main():
         n_inner, n_leaf = visits
         n_visits = n_inner + n_leaf
         # bytes one ray asks of the memory system (with this build's packet sizes):
-        # inner-node packet (64 B fp32 BVH2 / 32 B quantised BVH2 / 128 B 4-ary), 48 B per leaf
+        # inner-node packet (64 B fp32 BVH2 / 32 B quantised BVH2 / 128 B fp32 4-ary / 64 B quantised 4-ary), 48 B per leaf
         # triangle, plus per surfel 16 sample blocks x 64 B trace record and the 8 B result cell
-        inner_bytes = 128.0 if opts.bvh_width == 4 else (32.0 if opts.bvh_quantised else 64.0)
+        inner_bytes = ((64.0 if opts.bvh_quantised else 128.0) if opts.bvh_width == 4
+                       else (32.0 if opts.bvh_quantised else 64.0))
         b_ray = inner_bytes * n_inner + 48.0 * n_leaf + (16 * 64.0 + 8.0) / args.spp
         achieved = my_rays * b_ray / (kernel_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

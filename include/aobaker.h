@@ -63,8 +63,9 @@ typedef struct AobOptions {
     int32_t  clamp_tmax_to_falloff; /* falloff mode: cast with tmax=min(tmax,falloff)     */
     int32_t  bvh_width;           /* traversal structure: 2 = the reference's BVH2 nodes, one lane
                                      per ray; 4 = BVH2 collapsed to 4-ary nodes, four lanes per ray
-                                     (one per child box); 0 = 2.  Default 2 (fastest measured)    */
-    int32_t  bvh_quantised;       /* bvh_width 2 only (default 1).  0: 64-byte fp32 nodes (the reference layout);
+                                     (quantised: one lane per ray); 0 = 2.  Default 4             */
+    int32_t  bvh_quantised;       /* default 1.  With bvh_width 4: 1 = lane-per-ray walk of AobBvh4QNode,
+                                     0 = quad-per-ray walk of the fp32 AobBvh4Node.  With bvh_width 2:  0: 64-byte fp32 nodes (the reference layout);
                                      1: 32-byte nodes, child boxes as 16-bit fixed point on the scene
                                      box, rounded outward (AobBvh2QNode)                            */
     int32_t  reserved[2];
@@ -167,6 +168,10 @@ typedef struct AobBvh4Node { float lo[4][4]; float hi[4][4]; } AobBvh4Node;
  * triangle (address - (n-1)) of AobLeafTri[].  Two 16-byte fetches per visit instead of four. */
 typedef struct AobBvh2QNode { uint32_t w[8]; } AobBvh2QNode;
 typedef struct AobQuantFrame { float origin[3]; float scale[3]; } AobQuantFrame;
+/* 64 B 4-ary node with quantised child boxes (same grid and rounding as AobBvh2QNode): child j is
+ * w[4j..4j+2] = x, y, z words (min | max<<16) and w[4j+3] = ref_j (as in AobBvh4Node); an empty
+ * slot has ref = AOB_INVALID_ADDR.  Walked one lane per ray (bvh_width 4, bvh_quantised 1). */
+typedef struct AobBvh4QNode { uint32_t w[16]; } AobBvh4QNode;
 /* 48 B leaf triangle in Morton order: v0.w = shape id bits, v1.w = prim id bits. */
 typedef struct AobLeafTri { float v0[4], v1[4], v2[4]; } AobLeafTri;
 
@@ -236,6 +241,8 @@ int aob_bake_copy_leaf_tris(AobBake* bake, AobLeafTri* dst, uint64_t capacity);
 /* The quantised BVH2 (max(0, n-1) AobBvh2QNode entries) and its frame. */
 int aob_bake_copy_nodes2q(AobBake* bake, AobBvh2QNode* dst, uint64_t capacity);
 int aob_bake_quant_frame(AobBake* bake, AobQuantFrame* frame);
+/* The quantised 4-ary nodes: node4_count entries of AobBvh4QNode. */
+int aob_bake_copy_nodes4q(AobBake* bake, AobBvh4QNode* dst, uint64_t capacity);
 int aob_bake_surfel_count(AobBake* bake, int32_t material, uint64_t* count);
 int aob_bake_copy_surfels(AobBake* bake, int32_t material, AobSurfel* dst, uint64_t capacity);
 int aob_bake_copy_results(AobBake* bake, int32_t material, AobResult* dst, uint64_t capacity);

@@ -814,7 +814,85 @@ static inline int traverse2q(const AobBvh2QNode* nq, uint64_t n, const AobQuantF
     return hit;
 }
 
+/* Quantised 4-ary nodes (AobBvh4QNode): the boxes of orc_bvh4_build on the grid of orc_bvh2q_build. */
+uint64_t orc_bvh4q_build(const AobBvh4Node* nodes4, uint64_t count4, const AobQuantFrame* fr, AobBvh4QNode* out)
+{
+    for (uint64_t i = 0; i < count4; i++) {
+        for (int j = 0; j < 4; j++) {
+            const float* lo = nodes4[i].lo[j]; const float* hi = nodes4[i].hi[j];
+            uint32_t ref; memcpy(&ref, &lo[3], 4);
+            uint32_t* w = &out[i].w[4 * j];
+            w[0] = w[1] = w[2] = 0; w[3] = ref;
+            if (ref == AOB_INVALID_ADDR) continue;
+            if (ref == 0 && lo[0] == 0.0f && hi[0] == 0.0f && lo[1] == 0.0f && hi[1] == 0.0f && lo[2] == 0.0f && hi[2] == 0.0f) continue;
+            for (int k = 0; k < 3; k++)
+                w[k] = quant_down(lo[k], fr->origin[k], fr->scale[k]) | quant_up(hi[k], fr->origin[k], fr->scale[k]) << 16;
+        }
+    }
+    return count4;
+}
+
 #define ORC_STACK4 512
+
+/* traverse4 on the quantised boxes (frame folded into the ray as in traverse2q). */
+static inline int traverse4q(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const AobLeafTri* tris,
+                             f3 o, f3 d, float t_max, int any_hit, float* t_out, OrcTraceStats* st, int* error)
+{
+    if (count4 == 0) { *t_out = t_max; return 0; }
+    f3 invdir = safe_invdir(d);
+    f3 oxinvdir = f3_make(-o.x * invdir.x, -o.y * invdir.y, -o.z * invdir.z);
+    f3 fb = f3_make(fmaf(fr->origin[0], invdir.x, oxinvdir.x), fmaf(fr->origin[1], invdir.y, oxinvdir.y), fmaf(fr->origin[2], invdir.z, oxinvdir.z));
+    f3 fa = f3_make(fr->scale[0] * invdir.x, fr->scale[1] * invdir.y, fr->scale[2] * invdir.z);
+    float closest_t = t_max;
+    int hit = 0;
+    uint32_t stack[ORC_STACK4];
+    int sp = 0;
+    stack[sp++] = AOB_INVALID_ADDR;
+    uint32_t node = 0;
+    while (node != AOB_INVALID_ADDR) {
+        if (!(node & AOB_LEAF_FLAG)) {
+            const uint32_t* w = nq[node].w;
+            st->inner_visits++;
+            float key[4]; uint32_t ref[4]; int chit[4], nhit = 0;
+            for (int j = 0; j < 4; j++) {
+                const uint32_t* c = &w[4 * j];
+                const float qmin[3] = { (float)(c[0] & 0xffffu), (float)(c[1] & 0xffffu), (float)(c[2] & 0xffffu) };
+                const float qmax[3] = { (float)(c[0] >> 16), (float)(c[1] >> 16), (float)(c[2] >> 16) };
+                float t0, t1;
+                intersect_bbox(qmin, qmax, fa, fb, closest_t, &t0, &t1);
+                ref[j] = c[3];
+                chit[j] = t0 <= t1 && ref[j] != AOB_INVALID_ADDR;
+                key[j] = chit[j] ? t0 : INFINITY;
+                nhit += chit[j];
+            }
+            if (nhit == 0) { node = stack[--sp]; continue; }
+            if (sp + nhit - 1 > ORC_STACK4) { *error = AOB_ERR_BVH_TOO_DEEP; *t_out = t_max; return 0; }
+            uint32_t first = AOB_INVALID_ADDR;
+            for (int j = 0; j < 4; j++) {
+                if (!chit[j]) continue;
+                int rank = 0;
+                for (int k = 0; k < 4; k++) rank += (key[k] < key[j]) || (key[k] == key[j] && k < j);
+                if (rank == 0) first = ref[j];
+                else stack[sp + (nhit - 1) - rank] = ref[j];
+            }
+            sp += nhit - 1;
+            node = first;
+        } else {
+            const AobLeafTri* tr = &tris[node & ~AOB_LEAF_FLAG];
+            st->leaf_visits++;
+            float t = intersect_triangle(o, d, f3_make(tr->v0[0], tr->v0[1], tr->v0[2]), f3_make(tr->v1[0], tr->v1[1], tr->v1[2]),
+                                         f3_make(tr->v2[0], tr->v2[1], tr->v2[2]), closest_t);
+            if (t < closest_t) {
+                closest_t = t; hit = 1;
+                if (any_hit) break;
+            }
+            node = stack[--sp];
+        }
+    }
+    *t_out = closest_t;
+    return hit;
+}
+
 
 /* The 4-ary walk of the GPU's quad-per-ray kernel, one ray at a time: slab-test the four child
  * boxes (intersect_bvh2_lds.cl:54-63), follow the nearest hit child and defer the others
@@ -881,6 +959,7 @@ typedef struct {
     const AobBvhNode* nodes; uint64_t node_count;
     const AobBvh4Node* nodes4; uint64_t node4_count; const AobLeafTri* tris;   /* bvh_width != 2 */
     const AobBvh2QNode* nodes2q; AobQuantFrame frame; uint64_t tri_count;        /* bvh_width 2, bvh_quantised */
+    const AobBvh4QNode* nodes4q;                                                 /* bvh_width 4, bvh_quantised */
     const AobSurfel* surfels; const uint32_t* section_index;
     const AobOptions* opt; const float* hemisphere;
     int32_t width, height; AobResult* results;
@@ -998,7 +1077,8 @@ static void trace_surfel(const TraceJob* job, uint64_t k, OrcTraceStats* st, int
         f3 org = f3_make(fmaf(dir.x, opt->ray_bias, P.x), fmaf(dir.y, opt->ray_bias, P.y), fmaf(dir.z, opt->ray_bias, P.z));
         float t;
         st->rays++;
-        int hit = job->nodes2q ? traverse2q(job->nodes2q, job->tri_count, &job->frame, job->tris, org, dir, t_max, any_hit, &t, st, error)
+        int hit = job->nodes4q ? traverse4q(job->nodes4q, job->node4_count, &job->frame, job->tris, org, dir, t_max, any_hit, &t, st, error)
+                : job->nodes2q ? traverse2q(job->nodes2q, job->tri_count, &job->frame, job->tris, org, dir, t_max, any_hit, &t, st, error)
                 : job->nodes4 ? traverse4(job->nodes4, job->node4_count, job->tris, org, dir, t_max, any_hit, &t, st, error)
                               : traverse(job->nodes, job->node_count, org, dir, t_max, any_hit, &t, st, error);
         st->hits += (uint64_t)hit;
@@ -1072,6 +1152,15 @@ int orc_trace(const AobBvhNode* nodes, uint64_t node_count,
         job.node4_count = orc_bvh4_build(nodes, node_count, nodes4, tris);
         job.nodes4 = nodes4; job.tris = tris;
     }
+    AobBvh4QNode* nodes4q = NULL;
+    if (opt->bvh_width == 4 && opt->bvh_quantised && node_count) {
+        AobBvh2QNode* scratch2q = (AobBvh2QNode*)malloc(sizeof(AobBvh2QNode) * (node_count / 2 + 1));
+        orc_bvh2q_build(nodes, node_count, scratch2q, &job.frame);         /* for the frame */
+        free(scratch2q);
+        nodes4q = (AobBvh4QNode*)malloc(sizeof(AobBvh4QNode) * job.node4_count);
+        orc_bvh4q_build(nodes4, job.node4_count, &job.frame, nodes4q);
+        job.nodes4q = nodes4q;
+    }
     AobBvh2QNode* nodes2q = NULL;
     if (opt->bvh_width != 4 && opt->bvh_quantised && node_count) {
         const uint64_t n = (node_count + 1) / 2;
@@ -1092,7 +1181,7 @@ int orc_trace(const AobBvhNode* nodes, uint64_t node_count,
         for (int i = 0; i < threads; i++) pthread_join(th[i], NULL);
     }
     pthread_mutex_destroy(&job.lock);
-    free(nodes4); free(tris); free(nodes2q);
+    free(nodes4); free(tris); free(nodes2q); free(nodes4q);
     if (stats) {
         stats->rays += job.stats.rays; stats->inner_visits += job.stats.inner_visits;
         stats->leaf_visits += job.stats.leaf_visits; stats->hits += job.stats.hits;

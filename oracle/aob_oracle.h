@@ -81,6 +81,9 @@ uint64_t orc_bvh4_build(const AobBvhNode* nodes2, uint64_t node_count2, AobBvh4N
  * kernel walks when AobOptions::bvh_quantised is set (bvh_width 2).  out: max(1, n-1) entries. */
 uint64_t orc_bvh2q_build(const AobBvhNode* nodes2, uint64_t node_count2, AobBvh2QNode* out, AobQuantFrame* frame);
 
+/* The 4-ary nodes with the quantised boxes (AobBvh4QNode; bvh_width 4 + bvh_quantised). */
+uint64_t orc_bvh4q_build(const AobBvh4Node* nodes4, uint64_t count4, const AobQuantFrame* frame, AobBvh4QNode* out);
+
 /* UV rasterisation + texel extraction for one material
  * (Rasterize{Vertex,Pixel}Shader.hlsl, BakeEngine.cpp:130-145,531-588).
  * Writes up to `capacity` surfels (row-major per section, sections

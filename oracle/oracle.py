@@ -57,6 +57,7 @@ def load():
         "orc_bvh_build": (u64, [vp, u64, vp, P(u32)]),
         "orc_bvh4_build": (u64, [vp, u64, vp, vp]),
         "orc_bvh2q_build": (u64, [vp, u64, vp, vp]),
+        "orc_bvh4q_build": (u64, [vp, u64, vp, vp]),
         "orc_rasterize": (u64, [P(capi.AobSceneDesc), i32, P(capi.AobOptions), vp, vp, u64]),
         "orc_trace": (C.c_int, [vp, u64, vp, vp, u64, u64, P(capi.AobOptions), vp, i32, i32, vp, i32,
                                 P(OrcTraceStats)]),
@@ -169,6 +170,15 @@ def bvh2q_build(nodes2):
     return out[:cnt], frame
 
 
+def bvh4q_build(nodes4, frame):
+    lib = load()
+    nodes4 = np.ascontiguousarray(nodes4)
+    frame = np.ascontiguousarray(frame, dtype=np.float32)
+    out = np.zeros((max(1, len(nodes4)), 16), dtype=np.uint32)
+    lib.orc_bvh4q_build(nodes4.ctypes.data, len(nodes4), frame.ctypes.data, out.ctypes.data)
+    return out[:len(nodes4)]
+
+
 def rasterize(desc, material, opt):
     lib = load()
     n = int(lib.orc_rasterize(C.byref(desc), material, C.byref(opt), None, None, 0))
@@ -230,6 +240,6 @@ def default_options():
     o.normal_fp16 = capi.FP16_RNE
     o.ray_chunk_size = 0xFFFFFF
     o.clamp_tmax_to_falloff = 0
-    o.bvh_width = 2
+    o.bvh_width = 4
     o.bvh_quantised = 1
     return o

@@ -45,7 +45,7 @@ def test_oracle_reproduces_golden(orc, mode, bpc, case):
     assert np.array_equal(sc.GetMaterial(0).GetAOTexture().GetData(), GOLD[f"{mode}_image"])
 
 
-@pytest.mark.parametrize("structure", [(2, 1), (4, 0)])
+@pytest.mark.parametrize("structure", [(2, 1), (4, 0), (4, 1)])
 @pytest.mark.parametrize("case", sorted(CASES))
 @pytest.mark.parametrize("mode,bpc", [("compat", 1), ("cosine", 4)])
 def test_other_traversal_structures_give_the_golden_image(orc, mode, bpc, case, structure):

@@ -60,10 +60,13 @@ def test_bvh4_nodes_bit_exact(engine, orc, name):
     ref4, ref_tris = orc.bvh4_build(ref2)
     with Baker(flat, make_options(orc)) as b:
         b.build_bvh()
-        got4, got_tris = b.nodes4(), b.leaf_tris()
+        got4, got_tris, got4q = b.nodes4(), b.leaf_tris(), b.nodes4q()
     assert len(got4) == len(ref4) and len(got_tris) == len(ref_tris)
     assert bits(got_tris).tobytes() == bits(ref_tris).tobytes()
     assert bits(got4).tobytes() == bits(ref4).tobytes()
+    # and their quantised form (AobBvh4QNode) on the AobBvh2QNode grid
+    _, frame = orc.bvh2q_build(ref2)
+    assert np.array_equal(got4q, orc.bvh4q_build(ref4, frame))
 
 
 @pytest.mark.parametrize("name", ["cube", "two_section", "sphere", "terrain", "floor_wall", "plane"])
@@ -111,14 +114,14 @@ MODES = [
 ]
 
 
-@pytest.mark.parametrize("width", [4, 2, "2q"])
+@pytest.mark.parametrize("width", [4, 2, "2q", "4q"])
 @pytest.mark.parametrize("mode", range(len(MODES)))
 @pytest.mark.parametrize("name", ["cube", "two_section", "sphere", "terrain", "cube_inward"])
 def test_trace_results_match_oracle(engine, orc, name, mode, width):
     """width 4: quad-per-ray kernel on the 4-ary nodes (the default); width 2: lane-per-ray kernel
     on the reference's 64-byte BVH2 nodes.  Each against the oracle walking the same structure."""
     flat = FlatScene(SCENES[name]())
-    opt = make_options(orc, sample_count=24, bvh_width=2 if width == "2q" else width, bvh_quantised=int(width == "2q"), **MODES[mode])
+    opt = make_options(orc, sample_count=24, bvh_width=int(str(width)[0]), bvh_quantised=int(str(width).endswith("q")), **MODES[mode])
     m = flat.material_array[0]
     nodes, _ = orc.bvh_build(orc.scene_triangles(flat.desc))
     surfels, sidx = orc.rasterize(flat.desc, 0, opt)
