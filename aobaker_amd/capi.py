@@ -43,7 +43,8 @@ class AobOptions(C.Structure):
         ("clamp_tmax_to_falloff", C.c_int32),
         ("bvh_width", C.c_int32),
         ("bvh_quantised", C.c_int32),
-        ("reserved", C.c_int32 * 2),
+        ("bvh_builder", C.c_int32),
+        ("reserved", C.c_int32 * 1),
     ]
 
 

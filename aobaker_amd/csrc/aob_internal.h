@@ -82,6 +82,8 @@ struct AobBake {
     aob::Box* node_bounds = nullptr;
     uint32_t* refit_flags = nullptr;
     uint32_t* depth_dev = nullptr;
+    uint2*    ploc_sums = nullptr;      // PLOC builder: scan partials (alive, merged)
+    uint32_t* ploc_totals = nullptr;
     AobBvhNode* nodes = nullptr;
     float4*   nodes4 = nullptr;         // 8 x float4 per 4-ary node (AobBvh4Node), indexed by BVH2 inner index
     float4*   leaf_tris = nullptr;      // 3 x float4 per triangle in Morton order (AobLeafTri)

@@ -437,7 +437,7 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
         p.tmax = o.ray_tmax;
         if (!o.use_any_hit && o.clamp_tmax_to_falloff && o.falloff_distance < p.tmax) p.tmax = o.falloff_distance;
         p.bias = o.ray_bias; p.falloff = o.falloff_distance;
-        p.refill_idle = max(1, env_int("AOB_TRACE_REFILL_IDLE", 12));
+        p.refill_idle = max(1, env_int("AOB_TRACE_REFILL_IDLE", 20));
         p.leaf_wait = max(1, env_int("AOB_TRACE_LEAF_WAIT", 12));
         cosine_grid(o.sample_count, p.grid);
         // one launch per section: two sections of a material may cover the same texel, and

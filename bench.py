@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--grid", type=int, default=708, help="terrain grid (708 -> 999 698 triangles)")
     ap.add_argument("--bvh-width", type=int, default=0, help="0 = library default, 2 = lane-per-ray BVH2, 4 = quad-per-ray 4-ary")
     ap.add_argument("--bvh-quantised", type=int, default=-1, help="-1 = library default; 1 = 32-byte 16-bit nodes (width 2)")
+    ap.add_argument("--bvh-builder", type=int, default=-1, help="-1 = library default; 0 = LBVH, 1 = PLOC")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -79,6 +80,8 @@ def main():
         opts.bvh_width = args.bvh_width
     if args.bvh_quantised >= 0:
         opts.bvh_quantised = args.bvh_quantised
+    if args.bvh_builder >= 0:
+        opts.bvh_builder = args.bvh_builder
 
     baker = Baker(flat, opts)           # uploads the scene: inputs resident in HBM from here on
     cells = aod.alias_results(baker, 0, as_float=True) if world > 1 else None
@@ -160,7 +163,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"terrain {flat.triangle_count()} tris, {W}x{H} atlas, {args.spp} spp, "
-                                   f"cosine sampler, any-hit, float accumulate, bvh_width {opts.bvh_width or 2}"
+                                   f"cosine sampler, any-hit, float accumulate, {'PLOC' if opts.bvh_builder else 'LBVH'} bvh_width {opts.bvh_width or 2}"
                                    f"{' quantised' if opts.bvh_quantised else ''} (BASELINE configs[2]"
                                    f"{' scaled: N x 2048^2 texels' if world > 1 else ''})",
                        "triangles": flat.triangle_count(), "atlas": [W, H], "spp": args.spp,
@@ -181,7 +184,7 @@ def main():
 def _oracle_inputs(flat, opts):
     from oracle import oracle as orc
     tris = orc.scene_triangles(flat.desc)
-    nodes, _ = orc.bvh_build(tris)
+    nodes, _ = orc.bvh_build(tris, opts.bvh_builder)
     surfels, _ = orc.rasterize(flat.desc, 0, opts)
     return orc, nodes, surfels
 

@@ -68,7 +68,10 @@ typedef struct AobOptions {
                                      0 = quad-per-ray walk of the fp32 AobBvh4Node.  With bvh_width 2:  0: 64-byte fp32 nodes (the reference layout);
                                      1: 32-byte nodes, child boxes as 16-bit fixed point on the scene
                                      box, rounded outward (AobBvh2QNode)                            */
-    int32_t  reserved[2];
+    int32_t  bvh_builder;         /* 0: LBVH, the reference stack's GPU builder (kernels/CL/build_hlbvh.cl);
+                                     1: PLOC (locally-ordered agglomerative clustering over the same Morton
+                                     order) — same node layouts, cheaper trees, ~1.5 ms more build time   */
+    int32_t  reserved[1];
 } AobOptions;
 
 /* ---- scene description ----------------------------------------------------

@@ -388,7 +388,21 @@ static inline void box_union(Box* d, const Box* a, const Box* b)
     for (int k = 0; k < 3; k++) { d->pmin[k] = fminf(a->pmin[k], b->pmin[k]); d->pmax[k] = fmaxf(a->pmax[k], b->pmax[k]); }
 }
 
+/* merged-box surface area as the PLOC builder of the HIP library evaluates it */
+static inline float merged_area(const Box* a, const Box* b)
+{
+    const float dx = fmaxf(a->pmax[0], b->pmax[0]) - fminf(a->pmin[0], b->pmin[0]);
+    const float dy = fmaxf(a->pmax[1], b->pmax[1]) - fminf(a->pmin[1], b->pmin[1]);
+    const float dz = fmaxf(a->pmax[2], b->pmax[2]) - fminf(a->pmin[2], b->pmin[2]);
+    return fmaf(dz, dx, fmaf(dy, dz, dx * dy));
+}
+
 uint64_t orc_bvh_build(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes, uint32_t* depth_out)
+{
+    return orc_bvh_build_ex(tris, n, nodes, depth_out, 0);
+}
+
+uint64_t orc_bvh_build_ex(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes, uint32_t* depth_out, int builder)
 {
     if (depth_out) *depth_out = 0;
     if (n == 0) return 0;
@@ -434,6 +448,55 @@ uint64_t orc_bvh_build(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes, u
     uint32_t* parent = (uint32_t*)malloc(4 * node_count);
     Box* bounds = (Box*)malloc(sizeof(Box) * node_count);
     parent[0] = 0xffffffffu;
+    uint32_t max_depth = 0;
+    if (builder == 1) {
+        /* PLOC: the sequential statement of the library's parallel builder.  Clusters in Morton order look
+         * `radius` places left and right for the neighbour with the smallest merged surface area (ties: the
+         * lower position); mutual nearest neighbours merge; the list is compacted; repeat.  Node ids are final
+         * from the start: leaf at position p is n-1+p, the k-th inner node created is n-2-k (root = 0). */
+        const int64_t radius = 8;
+        for (int64_t p = 0; p < N; p++) bounds[N - 1 + p] = pb[keys[p].idx];
+        uint32_t* cl = (uint32_t*)malloc(4 * n); uint32_t* nxt = (uint32_t*)malloc(4 * n); uint32_t* nn = (uint32_t*)malloc(4 * n);
+        for (int64_t p = 0; p < N; p++) cl[p] = (uint32_t)(N - 1 + p);
+        int64_t m = N; uint32_t created = 0; int iter = 0;
+        while (m > 1) {
+            const int forced = iter >= 256;
+            for (int64_t i = 0; i < m; i++) {
+                if (forced) { nn[i] = (uint32_t)(((i ^ 1) < m) ? (i ^ 1) : i); continue; }
+                const int64_t lo = i > radius ? i - radius : 0, hi = i + radius < m - 1 ? i + radius : m - 1;
+                float best = INFINITY; int64_t bj = i;
+                for (int64_t j = lo; j <= hi; j++) {
+                    if (j == i) continue;
+                    const float a = merged_area(&bounds[cl[i]], &bounds[cl[j]]);
+                    if (a < best || bj == i) { best = a; bj = j; }
+                }
+                nn[i] = (uint32_t)bj;
+            }
+            int64_t pos = 0; uint32_t mk = 0;
+            for (int64_t i = 0; i < m; i++) {
+                const int64_t j = nn[i];
+                const int mutual = j != i && (int64_t)nn[j] == i;
+                if (mutual && i > j) continue;
+                uint32_t id = cl[i];
+                if (mutual) {
+                    const uint32_t a = cl[i], b2 = cl[j];
+                    id = (uint32_t)(N - 2) - (created + mk); mk++;
+                    box_union(&bounds[id], &bounds[a], &bounds[b2]);
+                    left[id] = a; right[id] = b2; parent[a] = id; parent[b2] = id;
+                }
+                nxt[pos++] = id;
+            }
+            uint32_t* t = cl; cl = nxt; nxt = t;
+            m = pos; created += mk; iter++;
+        }
+        parent[0] = 0xffffffffu;
+        for (int64_t p = 0; p < N; p++) {
+            uint32_t dpt = 0;
+            for (uint32_t a = (uint32_t)(N - 1 + p); parent[a] != 0xffffffffu; a = parent[a]) dpt++;
+            if (dpt > max_depth) max_depth = dpt;
+        }
+        free(cl); free(nxt); free(nn);
+    } else {
     /* build_hlbvh.cl:152-261: span, split, child links */
     for (int64_t idx = 0; idx < N - 1; idx++) {
         int dnext = lbvh_delta(keys, N, idx, idx + 1), dprev = lbvh_delta(keys, N, idx, idx - 1);
@@ -464,7 +527,6 @@ uint64_t orc_bvh_build(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes, u
     for (int64_t p = 0; p < N; p++) bounds[N - 1 + p] = pb[keys[p].idx];
     /* refit (build_hlbvh.cl:264-314), serial: children before parents via visit counts */
     uint8_t* flags = (uint8_t*)calloc(n - 1, 1);
-    uint32_t max_depth = 0;
     for (int64_t p = 0; p < N; p++) {
         uint32_t idx = (uint32_t)(N - 1 + p);
         uint32_t dpt = 0;
@@ -475,6 +537,8 @@ uint64_t orc_bvh_build(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes, u
             if (flags[idx]++ == 0) break;
             box_union(&bounds[idx], &bounds[left[idx]], &bounds[right[idx]]);
         } while (idx != 0);
+    }
+    free(flags);
     }
     if (depth_out) *depth_out = max_depth;
     /* emit the 64-byte traversal nodes (intersect_bvh2_lds.cl:40-52) */
@@ -494,7 +558,7 @@ uint64_t orc_bvh_build(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes, u
         nd->addr_left = AOB_INVALID_ADDR; nd->addr_right = 0;
         nd->shape_id = t->shape_id; nd->prim_id = t->prim_id;
     }
-    free(flags); free(bounds); free(parent); free(right); free(left); free(keys); free(pb);
+    free(bounds); free(parent); free(right); free(left); free(keys); free(pb);
     return node_count;
 }
 
@@ -1281,7 +1345,7 @@ int orc_bake(const AobSceneDesc* scene, const AobOptions* opt, int32_t threads, 
     orc_scene_triangles(scene, tris);
     AobBvhNode* nodes = (AobBvhNode*)malloc(sizeof(AobBvhNode) * (ntri ? 2 * ntri : 1));
     uint32_t depth = 0;
-    uint64_t node_count = orc_bvh_build(tris, ntri, nodes, &depth);
+    uint64_t node_count = orc_bvh_build_ex(tris, ntri, nodes, &depth, opt->bvh_builder);
     float* hemi = NULL;
     if (opt->sampler == AOB_SAMPLER_REFERENCE_COMPAT) {
         uint64_t n = orc_compat_table_entries(opt);

@@ -55,6 +55,7 @@ def load():
         "orc_scene_triangle_count": (u64, [P(capi.AobSceneDesc)]),
         "orc_scene_triangles": (None, [P(capi.AobSceneDesc), vp]),
         "orc_bvh_build": (u64, [vp, u64, vp, P(u32)]),
+        "orc_bvh_build_ex": (u64, [vp, u64, vp, P(u32), C.c_int]),
         "orc_bvh4_build": (u64, [vp, u64, vp, vp]),
         "orc_bvh2q_build": (u64, [vp, u64, vp, vp]),
         "orc_bvh4q_build": (u64, [vp, u64, vp, vp]),
@@ -139,13 +140,16 @@ def scene_triangles(desc):
     return out[:n]
 
 
-def bvh_build(tris):
+def bvh_build(tris, builder=None):
+    """builder: 0 = LBVH (build_hlbvh.cl), 1 = PLOC; None = the default options' builder."""
     lib = load()
+    if builder is None:
+        builder = default_options().bvh_builder
     n = len(tris)
     tris = np.ascontiguousarray(tris)
     nodes = np.zeros(max(1, 2 * n), dtype=capi.node_dtype())
     depth = C.c_uint32()
-    cnt = int(lib.orc_bvh_build(tris.ctypes.data, n, nodes.ctypes.data, C.byref(depth)))
+    cnt = int(lib.orc_bvh_build_ex(tris.ctypes.data, n, nodes.ctypes.data, C.byref(depth), builder))
     return nodes[:cnt], depth.value
 
 
@@ -242,4 +246,5 @@ def default_options():
     o.clamp_tmax_to_falloff = 0
     o.bvh_width = 4
     o.bvh_quantised = 1
+    o.bvh_builder = 1
     return o

@@ -35,8 +35,8 @@ def test_oracle_reproduces_golden(orc, mode, bpc, case):
     sc = make(bpc)
     flat = FlatScene(sc)
     o = options(orc.default_options(), mode)
-    o.bvh_width, o.bvh_quantised = 2, 0          # the vectors were made on the reference's node layout
-    nodes, depth = orc.bvh_build(orc.scene_triangles(flat.desc))
+    o.bvh_width, o.bvh_quantised, o.bvh_builder = 2, 0, 0          # the vectors were made with the LBVH on the reference's node layout
+    nodes, depth = orc.bvh_build(orc.scene_triangles(flat.desc), 0)
     surfels, sidx = orc.rasterize(flat.desc, 0, o)
     assert digest(nodes) == str(GOLD[f"{mode}_nodes_sha256"])
     assert digest(surfels) == str(GOLD[f"{mode}_surfels_sha256"])
@@ -45,15 +45,15 @@ def test_oracle_reproduces_golden(orc, mode, bpc, case):
     assert np.array_equal(sc.GetMaterial(0).GetAOTexture().GetData(), GOLD[f"{mode}_image"])
 
 
-@pytest.mark.parametrize("structure", [(2, 1), (4, 0), (4, 1)])
+@pytest.mark.parametrize("structure", [(2, 1, 0), (4, 0, 0), (4, 1, 0), (4, 1, 1), (2, 0, 1)])
 @pytest.mark.parametrize("case", sorted(CASES))
 @pytest.mark.parametrize("mode,bpc", [("compat", 1), ("cosine", 4)])
 def test_other_traversal_structures_give_the_golden_image(orc, mode, bpc, case, structure):
-    """The quantised BVH2 (the GPU default) and the 4-ary collapse bake the same image."""
+    """Every (width, quantised, builder) combination — incl. the GPU default (4, 1, PLOC) — bakes the same image."""
     make, GOLD = CASES[case]
     sc = make(bpc)
     o = options(orc.default_options(), mode)
-    o.bvh_width, o.bvh_quantised = structure
+    o.bvh_width, o.bvh_quantised, o.bvh_builder = structure
     orc.bake(FlatScene(sc).desc, o, threads=os.cpu_count() or 1)
     assert np.array_equal(sc.GetMaterial(0).GetAOTexture().GetData(), GOLD[f"{mode}_image"])
 
@@ -78,20 +78,29 @@ def test_golden_terrain_has_real_occlusion():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("structure", ["reference", "default"])
 @pytest.mark.parametrize("case", sorted(CASES))
 @pytest.mark.parametrize("mode,bpc", [("compat", 1), ("cosine", 4)])
-def test_gpu_reproduces_golden(engine, mode, bpc, case):
-    """The HIP path against the committed vectors — no oracle involved on the GPU box."""
+def test_gpu_reproduces_golden(engine, mode, bpc, case, structure):
+    """The HIP path against the committed vectors — no oracle involved on the GPU box.
+    "reference": LBVH + the reference's 64-byte nodes (what the vectors were made with): every stage digest.
+    "default": the library's defaults (PLOC, quantised 4-ary nodes): surfels, result cells and image."""
     from aobaker_amd import Baker
     make, GOLD = CASES[case]
     sc = make(bpc)
     flat = FlatScene(sc)
     o = options(capi.default_options(), mode)
+    if structure == "reference":
+        o.bvh_width, o.bvh_quantised, o.bvh_builder = 2, 0, 0
     with Baker(flat, o) as b:
         b.build_bvh(); b.rasterize(0); b.trace(0); b.resolve(0); b.download(0)
-        assert digest(b.nodes()) == str(GOLD[f"{mode}_nodes_sha256"])
+        if structure == "reference":
+            assert digest(b.nodes()) == str(GOLD[f"{mode}_nodes_sha256"])
         assert digest(b.surfels(0)) == str(GOLD[f"{mode}_surfels_sha256"])
         assert digest(b.results(0)) == str(GOLD[f"{mode}_results_sha256"])
         st = b.stats()
-    assert [st.node_count, st.bvh_depth, st.surfel_count, st.ray_count] == GOLD[f"{mode}_counts"].tolist()[:4]
+    want = GOLD[f"{mode}_counts"].tolist()
+    assert [st.node_count, st.surfel_count, st.ray_count] == [want[0], want[2], want[3]]
+    if structure == "reference":
+        assert st.bvh_depth == want[1]
     assert np.array_equal(sc.GetMaterial(0).GetAOTexture().GetData(), GOLD[f"{mode}_image"])

@@ -49,11 +49,12 @@ def test_config2_sphere_complete_bake(engine, orc):
     assert 0.2 < g.ao()[g.ao() > 0].mean() < 1.0
 
 
-def test_config3_bvh_and_surfels_bit_exact(engine, orc, terrain):
+@pytest.mark.parametrize("builder", [1, 0])
+def test_config3_bvh_and_surfels_bit_exact(engine, orc, terrain, builder):
     flat = FlatScene(terrain)
-    opt = cosine_options(orc, 4)
+    opt = cosine_options(orc, 4, bvh_builder=builder)
     tris = orc.scene_triangles(flat.desc)
-    ref_nodes, ref_depth = orc.bvh_build(tris)
+    ref_nodes, ref_depth = orc.bvh_build(tris, builder)
     refq, ref_frame = orc.bvh2q_build(ref_nodes)
     ref_surfels, _ = orc.rasterize(flat.desc, 0, opt)
     with Baker(flat, opt) as b:

@@ -38,11 +38,13 @@ SCENES = {
 }
 
 
-@pytest.mark.parametrize("name", ["cube", "two_section", "sphere", "terrain", "floor_wall"])
-def test_bvh_nodes_bit_exact(engine, orc, name):
+@pytest.mark.parametrize("builder", [0, 1])
+@pytest.mark.parametrize("name", ["cube", "two_section", "sphere", "terrain", "floor_wall", "plane"])
+def test_bvh_nodes_bit_exact(engine, orc, name, builder):
+    """builder 0: LBVH (build_hlbvh.cl); builder 1: PLOC.  Topology, boxes, leaf order, depth."""
     flat = FlatScene(SCENES[name]())
-    ref_nodes, ref_depth = orc.bvh_build(orc.scene_triangles(flat.desc))
-    with Baker(flat, make_options(orc)) as b:
+    ref_nodes, ref_depth = orc.bvh_build(orc.scene_triangles(flat.desc), builder)
+    with Baker(flat, make_options(orc, bvh_builder=builder)) as b:
         b.build_bvh()
         nodes = b.nodes()
         st = b.stats()
@@ -310,3 +312,31 @@ def test_instanced_scene_with_transforms(engine, orc, mode):
     assert np.array_equal(g.GetData(), c.GetData())
     ao = g.ao()
     assert ao.max() > 0.9 and 0.02 < (ao < 0.9).mean() < 0.97         # rocks darken the ground and each other; gutters are black
+
+
+@pytest.mark.parametrize("mode", [2, 3, 0])
+@pytest.mark.parametrize("name", ["terrain", "sphere", "cube_inward"])
+def test_ploc_builder_end_to_end(engine, orc, name, mode):
+    """bvh_builder = 1 through every derived structure and the trace, against the oracle's PLOC twin."""
+    flat = FlatScene(SCENES[name]())
+    opt = make_options(orc, sample_count=16, bvh_builder=1, **MODES[mode])
+    m = flat.material_array[0]
+    nodes, _ = orc.bvh_build(orc.scene_triangles(flat.desc), 1)
+    surfels, sidx = orc.rasterize(flat.desc, 0, opt)
+    hemi = orc.compat_table(opt) if opt.sampler == capi.SAMPLER_REFERENCE_COMPAT else None
+    ref, st1 = orc.trace(nodes, surfels, sidx, opt, m.width, m.height, hemi, threads=8)
+    with Baker(flat, opt) as b:
+        b.build_bvh(); b.rasterize(0); b.trace(0)
+        got = b.results(0)
+        ref4, _ = orc.bvh4_build(nodes)
+        assert bits(b.nodes4()).tobytes() == bits(ref4).tobytes()
+    assert np.array_equal(got["total_bits"], ref["total_bits"]) and np.array_equal(got["weight_bits"], ref["weight_bits"])
+    # same image as the LBVH, fewer node visits
+    opt0 = make_options(orc, sample_count=16, bvh_builder=0, **MODES[mode])
+    nodes0, _ = orc.bvh_build(orc.scene_triangles(flat.desc), 0)
+    ref0, st0 = orc.trace(nodes0, surfels, sidx, opt0, m.width, m.height, hemi, threads=8)
+    assert np.array_equal(ref0["weight_bits"], ref["weight_bits"])
+    if opt.use_any_hit:
+        assert np.array_equal(ref0["total_bits"], ref["total_bits"])
+    if name != "cube_inward":
+        assert st1.inner_visits < st0.inner_visits
