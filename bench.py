@@ -40,8 +40,8 @@ def main():
     ap.add_argument("--atlas", type=int, default=2048)
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--grid", type=int, default=708, help="terrain grid (708 -> 999 698 triangles)")
-    ap.add_argument("--bvh-width", type=int, default=0, help="0 = library default, 2 = lane-per-ray BVH2, 4 = quad-per-ray 4-ary")
-    ap.add_argument("--bvh-quantised", type=int, default=-1, help="-1 = library default; 1 = 32-byte 16-bit nodes (width 2)")
+    ap.add_argument("--bvh-width", type=int, default=0, help="0 = library default (4), 2 = BVH2 nodes, 4 = 4-ary nodes")
+    ap.add_argument("--bvh-quantised", type=int, default=-1, help="-1 = library default (1); 1 = 16-bit quantised boxes, lane per ray; 0 = fp32 boxes")
     ap.add_argument("--bvh-builder", type=int, default=-1, help="-1 = library default; 0 = LBVH, 1 = PLOC")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
