@@ -165,7 +165,8 @@ _LIB = None
 
 
 def library_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaobaker_hip.so")
+    # AOBAKER_HIP_LIBRARY: another build of the same library (kernel experiments); still no fallback
+    return os.environ.get("AOBAKER_HIP_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaobaker_hip.so")
 
 
 def load() -> C.CDLL:

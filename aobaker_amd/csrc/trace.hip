@@ -4,34 +4,31 @@
 //   GenerateRaysComputeShader.hlsl:31-55   (48-byte ray records, numthreads(1,1,1))
 //   IntersectionApi::QueryIntersection     (RadeonRays; kernels/CL/intersect_bvh2_lds.cl)
 //   ProcessIntersectionsComputeShader.hlsl:52-92 (2 atomics per sample, numthreads(1,1,1))
-// with ONE kernel: rays are generated in registers (no ray or hit records ever reach
-// HBM), walk the 64-byte-node BVH2 with the reference's near-child-first order and a
-// per-lane LDS stack (intersect_bvh2_lds.cl:78,123-153), are scored in registers, and
-// each texel's result cell is written once.
+// with ONE kernel: rays never reach HBM.  They are generated a wavefront at a time into a
+// small LDS queue, walk the BVH one lane per ray with a per-lane LDS stack
+// (intersect_bvh2_lds.cl:78,123-153), are scored in registers and added to per-surfel
+// LDS accumulators; each texel's result cell is written once.
 //
-// Work distribution.  A wavefront owns 64 consecutive surfels; their samples form a pool
-// of (surfel, sample block) items — 16 blocks per surfel — that the wave's lanes draw
-// from with a wave-uniform counter (__ballot + mbcnt ranking, no atomics, no LDS queue).
-// A lane that finishes its block early takes the next item of ANY surfel of its wave, so
-// lanes whose surfels have cheap rays do not idle behind the expensive ones.  Per-surfel
-// sums live in LDS as 64-bit integers (int32-range quantised sums in the reference's mode,
-// exact Q32.32 sums in float mode), which makes the result independent of which lane
-// traced which block, and bit-identical to the oracle's sequential loop.
-//
-// Wave scheduling (the kernel is VALU-issue bound, not HBM bound — profiles/r01): one
-// loop whose three sections are entered on wave-wide votes:
-//   refill   idle lanes pick their next ray (and, at block ends, their next item) once
-//            `refill_idle` of them are waiting;
-//   leaf     lanes parked at a leaf (leaf-ness is known from the address alone: leaves
-//            live at [leaf_base, 2n-1)) run Möller–Trumbore once `leaf_wait` are waiting;
-//   inner    every lane at an inner node does its two slab tests each iteration.
-// Keeping the leaf test out of the common iteration stops the 64 lanes from serialising
-// both code paths every step.  Each ray still visits its nodes in exactly the reference's
-// depth-first order, so the per-ray arithmetic — and the result — does not depend on it.
+// Work distribution.  A workgroup is ONE wavefront and owns 64 consecutive surfels of the
+// trace order (an 8x8 texel tile, raster.hip).  Three sections of one loop are entered on
+// wave-wide votes:
+//   refill   once `refill_idle` lanes have no ray, they pop rays from the wave's queue; when
+//            the queue runs dry ALL 64 lanes generate the next sample of the 64 surfels —
+//            lane = surfel, every lane produces a ray — so the sampler (a hash, a sincos
+//            polynomial, two square roots, three divisions) always runs at full occupancy
+//            however few lanes are waiting;
+//   leaf     lanes parked at a leaf (leaf-ness is known from the address alone) run
+//            Möller–Trumbore once `leaf_wait` are waiting;
+//   inner    every lane at an inner node does its slab tests each iteration.
+// A ray is traced by whichever lane pops it; it carries its surfel's slot and adds its score
+// to that surfel's 64-bit LDS accumulators (int32-range quantised sums in the reference's
+// mode, exact Q32.32 sums in float mode), so the result does not depend on which lane traced
+// which ray and is bit-identical to the oracle's sequential loop.  Each ray still visits its
+// nodes in exactly the reference's depth-first order.
 //
 // The hot data is the node array (64 B per inner visit, 48 B per leaf visit, shared by
-// neighbouring lanes and served from L1/L2/Infinity Cache); the per-surfel record (64 B)
-// is read once per sample block and the result cell (8 B) written once per surfel.
+// neighbouring lanes and served from L1/L2/Infinity Cache); the per-surfel frame (64 B) is
+// re-read from L1 once per generated sample and the result cell (8 B) written once per surfel.
 #include "aob_internal.h"
 #include "aob_math.h"
 
@@ -39,9 +36,9 @@
 
 namespace aob {
 
-static constexpr int kBlock = 256;
-static constexpr int kBlocksPerSurfel = 16;       // sample blocks per surfel
-static constexpr int kLdsStack = 16;              // traversal stack entries per lane kept in LDS
+static constexpr int kWave = 64;                  // threads per workgroup: one wavefront
+static constexpr int kLdsStack = 8;               // traversal stack entries per lane kept in LDS; deeper entries go to HBM
+                                                  // (4-ary walk, 1 M-triangle terrain: 96 % of the pushes land in slots 1..7)
 static constexpr uint32_t kInvalid = 0xffffffffu;
 
 struct TraceParams {
@@ -58,12 +55,11 @@ struct TraceParams {
     uint32_t node_count;
     uint32_t leaf_base;            // first leaf address (n - 1)
     int32_t spp;
-    int32_t block_samples;         // ceil(spp / kBlocksPerSurfel)
     uint32_t seed_hash;
     float tmax, bias, falloff;
     CosineGrid grid;
     uint32_t nblocks, blocks_per_xcd;
-    int32_t refill_idle;           // idle lanes that trigger the refill section
+    int32_t refill_idle;           // lanes without a ray that trigger the refill section
     int32_t leaf_wait;             // lanes parked at a leaf that trigger the leaf section
 };
 
@@ -79,29 +75,28 @@ __device__ __forceinline__ long long f2fix(float v)
 // LDS_N: stack entries per lane kept in LDS; deeper entries spill to p.gstack.
 // QUANT 1: walk the 32-byte BVH2 nodes with 16-bit quantised child boxes (two 16-byte fetches per visit
 // instead of four) and the 48-byte leaf triangles.  QUANT 2: the same boxes in 4-ary nodes (AobBvh4QNode,
-// every second level collapsed): 68 instead of 76 slab tests per ray and half the loop iterations.
+// every second level collapsed): fewer slab tests per ray and half the loop iterations.
 #ifndef AOB_TRACE_WAVES
 #define AOB_TRACE_WAVES 8          // waves per SIMD the register allocator must leave room for (<= 64 VGPRs):
                                    // measured 4.98 / 5.14 / 5.55 Grays/s at 6 / 7 / 8 — latency hiding beats the few spills
 #endif
 template <int SAMPLER, int ANYHIT, int ACCUM, int LDS_N, int QUANT>
-__global__ __launch_bounds__(kBlock, AOB_TRACE_WAVES)
+__global__ __launch_bounds__(kWave, AOB_TRACE_WAVES)
 void k_trace(TraceParams p)
 {
-    __shared__ uint32_t lds_stack[LDS_N * kBlock];
-    __shared__ unsigned long long acc[kBlock][2];       // per surfel of this block: total, weight
+    // 5 KB per wavefront: 32 wavefronts per CU fill its 160 KB
+    __shared__ uint32_t lds_stack[LDS_N * kWave];
+    __shared__ unsigned long long acc[kWave][2];        // per surfel: total, weight
+    __shared__ uint4 queue[kWave * 2];                  // ray queue: {dir.xyz, slot}, {1/dir.xyz, weight}
 
     // Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8).  Give each XCD
     // a contiguous run of surfel tiles so that its private 4 MiB L2 keeps seeing the same part
     // of the atlas, hence the same part of the BVH.
     const uint32_t lb = (blockIdx.x & 7u) * p.blocks_per_xcd + (blockIdx.x >> 3);
     if (lb >= p.nblocks) return;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
-    const uint64_t wave_first = p.begin + (uint64_t)lb * kBlock + (uint64_t)wave * 64u;   // first surfel of this wave
-    const uint32_t nsurf = wave_first >= p.end ? 0u : (uint32_t)min((uint64_t)64, p.end - wave_first);
-    const uint32_t total_items = nsurf ? 64u * kBlocksPerSurfel : 0u;      // item = block * 64 + surfel slot
-    uint32_t item_next = 0;                                                // wave-uniform
+    const uint32_t lane = threadIdx.x;
+    const uint64_t wave_first = p.begin + (uint64_t)lb * kWave;            // first surfel of this wave
+    const uint32_t nsurf = (uint32_t)min((uint64_t)kWave, p.end - wave_first);
 
     f3 q_origin = make_f3(0.f, 0.f, 0.f), q_scale = make_f3(0.f, 0.f, 0.f);
     if (QUANT) {
@@ -109,133 +104,136 @@ void k_trace(TraceParams p)
         q_scale = make_f3(p.quant_frame[3], p.quant_frame[4], p.quant_frame[5]);
     }
 
-    acc[tid][0] = 0ull; acc[tid][1] = 0ull;
-    lds_stack[tid] = kInvalid;       // entry 0: the INVALID sentinel (intersect_bvh2_lds.cl:103): a pop is one read
-    // overflow stack entry e of this lane lives at gstack[e * (gridDim.x*256) + blockIdx.x*256 + tid] (computed on use:
+    acc[lane][0] = 0ull; acc[lane][1] = 0ull;
+    lds_stack[lane] = kInvalid;      // entry 0: the INVALID sentinel (intersect_bvh2_lds.cl:103): a pop is one read
+    // overflow stack entry e of this lane lives at gstack[(e * gridDim.x + blockIdx.x) * 64 + lane] (computed on use:
     // the path is cold and the registers are better spent on occupancy)
-    auto gs_slot = [&](int e) -> uint32_t* { return p.gstack + ((uint64_t)e * gridDim.x + blockIdx.x) * kBlock + tid; };
+    auto gs_slot = [&](int e) -> uint32_t* { return p.gstack + ((uint64_t)e * gridDim.x + blockIdx.x) * kWave + lane; };
 
-    // current block of samples: [cur, blk_end) of surfel slot `slot`
-    int32_t cur = 0, blk_end = 0;
-    uint32_t slot = 0;
-    bool has_partial = false;
-    // block sums.  COSINE sampler: every weight is exactly 1, so the sums are counters (UNITW);
-    // REFERENCE_COMPAT: 64-bit sums of the per-ray weight cW converted at ray generation.
-    constexpr bool UNITW = SAMPLER == AOB_SAMPLER_COSINE;
+    // ---- the generator: lane = surfel; sample `gen_next` of every surfel is made in one go ----
+    constexpr bool UNITW = SAMPLER == AOB_SAMPLER_COSINE;   // every weight is exactly 1
     constexpr long long kUnit = ACCUM == AOB_ACCUMULATE_QUANTISED ? 255ll : (1ll << 32);   // ftoi(1*255) / f2fix(1)
-    long long pT = 0, pW = 0, cW = 0;
-    int32_t nW = 0, nMiss = 0;
-    f3 P, N, X, Z;
-    P = N = X = Z = make_f3(0.f, 0.f, 0.f);
-    uint32_t hash_base = 0;
-    const float* table = nullptr;
+    bool valid = false;              // this lane's surfel exists and has a tangent frame
+    uint32_t gen_key = 0;            // COSINE: hash base of the texel; REFERENCE_COMPAT: first hemisphere-table entry
+    if (lane < nsurf) {
+        const float4 d = p.frames[4ull * (wave_first + lane) + 3];
+        valid = __float_as_uint(d.z) != 0u;
+        gen_key = SAMPLER == AOB_SAMPLER_REFERENCE_COMPAT ? __float_as_uint(d.y)        // Hemisphere[DTid.x * SampleCount + i]
+                                                           : pcg_hash(__float_as_uint(d.x) + p.seed_hash);
+    }
+    const uint64_t valid_m = __ballot(valid);
+    const uint32_t n_valid = (uint32_t)__popcll(valid_m);
+    const int32_t gen_end = n_valid ? p.spp : 0;
+    int32_t gen_next = 0;            // wave-uniform: next sample index
+    uint32_t q_head = 0, q_count = 0;                   // wave-uniform: the queue is a ring of 64 rays
 
+    // ---- the ray a lane is tracing ----
     bool active = false;
     f3 org, dir, invdir, oxinvdir;
     org = dir = invdir = oxinvdir = make_f3(0.f, 0.f, 0.f);
     float w = 0.0f, closest_t = 0.0f;
     uint3 rot = make_uint3(0u, 0u, 0u);        // QUANT: 16 for axes the ray travels down, else 0
     bool hit = false;
+    uint32_t slot = 0;                         // the ray's surfel
     uint32_t addr = kInvalid;
     int sp = 1;
 
     auto push = [&](uint32_t v) {
-        if (sp < LDS_N) lds_stack[sp * kBlock + tid] = v;
+        if (sp < LDS_N) lds_stack[sp * kWave + lane] = v;
         else *gs_slot(sp - LDS_N) = v;
         sp++;
     };
     auto pop = [&]() -> uint32_t {
         sp--;
         uint32_t v;
-        if (sp < LDS_N) { v = lds_stack[sp * kBlock + tid]; asm volatile("" : "+v"(v)); }
+        if (sp < LDS_N) { v = lds_stack[sp * kWave + lane]; asm volatile("" : "+v"(v)); }
         else { v = *gs_slot(sp - LDS_N); asm volatile("" : "+v"(v)); }
         return v;
     };
-    // ProcessIntersectionsComputeShader.hlsl:69-90
+    // ProcessIntersectionsComputeShader.hlsl:69-90: the ray's score goes to its surfel's sums
     auto finish = [&]() {
         if (ANYHIT) {
             // r is 0 or 1: the sample adds its weight to the weight sum and, if unoccluded, to the total
-            // ((1.0f * w) * 255.0f == w * 255.0f exactly).  cW was converted when the ray was made, with the
-            // whole refill group active; this path runs with one or two lanes.
-            if (UNITW) { nW++; if (!hit) nMiss++; }
-            else { pW += cW; if (!hit) pT += cW; }
+            // ((1.0f * w) * 255.0f == w * 255.0f exactly).  Unit weights: the weight sum is the sample count (epilogue).
+            if (UNITW) {
+                if (!hit) atomicAdd(&acc[slot][0], (unsigned long long)kUnit);
+            } else {
+                const long long cW = ACCUM == AOB_ACCUMULATE_QUANTISED ? (long long)ftoi(w * 255.0f) : f2fix(w);
+                atomicAdd(&acc[slot][1], (unsigned long long)cW);
+                if (!hit) atomicAdd(&acc[slot][0], (unsigned long long)cW);
+            }
         } else {
             const float r = (hit && closest_t < p.falloff) ? closest_t / p.falloff : 1.0f;
-            if (UNITW) {
-                nW++;
-                pT += ACCUM == AOB_ACCUMULATE_QUANTISED ? (long long)ftoi(r * 1.0f * 255.0f) : f2fix(r * 1.0f);
-            } else {
-                if (ACCUM == AOB_ACCUMULATE_QUANTISED) { pT += ftoi(r * w * 255.0f); pW += cW; }
-                else { pT += f2fix(r * w); pW += cW; }
-            }
+            const float rw = UNITW ? r * 1.0f : r * w;
+            atomicAdd(&acc[slot][0], (unsigned long long)(ACCUM == AOB_ACCUMULATE_QUANTISED ? (long long)ftoi(rw * 255.0f) : f2fix(rw)));
+            if (!UNITW) atomicAdd(&acc[slot][1], (unsigned long long)(ACCUM == AOB_ACCUMULATE_QUANTISED ? (long long)ftoi(w * 255.0f) : f2fix(w)));
         }
         active = false;
     };
 
     for (;;) {
-        const bool pool_empty = item_next >= total_items;
-        const bool refillable = !active && (cur < blk_end || !pool_empty);
         const uint64_t active_m = __ballot(active);
-        const int n_refill = __popcll(__ballot(refillable));
-        if (active_m == 0ull && n_refill == 0) break;
+        const bool more = q_count != 0u || gen_next < gen_end;
+        if (active_m == 0ull && !more) break;
 
         // ---- refill section ----
-        if (n_refill >= p.refill_idle || active_m == 0ull) {
-            const bool need_item = !active && cur >= blk_end;
-            if (need_item && has_partial) {
-                // block finished: fold its sums into the surfel's accumulators
-                atomicAdd(&acc[wave * 64u + slot][0], (unsigned long long)(UNITW && ANYHIT ? nMiss * kUnit : pT));
-                atomicAdd(&acc[wave * 64u + slot][1], (unsigned long long)(UNITW ? nW * kUnit : pW));
-                has_partial = false;
-            }
-            const uint64_t want_m = __ballot(need_item && !pool_empty);
-            if (want_m != 0ull) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want_m, 0u));
-                const uint32_t item = item_next + rank;
-                item_next += (uint32_t)__popcll(want_m);
-                if (need_item && !pool_empty && item < total_items) {
-                    const uint32_t s = item & 63u, blk = item >> 6;
-                    if (s < nsurf) {
-                        const float4* fr = p.frames + 4ull * (wave_first + s);
-                        const float4 a = fr[0], b = fr[1], c = fr[2], d = fr[3];
-                        if (__float_as_uint(d.z) != 0u) {
-                            P = make_f3(a.x, a.y, a.z); N = make_f3(a.w, b.x, b.y);
-                            X = make_f3(b.z, b.w, c.x); Z = make_f3(c.y, c.z, c.w);
-                            slot = s;
-                            cur = (int32_t)blk * p.block_samples;
-                            blk_end = min(p.spp, cur + p.block_samples);
-                            pT = 0; pW = 0; nW = 0; nMiss = 0;
-                            has_partial = cur < blk_end;
-                            hash_base = pcg_hash(__float_as_uint(d.x) + p.seed_hash);
-                            if (SAMPLER == AOB_SAMPLER_REFERENCE_COMPAT)
-                                table = p.hemisphere + 3ull * __float_as_uint(d.y);   // Hemisphere[DTid.x * SampleCount + i]
+        if (more && (kWave - __popcll(active_m) >= p.refill_idle || active_m == 0ull)) {
+            for (int pass = 0; pass < 2; pass++) {
+                const uint64_t idle_m = __ballot(!active);
+                if (q_count != 0u) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
+                    if (!active && rank < q_count) {
+                        const uint32_t pos = (q_head + rank) & (kWave - 1u);
+                        const uint4 e0 = queue[pos * 2], e1 = queue[pos * 2 + 1];
+                        slot = e0.w;
+                        const float4 a = p.frames[4ull * (wave_first + slot)];
+                        dir = make_f3(__uint_as_float(e0.x), __uint_as_float(e0.y), __uint_as_float(e0.z));
+                        invdir = make_f3(__uint_as_float(e1.x), __uint_as_float(e1.y), __uint_as_float(e1.z));
+                        w = __uint_as_float(e1.w);
+                        org = make_f3(fmaf(dir.x, p.bias, a.x), fmaf(dir.y, p.bias, a.y), fmaf(dir.z, p.bias, a.z));   // GenerateRays:47
+                        oxinvdir = make_f3(-org.x * invdir.x, -org.y * invdir.y, -org.z * invdir.z);
+                        if (QUANT) {
+                            rot = make_uint3((e1.x >> 31) << 4, (e1.y >> 31) << 4, (e1.z >> 31) << 4);
+                            // fold the de-quantisation into the ray: (origin + q*scale - o) * invdir = q*(scale*invdir) + (origin*invdir + oxinvdir)
+                            oxinvdir = make_f3(fmaf(q_origin.x, invdir.x, oxinvdir.x), fmaf(q_origin.y, invdir.y, oxinvdir.y), fmaf(q_origin.z, invdir.z, oxinvdir.z));
+                            invdir = make_f3(q_scale.x * invdir.x, q_scale.y * invdir.y, q_scale.z * invdir.z);
                         }
+                        closest_t = p.tmax; hit = false; sp = 1;
+                        active = true;
+                        addr = 0;
+                        if (p.node_count == 0) finish();          // empty scene: every ray misses
                     }
+                    const uint32_t taken = min((uint32_t)__popcll(idle_m), q_count);
+                    q_head = (q_head + taken) & (kWave - 1u);
+                    q_count -= taken;
                 }
-            }
-            if (!active && cur < blk_end) {
-                f3 h;
-                if (SAMPLER == AOB_SAMPLER_REFERENCE_COMPAT) h = make_f3(table[3 * cur], table[3 * cur + 1], table[3 * cur + 2]);
-                else h = cosine_sample(hash_base, cur, p.grid);
-                cur++;
-                dir = make_f3(fmaf(h.z, Z.x, fmaf(h.y, N.x, h.x * X.x)),
-                              fmaf(h.z, Z.y, fmaf(h.y, N.y, h.x * X.y)),
-                              fmaf(h.z, Z.z, fmaf(h.y, N.z, h.x * X.z)));                       // GenerateRays:46
-                org = make_f3(fmaf(dir.x, p.bias, P.x), fmaf(dir.y, p.bias, P.y), fmaf(dir.z, p.bias, P.z)); // :47
-                w = SAMPLER == AOB_SAMPLER_REFERENCE_COMPAT ? dot(N, dir) : 1.0f;
-                if (!UNITW) cW = ACCUM == AOB_ACCUMULATE_QUANTISED ? (long long)ftoi(w * 255.0f) : f2fix(w);
-                invdir = make_f3(safe_inv1(dir.x), safe_inv1(dir.y), safe_inv1(dir.z));
-                oxinvdir = make_f3(-org.x * invdir.x, -org.y * invdir.y, -org.z * invdir.z);
-                if (QUANT) {
-                    rot = make_uint3((__float_as_uint(invdir.x) >> 31) << 4, (__float_as_uint(invdir.y) >> 31) << 4, (__float_as_uint(invdir.z) >> 31) << 4);
-                    // fold the de-quantisation into the ray: (origin + q*scale - o) * invdir = q*(scale*invdir) + (origin*invdir + oxinvdir)
-                    oxinvdir = make_f3(fmaf(q_origin.x, invdir.x, oxinvdir.x), fmaf(q_origin.y, invdir.y, oxinvdir.y), fmaf(q_origin.z, invdir.z, oxinvdir.z));
-                    invdir = make_f3(q_scale.x * invdir.x, q_scale.y * invdir.y, q_scale.z * invdir.z);
+                // rays left in the queue: every idle lane was served
+                if (pass == 1 || q_count != 0u || gen_next >= gen_end) break;
+                // the queue is empty: sample gen_next of all 64 surfels, one per lane
+                const int32_t i = gen_next++;
+                if (valid) {
+                    const float4* fr = p.frames + 4ull * (wave_first + lane);
+                    const float4 a = fr[0], b = fr[1], c = fr[2];
+                    const f3 N = make_f3(a.w, b.x, b.y), X = make_f3(b.z, b.w, c.x), Z = make_f3(c.y, c.z, c.w);
+                    f3 h;
+                    if (SAMPLER == AOB_SAMPLER_REFERENCE_COMPAT) {
+                        const float* t = p.hemisphere + 3ull * gen_key + 3 * i;
+                        h = make_f3(t[0], t[1], t[2]);
+                    } else {
+                        h = cosine_sample(gen_key, i, p.grid);
+                    }
+                    const f3 d = make_f3(fmaf(h.z, Z.x, fmaf(h.y, N.x, h.x * X.x)),
+                                         fmaf(h.z, Z.y, fmaf(h.y, N.y, h.x * X.y)),
+                                         fmaf(h.z, Z.z, fmaf(h.y, N.z, h.x * X.z)));                       // GenerateRays:46
+                    const float gw = SAMPLER == AOB_SAMPLER_REFERENCE_COMPAT ? dot(N, d) : 1.0f;
+                    const uint32_t pos = (q_head + __builtin_amdgcn_mbcnt_hi((uint32_t)(valid_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)valid_m, 0u))) & (kWave - 1u);
+                    queue[pos * 2] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), lane);
+                    queue[pos * 2 + 1] = make_uint4(__float_as_uint(safe_inv1(d.x)), __float_as_uint(safe_inv1(d.y)), __float_as_uint(safe_inv1(d.z)),
+                                                    __float_as_uint(gw));
                 }
-                closest_t = p.tmax; hit = false; sp = 1;
-                active = true;
-                addr = 0;
-                if (p.node_count == 0) finish();          // empty scene: every ray misses
+                q_count = n_valid;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the queue writes land before other lanes read them
+                __builtin_amdgcn_wave_barrier();
             }
         }
 
@@ -293,7 +291,7 @@ void k_trace(TraceParams p)
                 auto place = [&](bool h, int r, uint32_t ref) {
                     if (h && r > 0) {
                         const int e = sp + (nh - 1) - r;
-                        if (e < LDS_N) lds_stack[e * kBlock + tid] = ref; else *gs_slot(e - LDS_N) = ref;
+                        if (e < LDS_N) lds_stack[e * kWave + lane] = ref; else *gs_slot(e - LDS_N) = ref;
                     }
                 };
                 place(h0, r0, c0.w); place(h1, r1, c1.w); place(h2, r2, c2.w); place(h3, r3, c3.w);
@@ -340,41 +338,34 @@ void k_trace(TraceParams p)
           }
         }
     }
-
-    // blocks still held by lanes when the pool ran dry
-    if (has_partial) {
-        atomicAdd(&acc[wave * 64u + slot][0], (unsigned long long)(UNITW && ANYHIT ? nMiss * kUnit : pT));
-        atomicAdd(&acc[wave * 64u + slot][1], (unsigned long long)(UNITW ? nW * kUnit : pW));
-    }
     __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS atomics have landed
 
     // ProcessIntersectionsComputeShader.hlsl:89-90: one surfel per cell per launch, so a plain
     // read-modify-write replaces the 2*spp InterlockedAdds
-    if (lane < nsurf) {
+    if (valid) {
         const float4 d = p.frames[4ull * (wave_first + lane) + 3];
-        if (__float_as_uint(d.z) != 0u) {
-            const long long sT = (long long)acc[tid][0], sW = (long long)acc[tid][1];
-            AobResult* cell = p.results + __float_as_uint(d.x);
-            AobResult c = *cell;
-            if (ACCUM == AOB_ACCUMULATE_QUANTISED) {
-                c.total_bits = (uint32_t)((int32_t)c.total_bits + (int32_t)sT);
-                c.weight_bits = (uint32_t)((int32_t)c.weight_bits + (int32_t)sW);
-            } else {
-                // exact sums, rounded to float once
-                c.total_bits = __float_as_uint(__uint_as_float(c.total_bits) + (float)sT * 2.3283064365386962890625e-10f);
-                c.weight_bits = __float_as_uint(__uint_as_float(c.weight_bits) + (float)sW * 2.3283064365386962890625e-10f);
-            }
-            *cell = c;
+        const long long sT = (long long)acc[lane][0];
+        const long long sW = UNITW ? (long long)p.spp * kUnit : (long long)acc[lane][1];
+        AobResult* cell = p.results + __float_as_uint(d.x);
+        AobResult c = *cell;
+        if (ACCUM == AOB_ACCUMULATE_QUANTISED) {
+            c.total_bits = (uint32_t)((int32_t)c.total_bits + (int32_t)sT);
+            c.weight_bits = (uint32_t)((int32_t)c.weight_bits + (int32_t)sW);
+        } else {
+            // exact sums, rounded to float once
+            c.total_bits = __float_as_uint(__uint_as_float(c.total_bits) + (float)sT * 2.3283064365386962890625e-10f);
+            c.weight_bits = __float_as_uint(__uint_as_float(c.weight_bits) + (float)sW * 2.3283064365386962890625e-10f);
         }
+        *cell = c;
     }
 }
 
 template <int SAMPLER, int ANYHIT, int ACCUM>
 static void launch_stack(int quant, dim3 grid, hipStream_t s, const TraceParams& p)
 {
-    if (quant == 2) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, kLdsStack, 2>), grid, dim3(kBlock), 0, s, p);
-    else if (quant == 1) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, kLdsStack, 1>), grid, dim3(kBlock), 0, s, p);
-    else hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, kLdsStack, 0>), grid, dim3(kBlock), 0, s, p);
+    if (quant == 2) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, kLdsStack, 2>), grid, dim3(kWave), 0, s, p);
+    else if (quant == 1) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, kLdsStack, 1>), grid, dim3(kWave), 0, s, p);
+    else hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, kLdsStack, 0>), grid, dim3(kWave), 0, s, p);
 }
 template <int SAMPLER, int ANYHIT>
 static void launch_acc(int accum, int quant, dim3 grid, hipStream_t s, const TraceParams& p)
@@ -418,10 +409,9 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
         // a lane's stack holds the sentinel plus at most one deferred sibling per tree level
         // (the 4-ary walk defers up to three children per 4-ary level)
         const uint32_t need = (o.bvh_quantised && o.bvh_width == 4) ? 3u * ((b->bvh_depth + 2) / 2) + 2u : b->bvh_depth + 2;
-        // 16 stack entries per lane live in LDS (16 KB + 4 KB of sums per block = 8 blocks per CU);
-        // deeper entries — rare — go to an HBM array.  24 and 32 entries measured 11 % and 23 % slower.
-        const int lds_eff = kLdsStack;
-        const uint32_t overflow = need > (uint32_t)lds_eff ? need - (uint32_t)lds_eff : 0u;
+        // 8 stack entries per lane live in LDS (2 KB + 1 KB of sums + 2 KB of queued rays per wavefront = 32 wavefronts
+        // per CU); deeper entries — rare — go to an HBM array.
+        const uint32_t overflow = need > (uint32_t)kLdsStack ? need - (uint32_t)kLdsStack : 0u;
         TraceParams p;
         p.nodes = (const float4*)b->nodes;
         p.nodesq = b->nodes2q; p.nodes4q = b->nodes4q; p.leaf_tris = b->leaf_tris; p.quant_frame = b->quant_frame;
@@ -432,13 +422,12 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
         p.leaf_base = b->triangle_count ? (uint32_t)(b->triangle_count - 1) : 0u;
         if (quant == 2) p.leaf_base = 0x80000000u;          // 4-ary refs: leaf = 0x80000000 | triangle, inner = node index
         p.spp = o.sample_count;
-        p.block_samples = (o.sample_count + kBlocksPerSurfel - 1) / kBlocksPerSurfel;
         p.seed_hash = host_pcg(o.seed);
         p.tmax = o.ray_tmax;
         if (!o.use_any_hit && o.clamp_tmax_to_falloff && o.falloff_distance < p.tmax) p.tmax = o.falloff_distance;
         p.bias = o.ray_bias; p.falloff = o.falloff_distance;
-        p.refill_idle = max(1, env_int("AOB_TRACE_REFILL_IDLE", 20));
-        p.leaf_wait = max(1, env_int("AOB_TRACE_LEAF_WAIT", 12));
+        p.refill_idle = max(1, env_int("AOB_TRACE_REFILL_IDLE", 12));
+        p.leaf_wait = max(1, env_int("AOB_TRACE_LEAF_WAIT", 16));
         cosine_grid(o.sample_count, p.grid);
         // one launch per section: two sections of a material may cover the same texel, and
         // their contributions are added in section order (BakeEngine.cpp:473,659)
@@ -447,10 +436,10 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
             uint64_t se = m.section_offsets[si + 1] < end ? m.section_offsets[si + 1] : end;
             if (sb >= se) continue;
             p.begin = sb; p.end = se;
-            p.nblocks = (uint32_t)((se - sb + kBlock - 1) / kBlock);
+            p.nblocks = (uint32_t)((se - sb + kWave - 1) / kWave);
             p.blocks_per_xcd = (p.nblocks + 7) / 8;
             dim3 grid(p.blocks_per_xcd * 8);
-            const uint64_t words = (uint64_t)grid.x * kBlock * (overflow ? overflow : 1u);
+            const uint64_t words = (uint64_t)grid.x * kWave * (overflow ? overflow : 1u);
             if (overflow && words > b->gstack_words) {
                 AOB_HIP(hipStreamSynchronize(s));
                 if (b->gstack) AOB_HIP(hipFree(b->gstack));

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Sum the rocprofv3 PMC counters of the k_trace launches under a tools/pmc_passes.sh output directory.
+
+Prints one JSON object: counter name -> value summed over the k_trace dispatches of the pass that
+collected it (one bench step = one launch per section), plus the launch count and kernel name.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def main():
+    root = sys.argv[1]
+    kernel = sys.argv[2] if len(sys.argv) > 2 else "k_trace"
+    out = {"counters": {}, "kernel": None, "launches": {}}
+    for path in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
+        dispatches = set()
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                if kernel not in row["Kernel_Name"]:
+                    continue
+                out["kernel"] = row["Kernel_Name"]
+                name = row["Counter_Name"]
+                out["counters"][name] = out["counters"].get(name, 0.0) + float(row["Counter_Value"])
+                dispatches.add(row["Dispatch_Id"])
+                out["lds_block_size"] = int(row["LDS_Block_Size"])
+                out["vgpr_count"] = int(row["VGPR_Count"])
+                out["scratch_size"] = int(row["Scratch_Size"])
+        out["launches"][os.path.relpath(path, root)] = len(dispatches)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
