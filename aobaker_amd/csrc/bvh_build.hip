@@ -301,16 +301,20 @@ void k_collapse4(uint32_t n, const uint32_t* __restrict__ parent, const uint32_t
     }
 }
 
-// ---- 16-bit quantised BVH2 nodes ------------------------------------------------------------
-// frame: origin = scene min, scale = extent / 65535 nudged up until origin + 65535*scale >= scene max
+// ---- quantised nodes ---------------------------------------------------------------------------
+// Child boxes live on a 15-bit grid over the scene box (cell = extent / 32767; on the 1 M-triangle terrain
+// 0.3 % more node visits than a 16-bit grid), rounded outward.  15 bits because the 4-ary nodes store a
+// plane as 0x8000 | q: the traversal turns those two bytes into the float 1 + q/32768 with ONE v_perm_b32.
+// frame: origin = scene min, scale = extent / 32767 nudged up until origin + 32767*scale >= scene max
+static constexpr float kQuantMax = 32767.0f;
 __global__ void k_quant_frame(const uint32_t* __restrict__ scene_enc, float* __restrict__ frame)
 {
     const int k = threadIdx.x;
     if (k >= 3) return;
     const float smin = dec_float(scene_enc[k]), smax = dec_float(scene_enc[3 + k]);
     const float extent = smax - smin;
-    float scale = extent > 0.0f ? extent / 65535.0f : 0.0f;
-    if (scale > 0.0f) while (fmaf(65535.0f, scale, smin) < smax) scale = __uint_as_float(__float_as_uint(scale) + 1u);
+    float scale = extent > 0.0f ? extent / kQuantMax : 0.0f;
+    if (scale > 0.0f) while (fmaf(kQuantMax, scale, smin) < smax) scale = __uint_as_float(__float_as_uint(scale) + 1u);
     frame[k] = smin; frame[3 + k] = scale;
 }
 
@@ -318,15 +322,15 @@ __global__ void k_quant_frame(const uint32_t* __restrict__ scene_enc, float* __r
 __device__ __forceinline__ uint32_t quant_down(float v, float origin, float scale)
 {
     if (!(scale > 0.0f)) return 0u;
-    float q = fminf(fmaxf(floorf((v - origin) / scale), 0.0f), 65535.0f);
+    float q = fminf(fmaxf(floorf((v - origin) / scale), 0.0f), kQuantMax);
     while (q > 0.0f && fmaf(q, scale, origin) > v) q -= 1.0f;
     return (uint32_t)q;
 }
 __device__ __forceinline__ uint32_t quant_up(float v, float origin, float scale)
 {
     if (!(scale > 0.0f)) return 0u;
-    float q = fminf(fmaxf(ceilf((v - origin) / scale), 0.0f), 65535.0f);
-    while (q < 65535.0f && fmaf(q, scale, origin) < v) q += 1.0f;
+    float q = fminf(fmaxf(ceilf((v - origin) / scale), 0.0f), kQuantMax);
+    while (q < kQuantMax && fmaf(q, scale, origin) < v) q += 1.0f;
     return (uint32_t)q;
 }
 
@@ -351,7 +355,7 @@ void k_emit_nodes_q(uint32_t n, const uint32_t* __restrict__ child_left, const u
     nodesq[2ull * i + 1] = make_uint4(q[7] | q[10] << 16, q[8] | q[11] << 16, l, r);
 }
 
-// quantised form of the 4-ary nodes: child j = {x, y, z words (min | max << 16), ref}
+// quantised form of the 4-ary nodes: child j = {x, y, z words ((0x8000 | min) | (0x8000 | max) << 16), ref}
 __global__ __launch_bounds__(kBlock)
 void k_emit_nodes4q(uint32_t count4, const float4* __restrict__ nodes4, const float* __restrict__ frame, uint4* __restrict__ nodes4q)
 {
@@ -364,9 +368,9 @@ void k_emit_nodes4q(uint32_t count4, const float4* __restrict__ nodes4, const fl
         uint4 o = make_uint4(0u, 0u, 0u, ref);
         // collapsed-away levels keep all-zero records (ref 0 with a zero box is never reached)
         if (ref != 0xffffffffu && !(ref == 0u && lo.x == 0.0f && hi.x == 0.0f && lo.y == 0.0f && hi.y == 0.0f && lo.z == 0.0f && hi.z == 0.0f)) {
-            o.x = quant_down(lo.x, frame[0], frame[3]) | quant_up(hi.x, frame[0], frame[3]) << 16;
-            o.y = quant_down(lo.y, frame[1], frame[4]) | quant_up(hi.y, frame[1], frame[4]) << 16;
-            o.z = quant_down(lo.z, frame[2], frame[5]) | quant_up(hi.z, frame[2], frame[5]) << 16;
+            o.x = 0x80008000u | quant_down(lo.x, frame[0], frame[3]) | quant_up(hi.x, frame[0], frame[3]) << 16;
+            o.y = 0x80008000u | quant_down(lo.y, frame[1], frame[4]) | quant_up(hi.y, frame[1], frame[4]) << 16;
+            o.z = 0x80008000u | quant_down(lo.z, frame[2], frame[5]) | quant_up(hi.z, frame[2], frame[5]) << 16;
         }
         nodes4q[4ull * i + j] = o;
     }

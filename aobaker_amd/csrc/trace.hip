@@ -40,6 +40,7 @@ static constexpr int kWave = 64;                  // threads per workgroup: one 
 static constexpr int kLdsStack = 8;               // traversal stack entries per lane kept in LDS; deeper entries go to HBM
                                                   // (4-ary walk, 1 M-triangle terrain: 96 % of the pushes land in slots 1..7)
 static constexpr uint32_t kInvalid = 0xffffffffu;
+typedef float v2f __attribute__((ext_vector_type(2)));    // a register pair for v_pk_fma_f32
 
 struct TraceParams {
     const float4* nodes;
@@ -57,6 +58,7 @@ struct TraceParams {
     int32_t spp;
     uint32_t seed_hash;
     float tmax, bias, falloff;
+    float inv_tmax;                // 1 / tmax (QUANT 2, any hit: box distances are walked in units of tmax)
     CosineGrid grid;
     uint32_t nblocks, blocks_per_xcd;
     int32_t refill_idle;           // lanes without a ray that trigger the refill section
@@ -103,6 +105,11 @@ void k_trace(TraceParams p)
         q_origin = make_f3(p.quant_frame[0], p.quant_frame[1], p.quant_frame[2]);
         q_scale = make_f3(p.quant_frame[3], p.quant_frame[4], p.quant_frame[5]);
     }
+    if (QUANT == 2) {
+        // the 4-ary nodes hand over a plane q as the float f = 1 + q/32768:  origin + q*scale = (origin - 32768*scale) + f * (32768*scale)
+        q_origin = make_f3(fmaf(-32768.0f, q_scale.x, q_origin.x), fmaf(-32768.0f, q_scale.y, q_origin.y), fmaf(-32768.0f, q_scale.z, q_origin.z));
+        q_scale = make_f3(q_scale.x * 32768.0f, q_scale.y * 32768.0f, q_scale.z * 32768.0f);
+    }
 
     acc[lane][0] = 0ull; acc[lane][1] = 0ull;
     lds_stack[lane] = kInvalid;      // entry 0: the INVALID sentinel (intersect_bvh2_lds.cl:103): a pop is one read
@@ -132,7 +139,8 @@ void k_trace(TraceParams p)
     f3 org, dir, invdir, oxinvdir;
     org = dir = invdir = oxinvdir = make_f3(0.f, 0.f, 0.f);
     float w = 0.0f, closest_t = 0.0f;
-    uint3 rot = make_uint3(0u, 0u, 0u);        // QUANT: 16 for axes the ray travels down, else 0
+    uint3 rot = make_uint3(0u, 0u, 0u);        // QUANT 1: 16 for axes the ray travels down, else 0
+    uint3 nsel = make_uint3(0u, 0u, 0u), fsel = make_uint3(0u, 0u, 0u);   // QUANT 2: v_perm_b32 selectors of the near / far plane
     bool hit = false;
     uint32_t slot = 0;                         // the ray's surfel
     uint32_t addr = kInvalid;
@@ -192,11 +200,24 @@ void k_trace(TraceParams p)
                         w = __uint_as_float(e1.w);
                         org = make_f3(fmaf(dir.x, p.bias, a.x), fmaf(dir.y, p.bias, a.y), fmaf(dir.z, p.bias, a.z));   // GenerateRays:47
                         oxinvdir = make_f3(-org.x * invdir.x, -org.y * invdir.y, -org.z * invdir.z);
+                        if (QUANT == 2) {
+                            // a node word holds (0x8000 | min) | (0x8000 | max) << 16; bytes {0x3f, hi, lo, 0x00} are the float 1 + q/32768.
+                            // The near plane is min for rays that travel up the axis, max for rays that travel down it.
+                            constexpr uint32_t kLow = 0x0701000cu, kHigh = 0x0703020cu;
+                            nsel = make_uint3((e1.x >> 31) ? kHigh : kLow, (e1.y >> 31) ? kHigh : kLow, (e1.z >> 31) ? kHigh : kLow);
+                            fsel = make_uint3(nsel.x ^ (kLow ^ kHigh), nsel.y ^ (kLow ^ kHigh), nsel.z ^ (kLow ^ kHigh));
+                        }
                         if (QUANT) {
                             rot = make_uint3((e1.x >> 31) << 4, (e1.y >> 31) << 4, (e1.z >> 31) << 4);
                             // fold the de-quantisation into the ray: (origin + q*scale - o) * invdir = q*(scale*invdir) + (origin*invdir + oxinvdir)
                             oxinvdir = make_f3(fmaf(q_origin.x, invdir.x, oxinvdir.x), fmaf(q_origin.y, invdir.y, oxinvdir.y), fmaf(q_origin.z, invdir.z, oxinvdir.z));
                             invdir = make_f3(q_scale.x * invdir.x, q_scale.y * invdir.y, q_scale.z * invdir.z);
+                        }
+                        if (QUANT == 2 && ANYHIT) {
+                            // any hit: closest_t stays tmax, so walk the boxes in units of tmax — the clamp of the near
+                            // distance to [0, 1] is then an instruction modifier and the far one needs no clamp at all
+                            invdir = make_f3(invdir.x * p.inv_tmax, invdir.y * p.inv_tmax, invdir.z * p.inv_tmax);
+                            oxinvdir = make_f3(oxinvdir.x * p.inv_tmax, oxinvdir.y * p.inv_tmax, oxinvdir.z * p.inv_tmax);
                         }
                         closest_t = p.tmax; hit = false; sp = 1;
                         active = true;
@@ -261,12 +282,24 @@ void k_trace(TraceParams p)
             const uint4* np = p.nodes4q + 4ull * addr;
             const uint4 c0 = np[0], c1 = np[1], c2 = np[2], c3 = np[3];
             auto slab = [&](const uint4& c, float& tn) -> bool {
-                const uint32_t wx = __builtin_amdgcn_alignbit(c.x, c.x, rot.x), wy = __builtin_amdgcn_alignbit(c.y, c.y, rot.y),
-                               wz = __builtin_amdgcn_alignbit(c.z, c.z, rot.z);
-                tn = fmaxf(fmaxf(fmaxf(fmaf((float)(wx & 0xffffu), invdir.x, oxinvdir.x), fmaf((float)(wy & 0xffffu), invdir.y, oxinvdir.y)),
-                                 fmaf((float)(wz & 0xffffu), invdir.z, oxinvdir.z)), 0.0f);
-                const float tf = fminf(fminf(fminf(fmaf((float)(wx >> 16), invdir.x, oxinvdir.x), fmaf((float)(wy >> 16), invdir.y, oxinvdir.y)),
-                                             fmaf((float)(wz >> 16), invdir.z, oxinvdir.z)), closest_t);
+                // two v_perm_b32 and one v_pk_fma_f32 per axis: (t_near, t_far) = (f_near, f_far) * invdir + oxinvdir
+                constexpr uint32_t kHalf = 0x3f000000u;
+                const v2f fx = { __uint_as_float(__builtin_amdgcn_perm(kHalf, c.x, nsel.x)), __uint_as_float(__builtin_amdgcn_perm(kHalf, c.x, fsel.x)) };
+                const v2f fy = { __uint_as_float(__builtin_amdgcn_perm(kHalf, c.y, nsel.y)), __uint_as_float(__builtin_amdgcn_perm(kHalf, c.y, fsel.y)) };
+                const v2f fz = { __uint_as_float(__builtin_amdgcn_perm(kHalf, c.z, nsel.z)), __uint_as_float(__builtin_amdgcn_perm(kHalf, c.z, fsel.z)) };
+                const v2f tx = __builtin_elementwise_fma(fx, (v2f){ invdir.x, invdir.x }, (v2f){ oxinvdir.x, oxinvdir.x });
+                const v2f ty = __builtin_elementwise_fma(fy, (v2f){ invdir.y, invdir.y }, (v2f){ oxinvdir.y, oxinvdir.y });
+                const v2f tz = __builtin_elementwise_fma(fz, (v2f){ invdir.z, invdir.z }, (v2f){ oxinvdir.z, oxinvdir.z });
+                float tf;
+                if (ANYHIT) {
+                    // distances in units of tmax: the ray's span is [0, 1].  A box wholly beyond 1 passes (its near distance
+                    // clamps to 1 <= far) — harmless, the triangle test has the last word (traverse4q in the oracle does the same)
+                    tn = fminf(fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0f), 1.0f);
+                    tf = fminf(fminf(tx.y, ty.y), tz.y);
+                } else {
+                    tn = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0f);
+                    tf = fminf(fminf(fminf(tx.y, ty.y), tz.y), closest_t);
+                }
                 return tn <= tf && c.w != kInvalid;            // an empty slot is excluded by its ref
             };
             float k0, k1, k2, k3;
@@ -425,8 +458,9 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
         p.seed_hash = host_pcg(o.seed);
         p.tmax = o.ray_tmax;
         if (!o.use_any_hit && o.clamp_tmax_to_falloff && o.falloff_distance < p.tmax) p.tmax = o.falloff_distance;
+        p.inv_tmax = 1.0f / p.tmax;
         p.bias = o.ray_bias; p.falloff = o.falloff_distance;
-        p.refill_idle = max(1, env_int("AOB_TRACE_REFILL_IDLE", 12));
+        p.refill_idle = max(1, env_int("AOB_TRACE_REFILL_IDLE", 16));
         p.leaf_wait = max(1, env_int("AOB_TRACE_LEAF_WAIT", 16));
         cosine_grid(o.sample_count, p.grid);
         // one launch per section: two sections of a material may cover the same texel, and

@@ -11,7 +11,7 @@ N x 2048^2 texels (N=4 is configs[3]'s 4096^2) and each rank traces an equal str
 
 The JSON line also carries
   roofline     the trace kernel against HBM peak, ALGORITHMIC bytes:
-               B_ray = node_packet*n_inner + 48*n_leaf + 1032/spp, node visits counted by the CPU oracle on
+               B_ray = node_packet*n_inner + 48*n_leaf + 64 + 8/spp, node visits counted by the CPU oracle on
                a texel subsample of the same rays; kernel time from HIP events on the library's
                own stream.  frac can exceed 1: every node visit is counted as memory traffic
                although most are served by L1/L2/Infinity Cache — `traffic` is what reaches HBM.
@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--grid", type=int, default=708, help="terrain grid (708 -> 999 698 triangles)")
     ap.add_argument("--bvh-width", type=int, default=0, help="0 = library default (4), 2 = BVH2 nodes, 4 = 4-ary nodes")
-    ap.add_argument("--bvh-quantised", type=int, default=-1, help="-1 = library default (1); 1 = 16-bit quantised boxes, lane per ray; 0 = fp32 boxes")
+    ap.add_argument("--bvh-quantised", type=int, default=-1, help="-1 = library default (1); 1 = 15-bit quantised boxes, lane per ray; 0 = fp32 boxes")
     ap.add_argument("--bvh-builder", type=int, default=-1, help="-1 = library default; 0 = LBVH, 1 = PLOC")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -145,10 +145,11 @@ def main():
         n_visits = n_inner + n_leaf
         # bytes one ray asks of the memory system (with this build's packet sizes):
         # inner-node packet (64 B fp32 BVH2 / 32 B quantised BVH2 / 128 B fp32 4-ary / 64 B quantised 4-ary), 48 B per leaf
-        # triangle, plus per surfel 16 sample blocks x 64 B trace record and the 8 B result cell
+        # triangle, plus per ray 64 B of its surfel's frame (48 B when the sample is generated, 16 B when it is
+        # taken off the wavefront's queue) and per surfel the 8 B result cell
         inner_bytes = ((64.0 if opts.bvh_quantised else 128.0) if opts.bvh_width == 4
                        else (32.0 if opts.bvh_quantised else 64.0))
-        b_ray = inner_bytes * n_inner + 48.0 * n_leaf + (16 * 64.0 + 8.0) / args.spp
+        b_ray = inner_bytes * n_inner + 48.0 * n_leaf + 64.0 + 8.0 / args.spp
         achieved = my_rays * b_ray / (kernel_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(),

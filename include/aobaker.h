@@ -66,7 +66,7 @@ typedef struct AobOptions {
                                      (quantised: one lane per ray); 0 = 2.  Default 4             */
     int32_t  bvh_quantised;       /* default 1.  With bvh_width 4: 1 = lane-per-ray walk of AobBvh4QNode,
                                      0 = quad-per-ray walk of the fp32 AobBvh4Node.  With bvh_width 2:  0: 64-byte fp32 nodes (the reference layout);
-                                     1: 32-byte nodes, child boxes as 16-bit fixed point on the scene
+                                     1: 32-byte nodes, child boxes as 15-bit fixed point on the scene
                                      box, rounded outward (AobBvh2QNode)                            */
     int32_t  bvh_builder;         /* 0: LBVH, the reference stack's GPU builder (kernels/CL/build_hlbvh.cl);
                                      1: PLOC (locally-ordered agglomerative clustering over the same Morton
@@ -164,16 +164,19 @@ typedef struct AobBvhNode {
  * The two 64-byte halves are what the four lanes of a ray's quad fetch with one access each. */
 typedef struct AobBvh4Node { float lo[4][4]; float hi[4][4]; } AobBvh4Node;
 #define AOB_LEAF_FLAG 0x80000000u
-/* 32 B BVH2 node with quantised child boxes: q = 16-bit fixed point on the scene box,
- * box.min rounded down, box.max rounded up; decode: frame.origin + q * frame.scale.
+/* 32 B BVH2 node with quantised child boxes: q = 15-bit fixed point on the scene box (0..32767,
+ * scale = extent / 32767), box.min rounded down, box.max rounded up; decode: frame.origin + q * frame.scale.
  * One word per axis and box, min in the low half: w0 = lmin.x | lmax.x<<16, w1 = lmin.y | lmax.y<<16,
  * w2 = lmin.z | lmax.z<<16, w3..w5 the same for the right child, w6 = addr_left, w7 = addr_right.  Inner nodes only ([0, n-1)); a child address >= n-1 is leaf
  * triangle (address - (n-1)) of AobLeafTri[].  Two 16-byte fetches per visit instead of four. */
 typedef struct AobBvh2QNode { uint32_t w[8]; } AobBvh2QNode;
 typedef struct AobQuantFrame { float origin[3]; float scale[3]; } AobQuantFrame;
 /* 64 B 4-ary node with quantised child boxes (same grid and rounding as AobBvh2QNode): child j is
- * w[4j..4j+2] = x, y, z words (min | max<<16) and w[4j+3] = ref_j (as in AobBvh4Node); an empty
- * slot has ref = AOB_INVALID_ADDR.  Walked one lane per ray (bvh_width 4, bvh_quantised 1). */
+ * w[4j..4j+2] = x, y, z words and w[4j+3] = ref_j (as in AobBvh4Node); an empty slot has
+ * ref = AOB_INVALID_ADDR and zero words.  A word is (0x8000 | min) | (0x8000 | max) << 16: bit 15 of each
+ * half is set so that the bytes {0x3f, half>>8, half&0xff, 0x00} are the IEEE float 1 + q/32768 — one
+ * v_perm_b32 per plane in the traversal; decode q = half & 0x7fff.  Walked one lane per ray
+ * (bvh_width 4, bvh_quantised 1). */
 typedef struct AobBvh4QNode { uint32_t w[16]; } AobBvh4QNode;
 /* 48 B leaf triangle in Morton order: v0.w = shape id bits, v1.w = prim id bits. */
 typedef struct AobLeafTri { float v0[4], v1[4], v2[4]; } AobLeafTri;

@@ -766,22 +766,24 @@ uint64_t orc_bvh4_build(const AobBvhNode* nodes2, uint64_t node_count2, AobBvh4N
 
 #define ORC_STACK 128
 
-/* ---- 16-bit quantised BVH2 nodes (AobBvh2QNode) ----------------------------------------- */
-/* frame: origin = scene min, scale = extent/65535 nudged up until origin + 65535*scale >= max;
+/* ---- quantised BVH2 nodes (AobBvh2QNode) ------------------------------------------------- */
+/* A 15-bit grid (the 4-ary nodes keep the 16th bit of each plane set, see orc_bvh4q_build).
+ * frame: origin = scene min, scale = extent/32767 nudged up until origin + 32767*scale >= max;
  * child box min rounded down, max rounded up on that grid (so the decoded box contains the fp32
  * box).  The scene box is the union of the root's two child boxes. */
+#define ORC_QUANT_MAX 32767.0f
 static inline uint32_t quant_down(float v, float origin, float scale)
 {
     if (!(scale > 0.0f)) return 0u;
-    float q = fminf(fmaxf(floorf((v - origin) / scale), 0.0f), 65535.0f);
+    float q = fminf(fmaxf(floorf((v - origin) / scale), 0.0f), ORC_QUANT_MAX);
     while (q > 0.0f && fmaf(q, scale, origin) > v) q -= 1.0f;
     return (uint32_t)q;
 }
 static inline uint32_t quant_up(float v, float origin, float scale)
 {
     if (!(scale > 0.0f)) return 0u;
-    float q = fminf(fmaxf(ceilf((v - origin) / scale), 0.0f), 65535.0f);
-    while (q < 65535.0f && fmaf(q, scale, origin) < v) q += 1.0f;
+    float q = fminf(fmaxf(ceilf((v - origin) / scale), 0.0f), ORC_QUANT_MAX);
+    while (q < ORC_QUANT_MAX && fmaf(q, scale, origin) < v) q += 1.0f;
     return (uint32_t)q;
 }
 
@@ -801,8 +803,8 @@ uint64_t orc_bvh2q_build(const AobBvhNode* nodes2, uint64_t node_count2, AobBvh2
             smax[k] = fmaxf(root->lmax_or_v1[k], root->rmax[k]);
         }
         float extent = smax[k] - smin[k];
-        float scale = extent > 0.0f ? extent / 65535.0f : 0.0f;
-        if (scale > 0.0f) while (fmaf(65535.0f, scale, smin[k]) < smax[k]) { uint32_t u; memcpy(&u, &scale, 4); u++; memcpy(&scale, &u, 4); }
+        float scale = extent > 0.0f ? extent / ORC_QUANT_MAX : 0.0f;
+        if (scale > 0.0f) while (fmaf(ORC_QUANT_MAX, scale, smin[k]) < smax[k]) { uint32_t u; memcpy(&u, &scale, 4); u++; memcpy(&scale, &u, 4); }
         frame->origin[k] = smin[k]; frame->scale[k] = scale;
     }
     for (uint64_t i = 0; i + 1 < n; i++) {
@@ -878,7 +880,8 @@ static inline int traverse2q(const AobBvh2QNode* nq, uint64_t n, const AobQuantF
     return hit;
 }
 
-/* Quantised 4-ary nodes (AobBvh4QNode): the boxes of orc_bvh4_build on the grid of orc_bvh2q_build. */
+/* Quantised 4-ary nodes (AobBvh4QNode): the boxes of orc_bvh4_build on the grid of orc_bvh2q_build.  A plane q is
+ * stored as 0x8000 | q: with 0x3f above and 0x00 below, those two bytes are the float 1 + q/32768 (plane_float). */
 uint64_t orc_bvh4q_build(const AobBvh4Node* nodes4, uint64_t count4, const AobQuantFrame* fr, AobBvh4QNode* out)
 {
     for (uint64_t i = 0; i < count4; i++) {
@@ -890,7 +893,7 @@ uint64_t orc_bvh4q_build(const AobBvh4Node* nodes4, uint64_t count4, const AobQu
             if (ref == AOB_INVALID_ADDR) continue;
             if (ref == 0 && lo[0] == 0.0f && hi[0] == 0.0f && lo[1] == 0.0f && hi[1] == 0.0f && lo[2] == 0.0f && hi[2] == 0.0f) continue;
             for (int k = 0; k < 3; k++)
-                w[k] = quant_down(lo[k], fr->origin[k], fr->scale[k]) | quant_up(hi[k], fr->origin[k], fr->scale[k]) << 16;
+                w[k] = 0x80008000u | quant_down(lo[k], fr->origin[k], fr->scale[k]) | quant_up(hi[k], fr->origin[k], fr->scale[k]) << 16;
         }
     }
     return count4;
@@ -898,15 +901,40 @@ uint64_t orc_bvh4q_build(const AobBvh4Node* nodes4, uint64_t count4, const AobQu
 
 #define ORC_STACK4 512
 
-/* traverse4 on the quantised boxes (frame folded into the ray as in traverse2q). */
+/* bytes {0x3f, hi, lo, 0x00}: what one v_perm_b32 makes of a stored plane */
+static inline float plane_float(uint32_t half) { uint32_t u = 0x3f000000u | (half & 0xffffu) << 8; float f; memcpy(&f, &u, 4); return f; }
+/* v_max3_f32 / v_min3_f32: NaN operands are ignored */
+static inline float max3n(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+static inline float min3n(float a, float b, float c) { return fminf(fminf(a, b), c); }
+
+/* traverse4 on the quantised boxes, with the arithmetic of the HIP kernel (trace.hip, QUANT 2):
+ *   - a stored plane becomes f = 1 + q/32768, so the frame folded into the ray is origin - 32768*scale and 32768*scale:
+ *     t = f*fa + fb with fa = scale2*invdir, fb = origin2*invdir + oxinvdir;
+ *   - the near plane of an axis is min for rays that travel up it and max for rays that travel down it (the sign of 1/dir);
+ *   - any hit: closest_t never moves off t_max, so fa and fb are scaled by 1/t_max and the near distance is clamped to
+ *     [0, 1] (NaN -> 0, the clamp modifier of v_max3_f32); the far distance is not clamped — a box wholly beyond t_max
+ *     passes, which is harmless because the triangle test has the last word;
+ *   - closest hit: intersect_bvh2_lds.cl:54-63 as before, near clamped at 0 and far at closest_t. */
 static inline int traverse4q(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const AobLeafTri* tris,
                              f3 o, f3 d, float t_max, int any_hit, float* t_out, OrcTraceStats* st, int* error)
 {
     if (count4 == 0) { *t_out = t_max; return 0; }
     f3 invdir = safe_invdir(d);
     f3 oxinvdir = f3_make(-o.x * invdir.x, -o.y * invdir.y, -o.z * invdir.z);
-    f3 fb = f3_make(fmaf(fr->origin[0], invdir.x, oxinvdir.x), fmaf(fr->origin[1], invdir.y, oxinvdir.y), fmaf(fr->origin[2], invdir.z, oxinvdir.z));
-    f3 fa = f3_make(fr->scale[0] * invdir.x, fr->scale[1] * invdir.y, fr->scale[2] * invdir.z);
+    const float inv[3] = { invdir.x, invdir.y, invdir.z };
+    const float oxi[3] = { oxinvdir.x, oxinvdir.y, oxinvdir.z };
+    const float inv_tmax = 1.0f / t_max;
+    float fa[3], fb[3];
+    int down[3];
+    for (int k = 0; k < 3; k++) {
+        const float origin2 = fmaf(-32768.0f, fr->scale[k], fr->origin[k]);
+        const float scale2 = fr->scale[k] * 32768.0f;
+        fb[k] = fmaf(origin2, inv[k], oxi[k]);
+        fa[k] = scale2 * inv[k];
+        if (any_hit) { fa[k] = fa[k] * inv_tmax; fb[k] = fb[k] * inv_tmax; }
+        uint32_t bits; memcpy(&bits, &inv[k], 4);
+        down[k] = (int)(bits >> 31);
+    }
     float closest_t = t_max;
     int hit = 0;
     uint32_t stack[ORC_STACK4];
@@ -920,10 +948,15 @@ static inline int traverse4q(const AobBvh4QNode* nq, uint64_t count4, const AobQ
             float key[4]; uint32_t ref[4]; int chit[4], nhit = 0;
             for (int j = 0; j < 4; j++) {
                 const uint32_t* c = &w[4 * j];
-                const float qmin[3] = { (float)(c[0] & 0xffffu), (float)(c[1] & 0xffffu), (float)(c[2] & 0xffffu) };
-                const float qmax[3] = { (float)(c[0] >> 16), (float)(c[1] >> 16), (float)(c[2] >> 16) };
-                float t0, t1;
-                intersect_bbox(qmin, qmax, fa, fb, closest_t, &t0, &t1);
+                float tn[3], tf[3];
+                for (int k = 0; k < 3; k++) {
+                    const uint32_t nearh = down[k] ? c[k] >> 16 : c[k] & 0xffffu, farh = down[k] ? c[k] & 0xffffu : c[k] >> 16;
+                    tn[k] = fmaf(plane_float(nearh), fa[k], fb[k]);
+                    tf[k] = fmaf(plane_float(farh), fa[k], fb[k]);
+                }
+                float t0 = max3n(tn[0], tn[1], tn[2]), t1 = min3n(tf[0], tf[1], tf[2]);
+                if (any_hit) t0 = t0 != t0 ? 0.0f : fminf(fmaxf(t0, 0.0f), 1.0f);
+                else { t0 = fmaxf(t0, 0.0f); t1 = fminf(t1, closest_t); }
                 ref[j] = c[3];
                 chit[j] = t0 <= t1 && ref[j] != AOB_INVALID_ADDR;
                 key[j] = chit[j] ? t0 : INFINITY;
@@ -932,6 +965,9 @@ static inline int traverse4q(const AobBvh4QNode* nq, uint64_t count4, const AobQ
             if (nhit == 0) { node = stack[--sp]; continue; }
             if (sp + nhit - 1 > ORC_STACK4) { *error = AOB_ERR_BVH_TOO_DEEP; *t_out = t_max; return 0; }
             uint32_t first = AOB_INVALID_ADDR;
+            /* any hit: the answer does not depend on the order — the kernel follows the first hit child and defers the rest
+             * in index order; closest hit: nearest first, the others deferred farthest first, ties by child index */
+            if (any_hit) for (int j = 0; j < 4; j++) key[j] = chit[j] ? (float)j : INFINITY;
             for (int j = 0; j < 4; j++) {
                 if (!chit[j]) continue;
                 int rank = 0;

@@ -69,11 +69,21 @@ def test_bvh4_nodes_bit_exact(engine, orc, name):
     # and their quantised form (AobBvh4QNode) on the AobBvh2QNode grid
     _, frame = orc.bvh2q_build(ref2)
     assert np.array_equal(got4q, orc.bvh4q_build(ref4, frame))
+    # a plane is stored as 0x8000 | q (the bytes of the float 1 + q/32768); the decoded boxes contain the fp32 boxes
+    w = got4q.reshape(-1, 4, 4)
+    refs = w[:, :, 3]
+    used = (refs != capi.INVALID_ADDR) & ~((refs == 0) & (w[:, :, :3] == 0).all(axis=2))
+    assert ((w[:, :, :3][used] & 0x80008000) == 0x80008000).all()
+    assert (w[:, :, :3][~used] == 0).all()
+    f64 = frame.astype(np.float64)
+    lo = (f64[:3] + (w[:, :, :3] & 0x7fff).astype(np.float64) * f64[3:]).astype(np.float32)
+    hi = (f64[:3] + ((w[:, :, :3] >> 16) & 0x7fff).astype(np.float64) * f64[3:]).astype(np.float32)
+    assert (lo[used] <= got4["lo"][:, :, :3][used]).all() and (hi[used] >= got4["hi"][:, :, :3][used]).all()
 
 
 @pytest.mark.parametrize("name", ["cube", "two_section", "sphere", "terrain", "floor_wall", "plane"])
 def test_quantised_bvh2_nodes_bit_exact(engine, orc, name):
-    """AobBvh2QNode[]: 16-bit child boxes on the scene grid, rounded outward, plus the frame."""
+    """AobBvh2QNode[]: 15-bit child boxes on the scene grid, rounded outward, plus the frame."""
     flat = FlatScene(SCENES[name]())
     ref2, _ = orc.bvh_build(orc.scene_triangles(flat.desc))
     refq, ref_frame = orc.bvh2q_build(ref2)
