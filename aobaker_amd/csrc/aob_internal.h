@@ -97,6 +97,8 @@ struct AobBake {
     uint32_t* pinned = nullptr;         // 64 B of pinned host memory for small read-backs
 
     uint32_t* gstack = nullptr;         // traversal stacks in HBM, only for trees deeper than 62 levels
+    uint32_t* trace_unit_next = nullptr; // [8] per-XCD work queue heads of the trace launch
+    int cu_count = 256;
     uint64_t gstack_words = 0;
 
     float* hemisphere = nullptr;        // compat sampler table (float3 packed)

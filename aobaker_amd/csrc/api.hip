@@ -90,7 +90,7 @@ static void free_bake(AobBake* b)
     hipFree(b->codes[0]); hipFree(b->codes[1]); hipFree(b->prim_idx[0]); hipFree(b->prim_idx[1]);
     hipFree(b->sort_temp); hipFree(b->child_left); hipFree(b->child_right); hipFree(b->parent);
     hipFree(b->node_bounds); hipFree(b->refit_flags); hipFree(b->depth_dev); hipFree(b->ploc_sums); hipFree(b->ploc_totals); hipFree(b->nodes); hipFree(b->nodes4); hipFree(b->leaf_tris); hipFree(b->nodes2q); hipFree(b->nodes4q); hipFree(b->quant_frame);
-    hipFree(b->hemisphere); hipFree(b->gstack);
+    hipFree(b->hemisphere); hipFree(b->gstack); hipFree(b->trace_unit_next);
     if (b->pinned) hipHostFree(b->pinned);
     for (auto& e : b->ev) if (e) hipEventDestroy(e);
     for (auto& e : b->ev_trace) if (e) hipEventDestroy(e);
@@ -211,6 +211,8 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
     for (auto& e : b->ev) AOB_CH(hipEventCreate(&e));
     for (auto& e : b->ev_trace) AOB_CH(hipEventCreate(&e));
     AOB_CH(hipHostMalloc((void**)&b->pinned, 64));
+    AOB_CH(hipMalloc((void**)&b->trace_unit_next, 8 * sizeof(uint32_t)));
+    AOB_CH(hipDeviceGetAttribute(&b->cu_count, hipDeviceAttributeMultiprocessorCount, g_device));
     AOB_CH(hipEventRecord(b->ev[0], b->stream));
 
     // S1 upload (BakeEngine.cpp:370-398): de-interleave the strided vertex attributes
