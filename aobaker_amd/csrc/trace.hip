@@ -38,6 +38,7 @@ namespace aob {
 
 static constexpr int kWave = 64;                  // threads per workgroup: one wavefront
 static constexpr int kLdsStack = 8;               // traversal stack entries per lane kept in LDS; deeper entries go to HBM
+static constexpr int kLdsStackCount = 11;         // ... when the sums are 4-byte miss counters (unit weights, any hit): the same 5 KB
                                                   // (4-ary walk, 1 M-triangle terrain: 96 % of the pushes land in slots 1..7)
 static constexpr uint32_t kInvalid = 0xffffffffu;
 typedef float v2f __attribute__((ext_vector_type(2)));    // a register pair for v_pk_fma_f32
@@ -97,7 +98,11 @@ void k_trace(TraceParams p)
 {
     // 5 KB per wavefront: 32 wavefronts per CU fill its 160 KB
     __shared__ uint32_t lds_stack[LDS_N * kWave];
-    __shared__ unsigned long long acc[kWave][2];        // per surfel: total, weight
+    // per surfel: total, weight as 64-bit sums — or, with unit weights and any-hit scoring, one 32-bit count of the
+    // unoccluded samples (the weight sum is the sample count); the 768 B saved hold three more stack entries per lane
+    constexpr bool COUNT32 = SAMPLER == AOB_SAMPLER_COSINE && ANYHIT;
+    __shared__ unsigned long long acc[COUNT32 ? 1 : kWave][2];
+    __shared__ uint32_t miss_count[COUNT32 ? kWave : 1];
     __shared__ uint4 queue[kWave * 2];                  // ray queue: {dir.xyz, slot}, {1/dir.xyz, weight}
 
     const uint32_t lane = threadIdx.x;
@@ -152,7 +157,8 @@ void k_trace(TraceParams p)
     const uint64_t wave_first = p.begin + (uint64_t)tile * kWave;            // first surfel of this unit
     const uint32_t nsurf = (uint32_t)min((uint64_t)kWave, p.end - wave_first);
 
-    acc[lane][0] = 0ull; acc[lane][1] = 0ull;
+    if (COUNT32) miss_count[lane] = 0u;
+    else { acc[lane][0] = 0ull; acc[lane][1] = 0ull; }
     lds_stack[lane] = kInvalid;      // entry 0: the INVALID sentinel (intersect_bvh2_lds.cl:103): a pop is one read
 
 
@@ -205,7 +211,7 @@ void k_trace(TraceParams p)
             // r is 0 or 1: the sample adds its weight to the weight sum and, if unoccluded, to the total
             // ((1.0f * w) * 255.0f == w * 255.0f exactly).  Unit weights: the weight sum is the sample count (epilogue).
             if (UNITW) {
-                if (!hit) atomicAdd(&acc[slot][0], (unsigned long long)kUnit);
+                if (!hit) atomicAdd(&miss_count[slot], 1u);
             } else {
                 const long long cW = ACCUM == AOB_ACCUMULATE_QUANTISED ? (long long)ftoi(w * 255.0f) : f2fix(w);
                 atomicAdd(&acc[slot][1], (unsigned long long)cW);
@@ -420,7 +426,7 @@ void k_trace(TraceParams p)
     // hold whole numbers (unit weights, any hit: misses and samples counted), see kSplitExact.
     if (valid) {
         const float4 d = p.frames[4ull * (wave_first + lane) + 3];
-        const long long sT = (long long)acc[lane][0];
+        const long long sT = COUNT32 ? (long long)miss_count[lane] * kUnit : (long long)acc[lane][0];
         const long long sW = UNITW ? (long long)(gen_end - gen_begin) * kUnit : (long long)acc[lane][1];
         AobResult* cell = p.results + __float_as_uint(d.x);
         if (p.parts > 1u) {
@@ -447,12 +453,15 @@ void k_trace(TraceParams p)
   }   // next unit
 }
 
+constexpr int lds_stack_entries(int sampler, int anyhit) { return sampler == AOB_SAMPLER_COSINE && anyhit ? kLdsStackCount : kLdsStack; }
+
 template <int SAMPLER, int ANYHIT, int ACCUM>
 static void launch_stack(int quant, dim3 grid, hipStream_t s, const TraceParams& p)
 {
-    if (quant == 2) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, kLdsStack, 2>), grid, dim3(kWave), 0, s, p);
-    else if (quant == 1) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, kLdsStack, 1>), grid, dim3(kWave), 0, s, p);
-    else hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, kLdsStack, 0>), grid, dim3(kWave), 0, s, p);
+    constexpr int N = lds_stack_entries(SAMPLER, ANYHIT);
+    if (quant == 2) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 2>), grid, dim3(kWave), 0, s, p);
+    else if (quant == 1) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 1>), grid, dim3(kWave), 0, s, p);
+    else hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 0>), grid, dim3(kWave), 0, s, p);
 }
 template <int SAMPLER, int ANYHIT>
 static void launch_acc(int accum, int quant, dim3 grid, hipStream_t s, const TraceParams& p)
@@ -496,9 +505,10 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
         // a lane's stack holds the sentinel plus at most one deferred sibling per tree level
         // (the 4-ary walk defers up to three children per 4-ary level)
         const uint32_t need = (o.bvh_quantised && o.bvh_width == 4) ? 3u * ((b->bvh_depth + 2) / 2) + 2u : b->bvh_depth + 2;
-        // 8 stack entries per lane live in LDS (2 KB + 1 KB of sums + 2 KB of queued rays per wavefront = 32 wavefronts
-        // per CU); deeper entries — rare — go to an HBM array.
-        const uint32_t overflow = need > (uint32_t)kLdsStack ? need - (uint32_t)kLdsStack : 0u;
+        // 8 or 11 stack entries per lane live in LDS (2 KB + 1 KB of sums, or 2.75 KB + 256 B of counters, + 2 KB of queued
+        // rays per wavefront = 32 wavefronts per CU); deeper entries — rare — go to an HBM array.
+        const uint32_t in_lds = (uint32_t)lds_stack_entries(o.sampler, o.use_any_hit);
+        const uint32_t overflow = need > in_lds ? need - in_lds : 0u;
         TraceParams p;
         p.nodes = (const float4*)b->nodes;
         p.nodesq = b->nodes2q; p.nodes4q = b->nodes4q; p.leaf_tris = b->leaf_tris; p.quant_frame = b->quant_frame;
