@@ -524,8 +524,8 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
         if (!o.use_any_hit && o.clamp_tmax_to_falloff && o.falloff_distance < p.tmax) p.tmax = o.falloff_distance;
         p.inv_tmax = 1.0f / p.tmax;
         p.bias = o.ray_bias; p.falloff = o.falloff_distance;
-        p.refill_idle = max(1, env_int("AOB_TRACE_REFILL_IDLE", 16));
-        p.leaf_wait = max(1, env_int("AOB_TRACE_LEAF_WAIT", 16));
+        p.refill_idle = max(1, env_int("AOB_TRACE_REFILL_IDLE", 24));
+        p.leaf_wait = max(1, env_int("AOB_TRACE_LEAF_WAIT", 12));
         cosine_grid(o.sample_count, p.grid);
         // one launch per section: two sections of a material may cover the same texel, and
         // their contributions are added in section order (BakeEngine.cpp:473,659)
