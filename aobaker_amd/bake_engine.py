@@ -99,7 +99,7 @@ class Baker:
 
     def nodes4q(self) -> np.ndarray:
         n = C.c_uint64()
-        capi.check(self.lib.aob_bake_node4_count(self.handle, C.byref(n)))
+        capi.check(self.lib.aob_bake_node4q_count(self.handle, C.byref(n)))
         out = np.zeros((max(n.value, 1), 16), dtype=np.uint32)
         capi.check(self.lib.aob_bake_copy_nodes4q(self.handle, out.ctypes.data, n.value))
         return out[:n.value]

@@ -88,7 +88,10 @@ struct AobBake {
     float4*   nodes4 = nullptr;         // 8 x float4 per 4-ary node (AobBvh4Node), indexed by BVH2 inner index
     float4*   leaf_tris = nullptr;      // 3 x float4 per triangle in Morton order (AobLeafTri)
     uint64_t  node4_count = 0;
-    uint4*    nodes4q = nullptr;        // 4 x uint4 per quantised 4-ary node (AobBvh4QNode)
+    uint4*    nodes4q = nullptr;        // 4 x uint4 per quantised 4-ary node (AobBvh4QNode), packed
+    uint32_t* packed_index = nullptr;   // BVH2 inner-node index -> index in nodes4q
+    uint32_t* node4q_count_dev = nullptr;
+    uint64_t  node4q_count = 0;         // UINT64_MAX: not read back yet
     uint4*    nodes2q = nullptr;        // 2 x uint4 per quantised BVH2 node (AobBvh2QNode)
     float*    quant_frame = nullptr;    // origin[3], scale[3] (device)
     uint64_t node_count = 0;

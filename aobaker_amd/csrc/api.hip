@@ -89,7 +89,7 @@ static void free_bake(AobBake* b)
     hipFree(b->tri_verts); hipFree(b->prim_bounds); hipFree(b->scene_bounds_enc);
     hipFree(b->codes[0]); hipFree(b->codes[1]); hipFree(b->prim_idx[0]); hipFree(b->prim_idx[1]);
     hipFree(b->sort_temp); hipFree(b->child_left); hipFree(b->child_right); hipFree(b->parent);
-    hipFree(b->node_bounds); hipFree(b->refit_flags); hipFree(b->depth_dev); hipFree(b->ploc_sums); hipFree(b->ploc_totals); hipFree(b->nodes); hipFree(b->nodes4); hipFree(b->leaf_tris); hipFree(b->nodes2q); hipFree(b->nodes4q); hipFree(b->quant_frame);
+    hipFree(b->node_bounds); hipFree(b->refit_flags); hipFree(b->depth_dev); hipFree(b->ploc_sums); hipFree(b->ploc_totals); hipFree(b->nodes); hipFree(b->nodes4); hipFree(b->leaf_tris); hipFree(b->nodes2q); hipFree(b->nodes4q); hipFree(b->packed_index); hipFree(b->node4q_count_dev); hipFree(b->quant_frame);
     hipFree(b->hemisphere); hipFree(b->gstack); hipFree(b->trace_unit_next);
     if (b->pinned) hipHostFree(b->pinned);
     for (auto& e : b->ev) if (e) hipEventDestroy(e);
@@ -269,11 +269,16 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
     AOB_C(dev_alloc(&b->leaf_tris, 3 * n));
     AOB_C(dev_alloc(&b->nodes2q, 2 * n));
     AOB_C(dev_alloc(&b->nodes4q, 4 * n));
+    AOB_C(dev_alloc(&b->packed_index, n));
+    AOB_C(dev_alloc(&b->node4q_count_dev, 1));
     AOB_C(dev_alloc(&b->quant_frame, 8));
     if (n) {
         size_t temp = 0;
         AOB_CH(rocprim::radix_sort_pairs(nullptr, temp, b->codes[0], b->codes[1], b->prim_idx[0], b->prim_idx[1],
                                          (size_t)n, 0u, 63u, b->stream));
+        size_t temp_scan = 0;
+        AOB_CH(rocprim::exclusive_scan(nullptr, temp_scan, b->refit_flags, b->packed_index, 0u, (size_t)n, rocprim::plus<uint32_t>(), b->stream));
+        if (temp_scan > temp) temp = temp_scan;
         b->sort_temp_bytes = temp;
         AOB_CH(hipMalloc(&b->sort_temp, temp ? temp : 1));
     }
@@ -495,11 +500,33 @@ int aob_bake_copy_nodes2q(AobBake* b, AobBvh2QNode* dst, uint64_t capacity)
     return AOB_OK;
 }
 
+static int node4q_count(AobBake* b, uint64_t* count)
+{
+    if (!b->bvh_built || b->triangle_count == 0) { *count = 0; return AOB_OK; }
+    if (b->node4q_count == UINT64_MAX) {
+        uint32_t c = 0;
+        AOB_HIP(hipMemcpyAsync(&c, b->node4q_count_dev, sizeof c, hipMemcpyDeviceToHost, b->stream));
+        AOB_HIP(hipStreamSynchronize(b->stream));
+        b->node4q_count = c;
+    }
+    *count = b->node4q_count;
+    return AOB_OK;
+}
+
+int aob_bake_node4q_count(AobBake* b, uint64_t* count)
+{
+    AOB_TRY(check_bake(b, 0, false));
+    if (!count) { set_error("count is null"); return AOB_ERR_INVALID_ARGUMENT; }
+    return node4q_count(b, count);
+}
+
 int aob_bake_copy_nodes4q(AobBake* b, AobBvh4QNode* dst, uint64_t capacity)
 {
     AOB_TRY(check_bake(b, 0, false));
-    if (capacity < b->node4_count || (!dst && b->node4_count)) { set_error("node4q buffer too small"); return AOB_ERR_INVALID_ARGUMENT; }
-    if (b->node4_count) AOB_HIP(hipMemcpyAsync(dst, b->nodes4q, sizeof(AobBvh4QNode) * b->node4_count, hipMemcpyDeviceToHost, b->stream));
+    uint64_t n = 0;
+    AOB_TRY(node4q_count(b, &n));
+    if (capacity < n || (!dst && n)) { set_error("node4q buffer too small"); return AOB_ERR_INVALID_ARGUMENT; }
+    if (n) AOB_HIP(hipMemcpyAsync(dst, b->nodes4q, sizeof(AobBvh4QNode) * n, hipMemcpyDeviceToHost, b->stream));
     AOB_HIP(hipStreamSynchronize(b->stream));
     return AOB_OK;
 }

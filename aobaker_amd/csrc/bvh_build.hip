@@ -355,24 +355,41 @@ void k_emit_nodes_q(uint32_t n, const uint32_t* __restrict__ child_left, const u
     nodesq[2ull * i + 1] = make_uint4(q[7] | q[10] << 16, q[8] | q[11] << 16, l, r);
 }
 
-// quantised form of the 4-ary nodes: child j = {x, y, z words ((0x8000 | min) | (0x8000 | max) << 16), ref}
+// The 4-ary nodes sit at the index of the BVH2 node they were made from, so every second record is a hole (a
+// collapsed-away level).  The quantised array the traversal walks is packed: live records in index order — for both
+// builders that is the tree top-down, neighbours in space next to each other — and refs renumbered.  Half the
+// bytes, and both halves of every 128-byte cache line are nodes.
 __global__ __launch_bounds__(kBlock)
-void k_emit_nodes4q(uint32_t count4, const float4* __restrict__ nodes4, const float* __restrict__ frame, uint4* __restrict__ nodes4q)
+void k_live4(uint32_t count4, const float4* __restrict__ nodes4, uint32_t* __restrict__ live)
 {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= count4) return;
+    live[i] = __float_as_uint(nodes4[8ull * i].w) != 0u ? 1u : 0u;     // slot 0 of a node is never empty, and never node 0
+}
+
+// quantised form of the 4-ary nodes: child j = {x, y, z words ((0x8000 | min) | (0x8000 | max) << 16), ref}
+__global__ __launch_bounds__(kBlock)
+void k_emit_nodes4q(uint32_t count4, const float4* __restrict__ nodes4, const float* __restrict__ frame,
+                    const uint32_t* __restrict__ live, const uint32_t* __restrict__ packed_index, uint4* __restrict__ nodes4q,
+                    uint32_t* __restrict__ packed_count)
+{
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= count4) return;
+    if (i == count4 - 1) *packed_count = packed_index[i] + live[i];
+    if (!live[i]) return;
+    const uint64_t at = packed_index[i];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const float4 lo = nodes4[8ull * i + j], hi = nodes4[8ull * i + 4 + j];
-        const uint32_t ref = __float_as_uint(lo.w);
+        uint32_t ref = __float_as_uint(lo.w);
         uint4 o = make_uint4(0u, 0u, 0u, ref);
-        // collapsed-away levels keep all-zero records (ref 0 with a zero box is never reached)
-        if (ref != 0xffffffffu && !(ref == 0u && lo.x == 0.0f && hi.x == 0.0f && lo.y == 0.0f && hi.y == 0.0f && lo.z == 0.0f && hi.z == 0.0f)) {
+        if (ref != 0xffffffffu) {
+            if (ref < 0x80000000u) o.w = packed_index[ref];
             o.x = 0x80008000u | quant_down(lo.x, frame[0], frame[3]) | quant_up(hi.x, frame[0], frame[3]) << 16;
             o.y = 0x80008000u | quant_down(lo.y, frame[1], frame[4]) | quant_up(hi.y, frame[1], frame[4]) << 16;
             o.z = 0x80008000u | quant_down(lo.z, frame[2], frame[5]) | quant_up(hi.z, frame[2], frame[5]) << 16;
         }
-        nodes4q[4ull * i + j] = o;
+        nodes4q[4ull * at + j] = o;
     }
 }
 
@@ -646,8 +663,16 @@ int build_bvh(AobBake* b)
     hipLaunchKernelGGL(k_quant_frame, dim3(1), dim3(64), 0, s, b->scene_bounds_enc, b->quant_frame);
     if (n > 1) hipLaunchKernelGGL(k_emit_nodes_q, dim3(blocks_for(n - 1)), dim3(kBlock), 0, s, (uint32_t)n, b->child_left,
                                   b->child_right, b->node_bounds, b->quant_frame, b->nodes2q);
-    hipLaunchKernelGGL(k_emit_nodes4q, dim3(blocks_for(b->node4_count)), dim3(kBlock), 0, s, (uint32_t)b->node4_count, b->nodes4,
-                       b->quant_frame, b->nodes4q);
+    {
+        uint32_t* live = b->refit_flags;                     // free once the tree is built
+        uint32_t* packed = b->packed_index;
+        hipLaunchKernelGGL(k_live4, dim3(blocks_for(b->node4_count)), dim3(kBlock), 0, s, (uint32_t)b->node4_count, b->nodes4, live);
+        size_t temp = b->sort_temp_bytes;
+        AOB_HIP(rocprim::exclusive_scan(b->sort_temp, temp, live, packed, 0u, (size_t)b->node4_count, rocprim::plus<uint32_t>(), s));
+        hipLaunchKernelGGL(k_emit_nodes4q, dim3(blocks_for(b->node4_count)), dim3(kBlock), 0, s, (uint32_t)b->node4_count, b->nodes4,
+                           b->quant_frame, live, packed, b->nodes4q, b->node4q_count_dev);
+        b->node4q_count = UINT64_MAX;                        // read back on demand (aob_bake_node4q_count)
+    }
     hipLaunchKernelGGL(k_leaf_tris, dim3(blocks_for(n)), dim3(kBlock), 0, s, (uint32_t)n, b->prim_idx[1], b->tri_verts,
                        b->leaf_tris);
     AOB_HIP(hipGetLastError());

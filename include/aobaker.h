@@ -175,7 +175,8 @@ typedef struct AobQuantFrame { float origin[3]; float scale[3]; } AobQuantFrame;
  * w[4j..4j+2] = x, y, z words and w[4j+3] = ref_j (as in AobBvh4Node); an empty slot has
  * ref = AOB_INVALID_ADDR and zero words.  A word is (0x8000 | min) | (0x8000 | max) << 16: bit 15 of each
  * half is set so that the bytes {0x3f, half>>8, half&0xff, 0x00} are the IEEE float 1 + q/32768 — one
- * v_perm_b32 per plane in the traversal; decode q = half & 0x7fff.  Walked one lane per ray
+ * v_perm_b32 per plane in the traversal; decode q = half & 0x7fff.  The array is packed (no records for the
+ * collapsed-away levels): inner refs index this array, not AobBvh4Node[].  Walked one lane per ray
  * (bvh_width 4, bvh_quantised 1). */
 typedef struct AobBvh4QNode { uint32_t w[16]; } AobBvh4QNode;
 /* 48 B leaf triangle in Morton order: v0.w = shape id bits, v1.w = prim id bits. */
@@ -247,7 +248,9 @@ int aob_bake_copy_leaf_tris(AobBake* bake, AobLeafTri* dst, uint64_t capacity);
 /* The quantised BVH2 (max(0, n-1) AobBvh2QNode entries) and its frame. */
 int aob_bake_copy_nodes2q(AobBake* bake, AobBvh2QNode* dst, uint64_t capacity);
 int aob_bake_quant_frame(AobBake* bake, AobQuantFrame* frame);
-/* The quantised 4-ary nodes: node4_count entries of AobBvh4QNode. */
+/* The quantised 4-ary nodes, packed: the live entries of the AobBvh4Node array (those whose slot 0 holds a ref) in
+ * index order, refs renumbered accordingly; node4q_count entries of AobBvh4QNode. */
+int aob_bake_node4q_count(AobBake* bake, uint64_t* count);
 int aob_bake_copy_nodes4q(AobBake* bake, AobBvh4QNode* dst, uint64_t capacity);
 int aob_bake_surfel_count(AobBake* bake, int32_t material, uint64_t* count);
 int aob_bake_copy_surfels(AobBake* bake, int32_t material, AobSurfel* dst, uint64_t capacity);

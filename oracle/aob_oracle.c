@@ -884,19 +884,31 @@ static inline int traverse2q(const AobBvh2QNode* nq, uint64_t n, const AobQuantF
  * stored as 0x8000 | q: with 0x3f above and 0x00 below, those two bytes are the float 1 + q/32768 (plane_float). */
 uint64_t orc_bvh4q_build(const AobBvh4Node* nodes4, uint64_t count4, const AobQuantFrame* fr, AobBvh4QNode* out)
 {
+    /* packed: the live records (slot 0 holds a ref; collapsed-away levels are all zero) in index order, refs renumbered */
+    uint32_t* packed = (uint32_t*)malloc(sizeof(uint32_t) * (count4 ? count4 : 1));
+    uint64_t live = 0;
     for (uint64_t i = 0; i < count4; i++) {
+        uint32_t ref0; memcpy(&ref0, &nodes4[i].lo[0][3], 4);
+        packed[i] = (uint32_t)live;
+        live += ref0 != 0u;
+    }
+    for (uint64_t i = 0; i < count4; i++) {
+        uint32_t ref0; memcpy(&ref0, &nodes4[i].lo[0][3], 4);
+        if (ref0 == 0u) continue;
+        AobBvh4QNode* o = &out[packed[i]];
         for (int j = 0; j < 4; j++) {
             const float* lo = nodes4[i].lo[j]; const float* hi = nodes4[i].hi[j];
             uint32_t ref; memcpy(&ref, &lo[3], 4);
-            uint32_t* w = &out[i].w[4 * j];
+            uint32_t* w = &o->w[4 * j];
             w[0] = w[1] = w[2] = 0; w[3] = ref;
             if (ref == AOB_INVALID_ADDR) continue;
-            if (ref == 0 && lo[0] == 0.0f && hi[0] == 0.0f && lo[1] == 0.0f && hi[1] == 0.0f && lo[2] == 0.0f && hi[2] == 0.0f) continue;
+            if (!(ref & AOB_LEAF_FLAG)) w[3] = packed[ref];
             for (int k = 0; k < 3; k++)
                 w[k] = 0x80008000u | quant_down(lo[k], fr->origin[k], fr->scale[k]) | quant_up(hi[k], fr->origin[k], fr->scale[k]) << 16;
         }
     }
-    return count4;
+    free(packed);
+    return live;
 }
 
 #define ORC_STACK4 512

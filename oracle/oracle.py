@@ -179,8 +179,8 @@ def bvh4q_build(nodes4, frame):
     nodes4 = np.ascontiguousarray(nodes4)
     frame = np.ascontiguousarray(frame, dtype=np.float32)
     out = np.zeros((max(1, len(nodes4)), 16), dtype=np.uint32)
-    lib.orc_bvh4q_build(nodes4.ctypes.data, len(nodes4), frame.ctypes.data, out.ctypes.data)
-    return out[:len(nodes4)]
+    cnt = int(lib.orc_bvh4q_build(nodes4.ctypes.data, len(nodes4), frame.ctypes.data, out.ctypes.data))
+    return out[:cnt]
 
 
 def rasterize(desc, material, opt):

@@ -69,10 +69,18 @@ def test_bvh4_nodes_bit_exact(engine, orc, name):
     # and their quantised form (AobBvh4QNode) on the AobBvh2QNode grid
     _, frame = orc.bvh2q_build(ref2)
     assert np.array_equal(got4q, orc.bvh4q_build(ref4, frame))
-    # a plane is stored as 0x8000 | q (the bytes of the float 1 + q/32768); the decoded boxes contain the fp32 boxes
+    # packed: the live AobBvh4Node records (slot 0 holds a ref) in index order, refs renumbered
+    live = got4["lo"][:, 0, 3].view(np.uint32) != 0
+    assert len(got4q) == int(live.sum())
+    got4 = got4[live]
+    packed = np.cumsum(live) - 1
     w = got4q.reshape(-1, 4, 4)
     refs = w[:, :, 3]
-    used = (refs != capi.INVALID_ADDR) & ~((refs == 0) & (w[:, :, :3] == 0).all(axis=2))
+    refs4 = got4["lo"][:, :, 3].view(np.uint32)
+    inner = (refs4 != capi.INVALID_ADDR) & (refs4 < 0x80000000)
+    assert np.array_equal(refs[inner], packed[refs4[inner]]) and np.array_equal(refs[~inner], refs4[~inner])
+    # a plane is stored as 0x8000 | q (the bytes of the float 1 + q/32768); the decoded boxes contain the fp32 boxes
+    used = refs != capi.INVALID_ADDR
     assert ((w[:, :, :3][used] & 0x80008000) == 0x80008000).all()
     assert (w[:, :, :3][~used] == 0).all()
     f64 = frame.astype(np.float64)

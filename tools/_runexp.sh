@@ -1,5 +1,6 @@
-mkdir -p gpurun_out/exp21
-for r in 20 24 28 32 40; do for l in 8 10 12 14; do
-  AOB_TRACE_REFILL_IDLE=$r AOB_TRACE_LEAF_WAIT=$l timeout -k 10 120 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/exp21/r${r}_l$l.json 2>gpurun_out/exp21/r${r}_l$l.err || exit 1
-  echo refill $r leaf $l $(grep -o '"trace_kernel": [0-9.]*' gpurun_out/exp21/r${r}_l$l.json)
-done; done
+mkdir -p gpurun_out/exp22
+timeout -k 10 600 python -m pytest tests -q -x -m gpu > gpurun_out/exp22/pytest.log 2>&1; tail -3 gpurun_out/exp22/pytest.log
+for i in 1 2; do
+timeout -k 10 120 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/exp22/b$i.json 2>gpurun_out/exp22/b$i.err || exit 1
+echo $(grep -o '"trace_kernel": [0-9.]*' gpurun_out/exp22/b$i.json)
+done
