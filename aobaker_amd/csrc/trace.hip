@@ -347,10 +347,12 @@ void k_trace(TraceParams p)
                     tn = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0f);
                     tf = fminf(fminf(fminf(tx.y, ty.y), tz.y), closest_t);
                 }
-                return tn <= tf && c.w != kInvalid;            // an empty slot is excluded by its ref
+                return tn <= tf;
             };
             float k0, k1, k2, k3;
-            const bool h0 = slab(c0, k0), h1 = slab(c1, k1), h2 = slab(c2, k2), h3 = slab(c3, k3);
+            // an empty slot is excluded by its ref; slot 0 of a node is never empty
+            const bool h0 = slab(c0, k0), h1 = slab(c1, k1) && c1.w != kInvalid, h2 = slab(c2, k2) && c2.w != kInvalid,
+                       h3 = slab(c3, k3) && c3.w != kInvalid;
             if (!(h0 || h1 || h2 || h3)) {
                 addr = pop();
                 if (addr == kInvalid) finish();
