@@ -1,0 +1,209 @@
+"""Wavefront OBJ in, PNG out — the Python twin of aobaker_amd/host/Assets.cpp.
+
+`load_obj` mirrors `BakeObject::LoadFromFile` (reference BakeObject.cpp:170-195: assimp with
+ConvertToLeftHanded | FixInfacingNormals | GenNormals | ImproveCacheLocality | Triangulate) with the conventions the
+C++ importer documents: one vertex per face corner, one section per (object/group, material) in order of first
+appearance, fan triangulation, flat normals for a mesh that has none, z negated, v -> 1 - v, winding reversed;
+materials found in or added to the target scene by name.  `save_png` mirrors `BakeTexture::SavePNG`
+(BakeTexture.cpp:104-116) and writes the same bytes as the C++ writer (stored deflate blocks).  The tests compare the
+two implementations bit for bit; `read_png` is the decoder those tests use.
+"""
+from __future__ import annotations
+
+import struct
+import zlib
+
+import numpy as np
+
+from .scene import RENDER_VERTEX, BakeObject, BakeTexture, MaterialObject, RenderMesh, Scene, Section
+
+F = np.float32
+
+
+def _find_material(scene: Scene, name: str) -> int:
+    for i in range(scene.GetMaterialCount()):
+        if scene.GetMaterial(i).Name == name:
+            return i
+    return -1
+
+
+def _resolve(i: int, count: int) -> int:
+    return i - 1 if i > 0 else count + i if i < 0 else -1
+
+
+def load_obj(path: str, scene: Scene, atlas=(512, 512), channelCount=1, bytesPerChannel=1, target: BakeObject | None = None) -> BakeObject:
+    """Import `path` into `target` (a new BakeObject added to `scene` if None); returns the object."""
+    positions, normals, uvs = [], [], []
+    meshes: list[tuple[str, str, list]] = []
+    mesh_of: dict[tuple[str, str], int] = {}
+    obj, material = "defaultobject", "DefaultMaterial"
+    with open(path, "r", encoding="latin-1", newline="") as f:
+        for line in f:
+            p = line.lstrip(" \t")
+            head = p[:2]
+            if head in ("v ", "v\t"):
+                t = p[2:].split()
+                positions.append([F(float(t[0])), F(float(t[1])), F(float(t[2]))])
+            elif p[:3] in ("vn ", "vn\t"):
+                t = p[3:].split()
+                normals.append([F(float(t[0])), F(float(t[1])), F(float(t[2]))])
+            elif p[:3] in ("vt ", "vt\t"):
+                t = p[3:].split()
+                uvs.append([F(float(t[0])), F(float(t[1]))])
+            elif head in ("f ", "f\t"):
+                face = []
+                for tok in p[2:].split():
+                    if tok.startswith("#"):
+                        break
+                    parts = tok.split("/")
+                    v = _resolve(int(parts[0]), len(positions))
+                    vt = _resolve(int(parts[1]), len(uvs)) if len(parts) > 1 and parts[1] else -1
+                    vn = _resolve(int(parts[2]), len(normals)) if len(parts) > 2 and parts[2] else -1
+                    if not (0 <= v < len(positions)) or vt >= len(uvs) or vn >= len(normals):
+                        raise ValueError(f"{path}: face index out of range")
+                    face.append((v, vt, vn))
+                if len(face) < 3:
+                    continue
+                key = (obj, material)
+                if key not in mesh_of:
+                    mesh_of[key] = len(meshes)
+                    meshes.append((obj, material, []))
+                meshes[mesh_of[key]][2].append(face)
+            elif head in ("o ", "o\t", "g ", "g\t"):
+                obj = p[2:].strip(" \t\r\n") or "defaultobject"
+            elif p.startswith("usemtl") and p[6:7] in (" ", "\t"):
+                material = p[7:].strip(" \t\r\n") or "DefaultMaterial"
+
+    if target is None:
+        target = scene.AddObject(BakeObject("Object"))
+    P = np.asarray(positions, dtype=F).reshape(-1, 3)
+    N = np.asarray(normals, dtype=F).reshape(-1, 3)
+    T = np.asarray(uvs, dtype=F).reshape(-1, 2)
+    for obj_name, mat_name, faces in meshes:
+        has_normals = all(c[2] >= 0 for face in faces for c in face)
+        tris = [(face[0], face[k], face[k + 1]) for face in faces for k in range(1, len(face) - 1)]
+        n = len(tris)
+        vi = np.array([[c[0] for c in t] for t in tris], dtype=np.int64).reshape(n, 3)
+        ti = np.array([[c[1] for c in t] for t in tris], dtype=np.int64).reshape(n, 3)
+        ni = np.array([[c[2] for c in t] for t in tris], dtype=np.int64).reshape(n, 3)
+        pos = P[vi]                                                          # [n, 3 corners, xyz]
+        if has_normals:
+            nrm = N[ni]
+        else:
+            # aiProcess_GenNormals: the face normal of the (counter-clockwise, right-handed) triangle, float32 throughout
+            e1, e2 = pos[:, 1] - pos[:, 0], pos[:, 2] - pos[:, 0]
+            c = np.stack([e1[:, 1] * e2[:, 2] - e1[:, 2] * e2[:, 1], e1[:, 2] * e2[:, 0] - e1[:, 0] * e2[:, 2],
+                          e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0]], axis=1).astype(F)
+            length = np.sqrt((c[:, 0] * c[:, 0] + c[:, 1] * c[:, 1] + c[:, 2] * c[:, 2]).astype(F)).astype(F)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                flat = np.where(length[:, None] > 0, c / length[:, None], F(0)).astype(F)
+            nrm = np.repeat(flat[:, None, :], 3, axis=1)
+        uv = np.zeros((n, 3, 2), dtype=F)
+        have_uv = ti >= 0
+        if T.size:
+            src = T[np.where(have_uv, ti, 0)]
+            uv[..., 0] = np.where(have_uv, src[..., 0], F(0))
+            uv[..., 1] = np.where(have_uv, F(1) - src[..., 1], F(0))
+        v = np.zeros(3 * n, dtype=RENDER_VERTEX)
+        # aiProcess_ConvertToLeftHanded: z -> -z, v -> 1 - v, and the winding below
+        v["Position"] = (pos * np.array([1, 1, -1], dtype=F)).reshape(-1, 3)
+        v["Normal"] = (nrm * np.array([1, 1, -1], dtype=F)).reshape(-1, 3)
+        v["UV"] = uv.reshape(-1, 2)
+        v["Color"] = 1.0
+        base = 3 * np.arange(n, dtype=np.uint32)
+        indices = np.stack([base, base + 2, base + 1], axis=1).reshape(-1)
+        at = _find_material(scene, mat_name)
+        if at > -1:
+            mat = scene.GetMaterial(at)
+        else:
+            mat = scene.AddMaterial(MaterialObject(mat_name, atlas[0], atlas[1], channelCount, bytesPerChannel))
+        target.AddSection(Section(obj_name, RenderMesh(v, indices), mat))
+    return target
+
+
+# ---- PNG ----------------------------------------------------------------------------------------------------
+_COLOR_TYPE = {1: 0, 2: 4, 3: 2, 4: 6}
+
+
+def _chunk(kind: bytes, body: bytes) -> bytes:
+    return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xFFFFFFFF)
+
+
+def png_bytes(texture: BakeTexture) -> bytes:
+    w, h, ch, bpc = texture.GetWidth(), texture.GetHeight(), texture.GetChannelCount(), texture.GetBytesPerChannel()
+    if bpc == 1:
+        rows = texture.GetData().reshape(h, w * ch)
+        depth = 8
+    else:
+        v = texture.as_array().astype(np.float32).reshape(h, w * ch)
+        # clamp to [0,1] (NaN -> 0), round to nearest, big-endian 16-bit samples
+        q = np.where(v > 0, np.where(v >= 1, F(65535), v * F(65535) + F(0.5)), F(0)).astype(np.float32)
+        rows = q.astype(np.uint16).astype(">u2").view(np.uint8).reshape(h, w * ch * 2)
+        depth = 16
+    raw = np.concatenate([np.zeros((h, 1), dtype=np.uint8), rows], axis=1).tobytes()        # filter type 0 per scanline
+    z = bytearray(b"\x78\x01")
+    at = 0
+    while True:                                                              # stored deflate blocks of at most 65535 bytes
+        n = min(65535, len(raw) - at)
+        z += bytes([1 if at + n == len(raw) else 0]) + struct.pack("<HH", n, n ^ 0xFFFF) + raw[at:at + n]
+        at += n
+        if at >= len(raw):
+            break
+    z += struct.pack(">I", zlib.adler32(raw) & 0xFFFFFFFF)
+    ihdr = struct.pack(">IIBBBBB", w, h, depth, _COLOR_TYPE[ch], 0, 0, 0)
+    return b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", ihdr) + _chunk(b"IDAT", bytes(z)) + _chunk(b"IEND", b"")
+
+
+def save_png(texture: BakeTexture, path: str) -> None:
+    with open(path, "wb") as f:
+        f.write(png_bytes(texture))
+
+
+def read_png(path: str) -> np.ndarray:
+    """Decode a non-interlaced 8- or 16-bit PNG (any filter types) to an (H, W, C) uint8 / uint16 array."""
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    at, idat, ihdr = 8, b"", None
+    while at < len(data):
+        n, kind = struct.unpack(">I4s", data[at:at + 8])
+        body = data[at + 8:at + 8 + n]
+        assert struct.unpack(">I", data[at + 8 + n:at + 12 + n])[0] == zlib.crc32(kind + body) & 0xFFFFFFFF, "chunk CRC"
+        if kind == b"IHDR":
+            ihdr = struct.unpack(">IIBBBBB", body)
+        elif kind == b"IDAT":
+            idat += body
+        at += 12 + n
+    w, h, depth, color, _, _, interlace = ihdr
+    assert interlace == 0 and depth in (8, 16)
+    ch = {0: 1, 4: 2, 2: 3, 6: 4}[color]
+    bpp = ch * depth // 8
+    raw = zlib.decompress(idat)
+    stride = w * bpp
+    out = np.zeros((h, stride), dtype=np.uint8)
+    prev = np.zeros(stride, dtype=np.int32)
+    for y in range(h):
+        ft = raw[y * (stride + 1)]
+        line = np.frombuffer(raw, dtype=np.uint8, count=stride, offset=y * (stride + 1) + 1).astype(np.int32)
+        if ft == 0:
+            cur = line
+        elif ft == 2:
+            cur = (line + prev) & 255
+        else:                                                                # sub / average / paeth: sequential per byte
+            cur = np.zeros(stride, dtype=np.int32)
+            for i in range(stride):
+                a = cur[i - bpp] if i >= bpp else 0
+                b = prev[i]
+                c = prev[i - bpp] if i >= bpp else 0
+                if ft == 1:
+                    pred = a
+                elif ft == 3:
+                    pred = (a + b) >> 1
+                else:
+                    pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                    pred = a if pa <= pb and pa <= pc else b if pb <= pc else c
+                cur[i] = (line[i] + pred) & 255
+        out[y] = cur
+        prev = cur
+    if depth == 8:
+        return out.reshape(h, w, ch)
+    return out.view(">u2").astype(np.uint16).reshape(h, w, ch)

@@ -1,0 +1,313 @@
+// Assets.cpp — the data formats either side of the bake: Wavefront OBJ in,
+// PNG out, behind the reference's own entry points BakeObject::LoadFromFile (BakeObject.cpp:170-195) and
+// BakeTexture::SavePNG (BakeTexture.cpp:104-116).  Host code only — nothing here touches the GPU.
+// The Python twin, used by the tests, is aobaker_amd/assets.py: both produce the same vertices and the same bytes.
+//
+// OBJ import.  The reference hands the file to assimp with
+//   aiProcess_ConvertToLeftHanded | FixInfacingNormals | GenNormals | ImproveCacheLocality | Triangulate
+// (BakeObject.cpp:183) and turns every aiMesh into one Section whose material is found or created in the target
+// scene by name (:137-152).  Kept: one vertex per face corner and one mesh per (object/group, material), in order of
+// first appearance (assimp's OBJ importer does not share vertices); polygons triangulated; flat normals generated
+// for a mesh that has none; left-handed conversion = z negated on positions and normals, v -> 1 - v, winding
+// reversed.  Not kept: the zero-filled first half of the index buffer (:96,127 — `vector(n)` followed by
+// push_back), assimp's ear clipping for concave polygons (a fan is used), its triangle reordering for cache
+// locality and its in-facing-normal heuristic — none of which changes what a well-formed mesh bakes to.
+#include "../../include/aobaker_scene.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <string>
+#include <utility>
+
+using DirectX::SimpleMath::Vector2;
+using DirectX::SimpleMath::Vector3;
+using DirectX::SimpleMath::Vector4;
+
+// ---------------------------------------------------------------------------------------------------------
+// PNG (RFC 2083) with stored deflate blocks: no compressor needed, any decoder reads it
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+uint32_t crc32_update(uint32_t crc, const unsigned char* p, size_t n)
+{
+	static uint32_t table[256];
+	static bool ready = false;
+	if (!ready)
+	{
+		for (uint32_t i = 0; i < 256; i++)
+		{
+			uint32_t c = i;
+			for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+			table[i] = c;
+		}
+		ready = true;
+	}
+	for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 0xffu] ^ (crc >> 8);
+	return crc;
+}
+
+void put_be32(std::vector<unsigned char>& v, uint32_t x)
+{
+	v.push_back((unsigned char)(x >> 24)); v.push_back((unsigned char)(x >> 16)); v.push_back((unsigned char)(x >> 8)); v.push_back((unsigned char)x);
+}
+
+void put_chunk(std::vector<unsigned char>& png, const char type[4], const std::vector<unsigned char>& body)
+{
+	put_be32(png, (uint32_t)body.size());
+	const size_t at = png.size();
+	png.insert(png.end(), type, type + 4);
+	png.insert(png.end(), body.begin(), body.end());
+	put_be32(png, crc32_update(0xffffffffu, png.data() + at, png.size() - at) ^ 0xffffffffu);
+}
+
+float half_to_float(uint16_t h)
+{
+	const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
+	uint32_t bits;
+	if (exp == 0)
+	{
+		if (man == 0) bits = sign;
+		else
+		{
+			int e = -1; uint32_t m = man;
+			do { e++; m <<= 1; } while (!(m & 0x400u));
+			bits = sign | (uint32_t)(127 - 15 - e) << 23 | (m & 0x3ffu) << 13;
+		}
+	}
+	else if (exp == 31) bits = sign | 0x7f800000u | man << 13;
+	else bits = sign | (exp + 112u) << 23 | man << 13;
+	float f; std::memcpy(&f, &bits, 4);
+	return f;
+}
+
+// the 16-bit sample of a float channel: clamp to [0,1] (NaN -> 0), round to nearest
+uint16_t unorm16(float v)
+{
+	if (!(v > 0.0f)) return 0;
+	if (v >= 1.0f) return 65535;
+	return (uint16_t)(v * 65535.0f + 0.5f);
+}
+
+} // namespace
+
+bool BakeTexture::SavePNG(const char* filename) const
+{
+	static const unsigned char kColorType[5] = { 0, 0, 4, 2, 6 };        // grey, grey + alpha, RGB, RGBA
+	if (ChannelCount < 1 || ChannelCount > 4 || (BytesPerChannel != 1 && BytesPerChannel != 2 && BytesPerChannel != 4)) return false;
+	const int depth = BytesPerChannel == 1 ? 8 : 16;
+	const size_t row = (size_t)Width * ChannelCount * (depth / 8);
+	// scanlines, filter type 0 each
+	std::vector<unsigned char> raw;
+	raw.reserve((row + 1) * Height);
+	for (int y = 0; y < Height; y++)
+	{
+		raw.push_back(0);
+		const unsigned char* src = Data.data() + (size_t)y * Width * ChannelCount * BytesPerChannel;
+		if (BytesPerChannel == 1) raw.insert(raw.end(), src, src + row);
+		else for (int i = 0; i < Width * ChannelCount; i++)
+		{
+			float v;
+			if (BytesPerChannel == 4) std::memcpy(&v, src + 4 * (size_t)i, 4);
+			else { uint16_t h; std::memcpy(&h, src + 2 * (size_t)i, 2); v = half_to_float(h); }
+			const uint16_t q = unorm16(v);
+			raw.push_back((unsigned char)(q >> 8)); raw.push_back((unsigned char)q);       // PNG samples are big endian
+		}
+	}
+	// zlib stream of stored blocks
+	std::vector<unsigned char> z;
+	z.push_back(0x78); z.push_back(0x01);
+	uint32_t a = 1, b = 0;
+	for (size_t i = 0; i < raw.size(); i++) { a = (a + raw[i]) % 65521u; b = (b + a) % 65521u; }
+	size_t at = 0;
+	do
+	{
+		const size_t n = raw.size() - at < 65535 ? raw.size() - at : 65535;
+		z.push_back(at + n == raw.size() ? 1 : 0);
+		z.push_back((unsigned char)(n & 0xff)); z.push_back((unsigned char)(n >> 8));
+		z.push_back((unsigned char)(~n & 0xff)); z.push_back((unsigned char)((~n >> 8) & 0xff));
+		z.insert(z.end(), raw.begin() + at, raw.begin() + at + n);
+		at += n;
+	} while (at < raw.size());
+	put_be32(z, b << 16 | a);
+
+	std::vector<unsigned char> png = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a };
+	std::vector<unsigned char> ihdr;
+	put_be32(ihdr, (uint32_t)Width); put_be32(ihdr, (uint32_t)Height);
+	ihdr.push_back((unsigned char)depth); ihdr.push_back(kColorType[ChannelCount]);
+	ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+	put_chunk(png, "IHDR", ihdr);
+	put_chunk(png, "IDAT", z);
+	put_chunk(png, "IEND", {});
+	FILE* f = std::fopen(filename, "wb");
+	if (!f) return false;
+	const bool ok = std::fwrite(png.data(), 1, png.size(), f) == png.size();
+	return std::fclose(f) == 0 && ok;
+}
+
+void BakeTexture::SavePNG(const wchar_t* filename) const
+{
+	char name[4096];
+	if (std::wcstombs(name, filename, sizeof name) == (size_t)-1) return;     // BakeTexture.cpp:112-113
+	SavePNG(name);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Wavefront OBJ
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Corner { int v, vt, vn; };        // 0-based, -1 = absent
+
+struct ObjMesh
+{
+	std::string object, material;
+	std::vector<std::vector<Corner>> faces;
+};
+
+// decimal -> double -> float, the two roundings a Python float() / numpy float32 pair makes
+float parse_float(const char*& p)
+{
+	char* end;
+	const double d = std::strtod(p, &end);
+	p = end;
+	return (float)d;
+}
+
+void skip_space(const char*& p) { while (*p == ' ' || *p == '\t') p++; }
+
+std::string rest_of_line(const char* p)
+{
+	skip_space(p);
+	std::string s(p);
+	while (!s.empty() && (s.back() == '\n' || s.back() == '\r' || s.back() == ' ' || s.back() == '\t')) s.pop_back();
+	return s;
+}
+
+int resolve_index(long i, size_t count) { return i > 0 ? (int)(i - 1) : i < 0 ? (int)((long)count + i) : -1; }
+
+std::wstring widen(const std::string& s) { return std::wstring(s.begin(), s.end()); }
+
+Vector3 sub(const Vector3& a, const Vector3& b) { return Vector3(a.x - b.x, a.y - b.y, a.z - b.z); }
+
+} // namespace
+
+bool BakeObject::LoadFromFile(const char* filename, Scene* const targetScene, int atlasWidth, int atlasHeight, int channelCount, int bytesPerChannel)
+{
+	FILE* f = std::fopen(filename, "rb");
+	if (!f) return false;
+	std::vector<Vector3> positions, normals;
+	std::vector<Vector2> uvs;
+	std::vector<ObjMesh> meshes;
+	std::map<std::pair<std::string, std::string>, size_t> mesh_of;
+	std::string object = "defaultobject", material = "DefaultMaterial";
+	std::vector<char> line(1 << 16);
+	while (std::fgets(line.data(), (int)line.size(), f))
+	{
+		const char* p = line.data();
+		skip_space(p);
+		if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t'))
+		{
+			p += 2; Vector3 v; v.x = parse_float(p); v.y = parse_float(p); v.z = parse_float(p);
+			positions.push_back(v);
+		}
+		else if (p[0] == 'v' && p[1] == 'n' && (p[2] == ' ' || p[2] == '\t'))
+		{
+			p += 3; Vector3 v; v.x = parse_float(p); v.y = parse_float(p); v.z = parse_float(p);
+			normals.push_back(v);
+		}
+		else if (p[0] == 'v' && p[1] == 't' && (p[2] == ' ' || p[2] == '\t'))
+		{
+			p += 3; Vector2 v; v.x = parse_float(p); v.y = parse_float(p);
+			uvs.push_back(v);
+		}
+		else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t'))
+		{
+			p += 2;
+			std::vector<Corner> face;
+			for (;;)
+			{
+				skip_space(p);
+				if (*p == '\0' || *p == '\n' || *p == '\r' || *p == '#') break;
+				char* end;
+				Corner c = { -1, -1, -1 };
+				c.v = resolve_index(std::strtol(p, &end, 10), positions.size());
+				if (end == p) break;
+				p = end;
+				if (*p == '/')
+				{
+					p++;
+					if (*p != '/') { c.vt = resolve_index(std::strtol(p, &end, 10), uvs.size()); p = end; }
+					if (*p == '/') { p++; c.vn = resolve_index(std::strtol(p, &end, 10), normals.size()); p = end; }
+				}
+				if (c.v < 0 || c.v >= (int)positions.size()) { std::fclose(f); return false; }
+				if (c.vt >= (int)uvs.size() || c.vn >= (int)normals.size()) { std::fclose(f); return false; }
+				face.push_back(c);
+			}
+			if (face.size() < 3) continue;
+			const auto key = std::make_pair(object, material);
+			auto it = mesh_of.find(key);
+			if (it == mesh_of.end())
+			{
+				it = mesh_of.emplace(key, meshes.size()).first;
+				meshes.push_back({ object, material, {} });
+			}
+			meshes[it->second].faces.push_back(std::move(face));
+		}
+		else if ((p[0] == 'o' || p[0] == 'g') && (p[1] == ' ' || p[1] == '\t')) { object = rest_of_line(p + 2); if (object.empty()) object = "defaultobject"; }
+		else if (std::strncmp(p, "usemtl", 6) == 0 && (p[6] == ' ' || p[6] == '\t')) { material = rest_of_line(p + 7); if (material.empty()) material = "DefaultMaterial"; }
+	}
+	std::fclose(f);
+
+	for (const ObjMesh& mesh : meshes)
+	{
+		bool has_normals = true;
+		for (const auto& face : mesh.faces) for (const Corner& c : face) has_normals = has_normals && c.vn >= 0;
+		std::vector<RenderVertex> vertices;
+		std::vector<unsigned int> indices;
+		for (const auto& face : mesh.faces)
+		{
+			for (size_t k = 1; k + 1 < face.size(); k++)
+			{
+				const Corner tri[3] = { face[0], face[k], face[k + 1] };
+				Vector3 flat;
+				if (!has_normals)
+				{
+					// aiProcess_GenNormals: the face normal of the (counter-clockwise, right-handed) triangle
+					const Vector3 e1 = sub(positions[(size_t)tri[1].v], positions[(size_t)tri[0].v]), e2 = sub(positions[(size_t)tri[2].v], positions[(size_t)tri[0].v]);
+					const Vector3 n(e1.y * e2.z - e1.z * e2.y, e1.z * e2.x - e1.x * e2.z, e1.x * e2.y - e1.y * e2.x);
+					const float len = std::sqrt(n.x * n.x + n.y * n.y + n.z * n.z);
+					flat = len > 0.0f ? Vector3(n.x / len, n.y / len, n.z / len) : Vector3(0.0f, 0.0f, 0.0f);
+				}
+				const unsigned int base = (unsigned int)vertices.size();
+				for (int c = 0; c < 3; c++)
+				{
+					RenderVertex v;
+					const Vector3& p3 = positions[(size_t)tri[c].v];
+					const Vector3 n3 = has_normals ? normals[(size_t)tri[c].vn] : flat;
+					// aiProcess_ConvertToLeftHanded: z -> -z, v -> 1 - v (and the winding below)
+					v.Position = Vector3(p3.x, p3.y, -p3.z);
+					v.Normal = Vector3(n3.x, n3.y, -n3.z);
+					v.UV = tri[c].vt >= 0 ? Vector2(uvs[(size_t)tri[c].vt].x, 1.0f - uvs[(size_t)tri[c].vt].y) : Vector2(0.0f, 0.0f);   // no UV channel: left as constructed (:113-120)
+					v.Color = Vector4(1.0f, 1.0f, 1.0f, 1.0f);
+					vertices.push_back(v);
+				}
+				indices.push_back(base); indices.push_back(base + 2); indices.push_back(base + 1);
+			}
+		}
+		// BakeObject.cpp:137-152: the material is found in, or added to, the target scene by name
+		const std::wstring materialName = widen(mesh.material);
+		MaterialObject* materialObject;
+		const int existing = targetScene->FindMaterial(materialName);
+		if (existing > -1) materialObject = targetScene->GetMaterial(existing);
+		else { materialObject = new MaterialObject(materialName, atlasWidth, atlasHeight, channelCount, bytesPerChannel); targetScene->AddMaterial(materialObject); }
+		AddSection(new Section(widen(mesh.object), new RenderMesh(vertices.data(), (int)vertices.size(), indices.data(), (int)indices.size()), materialObject));
+	}
+	return true;
+}
+
+void BakeObject::LoadFromFile(const std::wstring& filename, Scene* const targetScene)
+{
+	std::string name(filename.begin(), filename.end());
+	LoadFromFile(name.c_str(), targetScene);
+}

@@ -88,6 +88,10 @@ public:
     unsigned char* GetData() const { return const_cast<unsigned char*>(Data.data()); }
     size_t GetDataLength() const { return Data.size(); }
     void RefreshPreview() const {}          // GPU preview upload (BakeTexture.cpp:119-122): nothing to do headless
+    // BakeTexture.cpp:104-116 (stb_image_write there; 8-bit only).  Here: 8-bit PNG for 1-byte channels, 16-bit PNG
+    // (UNORM of the float value clamped to [0,1]) for the 2- and 4-byte float channels.  aobaker_amd/host/Assets.cpp
+    bool SavePNG(const char* filename) const;
+    void SavePNG(const wchar_t* filename) const;
 private:
     int Width, Height, ChannelCount, BytesPerChannel;
     std::vector<unsigned char> Data;
@@ -122,6 +126,8 @@ private:
     DirectX::SimpleMath::Vector3 Position, Rotation, Scale { 1.0f, 1.0f, 1.0f };
 };
 
+class Scene;
+
 class BakeObject : public TransformObject {
 public:
     class Section {
@@ -129,6 +135,7 @@ public:
         Section(const std::wstring& name, RenderMesh* mesh, MaterialObject* material) : Name(name), PreviewMesh(mesh), Material(material) {}
         MaterialObject* GetMaterial() const { return Material; }
         void SetMaterial(MaterialObject* m) { Material = m; }
+        const std::wstring& GetName() const { return Name; }
         RenderMesh* GetPreviewMesh() const { return PreviewMesh.get(); }
     private:
         std::wstring Name;
@@ -136,6 +143,14 @@ public:
         MaterialObject* Material;
     };
     explicit BakeObject(const std::wstring& name) : Name(name) {}
+    // BakeObject.cpp:170-195 (assimp there).  Wavefront OBJ only, with the reference's import conventions:
+    // triangulated, normals generated where absent, left-handed with V flipped, one section per object/material;
+    // materials are looked up in / added to the target scene by name.  New materials get an atlasWidth x atlasHeight
+    // AO texture (MaterialObject.cpp:7 hard-codes 512 x 512 x 1 x 1).  aobaker_amd/host/Assets.cpp
+    bool LoadFromFile(const char* filename, Scene* const targetScene, int atlasWidth = 512, int atlasHeight = 512,
+                      int channelCount = 1, int bytesPerChannel = 1);
+    void LoadFromFile(const std::wstring& filename, Scene* const targetScene);
+    const std::wstring& GetName() const { return Name; }
     Section* AddSection(Section* s) { Sections.emplace_back(s); return s; }     // takes ownership
     int GetSectionCount() const { return (int)Sections.size(); }
     Section* GetSection(int index) const { return Sections[(size_t)index].get(); }
@@ -155,6 +170,10 @@ public:
     int GetMaterialCount() const { return (int)Materials.size(); }
     int FindMaterial(MaterialObject* material) const {
         for (size_t i = 0; i < Materials.size(); i++) if (Materials[i].get() == material) return (int)i;
+        return -1;
+    }
+    int FindMaterial(const std::wstring& name) const {                         // Scene.h:29
+        for (size_t i = 0; i < Materials.size(); i++) if (Materials[i]->GetName() == name) return (int)i;
         return -1;
     }
 private:

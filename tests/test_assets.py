@@ -1,0 +1,135 @@
+"""OBJ import and PNG export: the C++ host code (aobaker_amd/host/Assets.cpp, through
+tools/aobake_assets) and its Python twin (aobaker_amd/assets.py) agree bit for bit, and both follow the import
+conventions the reference asks assimp for (BakeObject.cpp:183).  No GPU involved."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from aobaker_amd import assets
+from aobaker_amd.scene import BakeTexture, Scene
+from aobaker_amd.scenefile import read_scene
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "aobaker_amd", "host", "aobake_assets")
+
+OBJ = """# two objects, two materials, quads and a pentagon, relative indices, a mesh without normals
+o box
+v -0.5 -0.5 0.5
+v 0.5 -0.5 0.5
+v 0.5 0.5 0.5
+v -0.5 0.5 0.5
+v 0.1234567 0.7654321 -0.3333333
+vt 0 0
+vt 1 0
+vt 1 1
+vt 0.25 0.75
+vn 0 0 1
+usemtl red
+f 1/1/1 2/2/1 3/3/1 4/4/1
+f -5/1/1 -4/2/1 -1/3/1
+usemtl blue
+f 1/1 2/2 3/3 4/4 5/1
+g lid
+f 1 2 5
+f 2//1 3//1 5//1
+usemtl red
+f 4/4/1 3/3/1 5/2/1
+"""
+
+
+@pytest.fixture(scope="module")
+def tool():
+    if not os.path.exists(TOOL):
+        subprocess.run(["make", "-s", "-C", os.path.dirname(TOOL), "aobake_assets"], check=True)
+    return TOOL
+
+
+def test_obj_import_conventions(tmp_path):
+    path = tmp_path / "t.obj"
+    path.write_text(OBJ)
+    scene = Scene()
+    obj = assets.load_obj(str(path), scene, atlas=(64, 32))
+    # one section per (object/group, material), in order of first appearance; materials by name
+    assert [(s.Name, s.GetMaterial().Name) for s in obj.Sections] == [("box", "red"), ("box", "blue"), ("lid", "blue"), ("lid", "red")]
+    assert [scene.GetMaterial(i).Name for i in range(scene.GetMaterialCount())] == ["red", "blue"]
+    assert scene.GetMaterial(0).GetAOTexture().GetWidth() == 64 and scene.GetMaterial(0).GetAOTexture().GetHeight() == 32
+    red = obj.GetSection(0).GetPreviewMesh()
+    # a quad and a triangle -> 3 triangles, one vertex per corner
+    assert red.GetVertexCount() == 9 and red.GetIndexCount() == 9
+    v = red.GetVertices()
+    # left-handed: z negated on positions and normals, v flipped, winding reversed
+    assert np.array_equal(v["Position"][0], np.float32([-0.5, -0.5, -0.5]))
+    assert np.array_equal(v["Normal"][0], np.float32([0, 0, -1]))
+    assert np.array_equal(v["UV"][:3], np.float32([[0, 1], [1, 1], [1, 0]]))
+    assert red.GetIndices().tolist() == [0, 2, 1, 3, 5, 4, 6, 8, 7]
+    # relative indices: -5 is vertex 1, -1 is vertex 5
+    assert np.array_equal(v["Position"][6], np.float32([-0.5, -0.5, -0.5]))
+    assert np.array_equal(v["Position"][8], np.float32([0.1234567, 0.7654321, 0.3333333]))
+    # the pentagon fans into 3 triangles; no normals in that mesh: flat face normals, unit length, z negated
+    blue = obj.GetSection(1).GetPreviewMesh()
+    assert blue.GetVertexCount() == 9
+    n = blue.GetVertices()["Normal"]
+    assert np.array_equal(n[0], n[1]) and np.array_equal(n[1], n[2]) and np.array_equal(n[0], np.float32([0, 0, -1]))
+    assert np.allclose(np.linalg.norm(n.astype(np.float64), axis=1), 1.0, atol=1e-6)
+    # a mesh with normals on only some corners gets generated normals for every triangle; no UVs -> (0, 0)
+    lid = obj.GetSection(2).GetPreviewMesh()
+    assert lid.GetVertexCount() == 6 and np.array_equal(lid.GetVertices()["UV"], np.zeros((6, 2), np.float32))
+
+
+def test_obj_import_cpp_equals_python(tool, tmp_path):
+    path = tmp_path / "t.obj"
+    path.write_text(OBJ)
+    out = tmp_path / "t.aobs"
+    r = subprocess.run([tool, "obj2aobs", str(path), str(out), "64", "32", "1", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    cpp = read_scene(str(out))
+    py = Scene()
+    assets.load_obj(str(path), py, atlas=(64, 32))
+    assert cpp.GetMaterialCount() == py.GetMaterialCount() == 2
+    a, b = cpp.GetObject(0), py.GetObject(0)
+    assert a.GetSectionCount() == b.GetSectionCount() == 4
+    for s in range(4):
+        ma, mb = a.GetSection(s).GetPreviewMesh(), b.GetSection(s).GetPreviewMesh()
+        assert ma.GetVertices().tobytes() == mb.GetVertices().tobytes()
+        assert np.array_equal(ma.GetIndices(), mb.GetIndices())
+        assert cpp.FindMaterial(a.GetSection(s).GetMaterial()) == py.FindMaterial(b.GetSection(s).GetMaterial())
+
+
+def test_obj_import_rejects_bad_indices(tool, tmp_path):
+    path = tmp_path / "bad.obj"
+    path.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 7\n")
+    r = subprocess.run([tool, "obj2aobs", str(path), str(tmp_path / "x.aobs"), "8", "8", "1", "1"], capture_output=True, text=True)
+    assert r.returncode == 1
+    with pytest.raises(ValueError):
+        assets.load_obj(str(path), Scene())
+
+
+@pytest.mark.parametrize("channels,bpc", [(1, 1), (2, 1), (4, 1), (1, 2), (1, 4), (3, 4), (4, 4)])
+def test_png_cpp_equals_python_and_decodes(tool, tmp_path, channels, bpc):
+    w, h = 37, 300                       # 300 rows x (37*4*2+1) bytes: more than one stored block
+    rng = np.random.default_rng(channels * 10 + bpc)
+    tex = BakeTexture(w, h, channels, bpc)
+    if bpc == 1:
+        tex.Data[:] = rng.integers(0, 256, tex.Data.size, dtype=np.uint8)
+    else:
+        vals = rng.uniform(-0.25, 1.25, w * h * channels).astype(np.float32)
+        vals[:4] = [np.nan, np.inf, -np.inf, 1.0]
+        tex.Data[:] = (vals.astype(np.float16) if bpc == 2 else vals).view(np.uint8)
+    raw, cpp_png, py_png = tmp_path / "t.raw", tmp_path / "cpp.png", tmp_path / "py.png"
+    tex.Data.tofile(str(raw))
+    r = subprocess.run([tool, "png", str(raw), str(cpp_png), str(w), str(h), str(channels), str(bpc)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assets.save_png(tex, str(py_png))
+    assert cpp_png.read_bytes() == py_png.read_bytes()
+    img = assets.read_png(str(cpp_png))
+    assert img.shape == (h, w, channels)
+    if bpc == 1:
+        assert img.dtype == np.uint8 and np.array_equal(img, tex.as_array())
+    else:
+        v = tex.as_array().astype(np.float32)
+        want = np.where(v > 0, np.where(v >= 1, 65535.0, np.floor(v.astype(np.float64) * 65535.0 + 0.5)), 0.0)
+        assert img.dtype == np.uint16
+        assert np.abs(img.astype(np.float64) - want).max() <= 1          # float32 vs float64 rounding of v*65535+0.5
+        assert img.reshape(-1)[0] == 0 and img.reshape(-1)[1] == 65535 and img.reshape(-1)[2] == 0 and img.reshape(-1)[3] == 65535

@@ -40,3 +40,50 @@ def test_cpp_bake_engine_matches_python_host(engine, tmp_path, mode):
     if bpc == 1:
         pgm = open(str(out) + "_0.pgm", "rb").read()
         assert pgm.startswith(b"P5\n128 128\n255\n") and pgm[15:] == raw.tobytes()
+
+
+def _grid_obj(n=24):
+    """A bumpy n x n quad grid with planar UVs and no normals, as OBJ text (right-handed, counter-clockwise)."""
+    lines = ["o terrain", "usemtl ground"]
+    for j in range(n + 1):
+        for i in range(n + 1):
+            x, z = i / n, j / n
+            y = 0.08 * np.sin(7.0 * x) * np.cos(5.0 * z) + (0.25 if 8 <= i <= 12 and 8 <= j <= 12 else 0.0)
+            lines.append(f"v {x:.6f} {y:.6f} {-z:.6f}")
+    for j in range(n + 1):
+        for i in range(n + 1):
+            lines.append(f"vt {i / n:.6f} {j / n:.6f}")
+    for j in range(n):
+        for i in range(n):
+            a, b, c, d = j * (n + 1) + i + 1, j * (n + 1) + i + 2, (j + 1) * (n + 1) + i + 2, (j + 1) * (n + 1) + i + 1
+            lines.append(f"f {a}/{a} {b}/{b} {c}/{c} {d}/{d}")
+    return "\n".join(lines) + "\n"
+
+
+@pytest.mark.parametrize("bpc", [1, 4])
+def test_cli_obj_to_png_matches_python_host(engine, tmp_path, bpc):
+    """OBJ -> BakeObject::LoadFromFile -> Bake -> BakeTexture::SavePNG in C++ == the same chain in Python, byte for byte."""
+    from aobaker_amd import assets
+    from aobaker_amd.scene import Scene
+    assert os.path.exists(CLI), "build the C++ host side: make -C aobaker_amd/host"
+    obj = tmp_path / "grid.obj"
+    obj.write_text(_grid_obj())
+    sc = Scene()
+    assets.load_obj(str(obj), sc, atlas=(96, 96), channelCount=1, bytesPerChannel=bpc)
+    opts = capi.default_options()
+    opts.sample_count, opts.seed = 32, 5
+    opts.sampler, opts.accumulate, opts.normal_fp16 = capi.SAMPLER_COSINE, capi.ACCUMULATE_FLOAT, capi.FP16_OFF
+    engine.Options = opts
+    engine.Bake(sc)
+    tex = sc.GetMaterial(0).GetAOTexture()
+    ao = tex.ao()
+    assert 0.2 < ao.mean() < 0.999 and ao.min() < 0.9          # the raised block occludes its surroundings
+    out = tmp_path / "ao"
+    r = subprocess.run([CLI, "--obj", str(obj), "--atlas", "96", "--bpc", str(bpc), "--out", str(out), "--png",
+                        "--spp", "32", "--seed", "5", "--sampler", "1", "--accumulate", "1", "--normal-fp16", "0"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(np.fromfile(str(out) + "_0.raw", dtype=np.uint8), tex.GetData())
+    assert open(str(out) + "_0.png", "rb").read() == assets.png_bytes(tex)
+    img = assets.read_png(str(out) + "_0.png")
+    assert img.shape == (96, 96, 1) and img.dtype == (np.uint8 if bpc == 1 else np.uint16)
