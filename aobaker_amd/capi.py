@@ -23,6 +23,8 @@ ACCUMULATE_FLOAT = 1
 FP16_OFF = 0
 FP16_RTZ = 1
 FP16_RNE = 2
+BLEED_REFERENCE = 0
+BLEED_NEAREST = 1
 INVALID_ADDR = 0xFFFFFFFF
 UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 
@@ -44,7 +46,7 @@ class AobOptions(C.Structure):
         ("bvh_width", C.c_int32),
         ("bvh_quantised", C.c_int32),
         ("bvh_builder", C.c_int32),
-        ("reserved", C.c_int32 * 1),
+        ("bleed_mode", C.c_int32),
     ]
 
 

@@ -54,6 +54,7 @@ static int validate_options(const AobOptions* o)
     if (o->accumulate != AOB_ACCUMULATE_QUANTISED && o->accumulate != AOB_ACCUMULATE_FLOAT) { set_error("unknown accumulate mode %d", o->accumulate); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->normal_fp16 < AOB_FP16_OFF || o->normal_fp16 > AOB_FP16_RNE) { set_error("unknown normal_fp16 mode %d", o->normal_fp16); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->bleed_distance < 0 || o->bleed_distance > 64) { set_error("bleed_distance %d out of range", o->bleed_distance); return AOB_ERR_INVALID_ARGUMENT; }
+    if (o->bleed_mode != AOB_BLEED_REFERENCE && o->bleed_mode != AOB_BLEED_NEAREST) { set_error("unknown bleed_mode %d", o->bleed_mode); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->bvh_builder != 0 && o->bvh_builder != 1) { set_error("bvh_builder %d: must be 0 (LBVH) or 1 (PLOC)", o->bvh_builder); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->bvh_width != 0 && o->bvh_width != 2 && o->bvh_width != 4) { set_error("bvh_width %d: must be 0, 2 or 4", o->bvh_width); return AOB_ERR_INVALID_ARGUMENT; }
     if (!(o->falloff_distance > 0.0f)) { set_error("falloff_distance must be positive"); return AOB_ERR_INVALID_ARGUMENT; }
@@ -140,6 +141,7 @@ void aob_default_options(AobOptions* o)
     o->ray_tmax = 1000000.0f;
     o->ray_bias = 0.001f;
     o->bleed_distance = 5;
+    o->bleed_mode = AOB_BLEED_REFERENCE;
     o->accumulate = AOB_ACCUMULATE_QUANTISED;
     o->normal_fp16 = AOB_FP16_RNE;
     o->ray_chunk_size = 0xFFFFFF;

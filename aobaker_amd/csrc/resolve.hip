@@ -44,7 +44,7 @@ __device__ __forceinline__ uint8_t to_unorm8(float v)
 
 template <int QUANT>
 __global__ __launch_bounds__(kBlock)
-void k_resolve(const AobResult* __restrict__ results, int32_t W, int32_t H, int32_t B,
+void k_resolve(const AobResult* __restrict__ results, int32_t W, int32_t H, int32_t B, int32_t bleed_mode,
                int32_t channels, int32_t bpc, int f16mode, uint8_t* __restrict__ out)
 {
     const int64_t cells = (int64_t)W * H;
@@ -53,7 +53,18 @@ void k_resolve(const AobResult* __restrict__ results, int32_t W, int32_t H, int3
     const int32_t py = (int32_t)(cell / W), px = (int32_t)(cell % W);
     const AobResult me = results[cell];
     float result = 0.0f;
-    if (!cell_covered<QUANT>(me)) {
+    if (!cell_covered<QUANT>(me) && bleed_mode == AOB_BLEED_NEAREST) {
+        // the nearest covered texel within B (inclusive), inside the texture only; ties: rows top to bottom, then left to right
+        int32_t closest = B * B + 1;
+        for (int32_t y = max(py - B, 0); y <= min(py + B, H - 1); y++) {
+            for (int32_t x = max(px - B, 0); x <= min(px + B, W - 1); x++) {
+                const int32_t d2 = (x - px) * (x - px) + (y - py) * (y - py);
+                if (d2 >= closest) continue;
+                const AobResult nb = results[(int64_t)y * W + x];
+                if (cell_positive<QUANT>(nb)) { closest = d2; result = cell_value<QUANT>(nb); }
+            }
+        }
+    } else if (!cell_covered<QUANT>(me)) {
         // :43-78 — x outer, y inner; the reference reads Results[y*W + x] with the RAW x and y
         // (its wrapped realx/realy are never used), so a negative x aliases into the previous
         // row and an index outside the buffer reads zeros (D3D11 out-of-bounds = 0)
@@ -91,10 +102,10 @@ int resolve_material(AobBake* b, int32_t material)
     dim3 grid((uint32_t)((cells + kBlock - 1) / kBlock));
     if (b->opt.accumulate == AOB_ACCUMULATE_QUANTISED)
         hipLaunchKernelGGL(k_resolve<1>, grid, dim3(kBlock), 0, b->stream, m.results, m.width, m.height,
-                           b->opt.bleed_distance, m.channels, m.bytes_per_channel, f16mode, m.image);
+                           b->opt.bleed_distance, b->opt.bleed_mode, m.channels, m.bytes_per_channel, f16mode, m.image);
     else
         hipLaunchKernelGGL(k_resolve<0>, grid, dim3(kBlock), 0, b->stream, m.results, m.width, m.height,
-                           b->opt.bleed_distance, m.channels, m.bytes_per_channel, f16mode, m.image);
+                           b->opt.bleed_distance, b->opt.bleed_mode, m.channels, m.bytes_per_channel, f16mode, m.image);
     AOB_HIP(hipGetLastError());
     return AOB_OK;
 }

@@ -48,6 +48,14 @@ enum { AOB_FP16_OFF = 0,                   /* keep normal + V in fp32 */
        AOB_FP16_RTZ = 1,                   /* through fp16, round toward zero */
        AOB_FP16_RNE = 2 };                 /* through fp16, round to nearest even */
 
+/* Edge bleed of uncovered texels (resolve).  REFERENCE reproduces PostprocessPixelShader.hlsl:43-78 including its
+ * quirks: the window is read with the raw x and y, so at the left/right border it aliases into
+ * the neighbouring rows; the radius is exclusive (d^2 < B^2) and ties go to the first hit of an x-outer scan.
+ * NEAREST is the dilation the reference's readme says is unfinished: neighbours outside the texture are ignored
+ * (no aliasing, no wrap), the radius is inclusive (d^2 <= B^2), and the nearest covered texel wins with ties broken
+ * by scan order (rows top to bottom, then left to right). */
+enum { AOB_BLEED_REFERENCE = 0, AOB_BLEED_NEAREST = 1 };
+
 typedef struct AobOptions {
     int32_t  sample_count;        /* rays per surfel (reference sampleCount)              */
     int32_t  sampler;             /* AOB_SAMPLER_*                                        */
@@ -71,7 +79,7 @@ typedef struct AobOptions {
     int32_t  bvh_builder;         /* 0: LBVH, the reference stack's GPU builder (kernels/CL/build_hlbvh.cl);
                                      1: PLOC (locally-ordered agglomerative clustering over the same Morton
                                      order) — same node layouts, cheaper trees, ~1.5 ms more build time   */
-    int32_t  reserved[1];
+    int32_t  bleed_mode;          /* AOB_BLEED_*: how uncovered texels borrow a neighbour's value     */
 } AobOptions;
 
 /* ---- scene description ----------------------------------------------------

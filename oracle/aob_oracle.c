@@ -1348,7 +1348,18 @@ void orc_resolve(const AobResult* results, int32_t W, int32_t H, const AobOption
         for (int32_t px = 0; px < W; px++) {
             const AobResult* me = &results[(size_t)py * W + px];
             float result = 0.0f;
-            if (!cell_covered(me, quantised)) {
+            if (!cell_covered(me, quantised) && opt->bleed_mode == AOB_BLEED_NEAREST) {
+                /* the nearest covered texel within B (inclusive), inside the texture only; ties by scan order */
+                int32_t closest = B * B + 1;
+                for (int32_t y = py - B < 0 ? 0 : py - B; y <= (py + B > H - 1 ? H - 1 : py + B); y++) {
+                    for (int32_t x = px - B < 0 ? 0 : px - B; x <= (px + B > W - 1 ? W - 1 : px + B); x++) {
+                        const int32_t d2 = (x - px) * (x - px) + (y - py) * (y - py);
+                        if (d2 >= closest) continue;
+                        const AobResult* nb = &results[(size_t)y * W + x];
+                        if (cell_positive(nb, quantised)) { closest = d2; result = cell_value(nb, quantised); }
+                    }
+                }
+            } else if (!cell_covered(me, quantised)) {
                 /* :43-78: scan x outer / y inner; the read uses the RAW (x, y), so a negative x
                  * aliases into the previous row and an index outside the buffer reads zeros */
                 int32_t closest = (B + 1) * (B + 1);

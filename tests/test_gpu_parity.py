@@ -168,12 +168,13 @@ def test_trace_results_match_oracle(engine, orc, name, mode, width):
     assert 0 < stats.rays <= len(surfels) * opt.sample_count     # surfels with a NaN frame cast nothing
 
 
+@pytest.mark.parametrize("bleed_mode", [capi.BLEED_REFERENCE, capi.BLEED_NEAREST])
 @pytest.mark.parametrize("fmt", [(1, 1), (4, 1), (1, 2), (2, 2), (1, 4), (3, 4), (4, 4)])
-def test_resolve_formats(engine, orc, fmt):
+def test_resolve_formats(engine, orc, fmt, bleed_mode):
     channels, bpc = fmt
-    sc = scenes.cube_scene(64, channels=channels, bpc=bpc)
+    sc = scenes.cube_scene(64, channels=channels, bpc=bpc)          # six charts with gutters: the bleed has work to do
     flat = FlatScene(sc)
-    opt = make_options(orc, sample_count=16)
+    opt = make_options(orc, sample_count=16, bleed_mode=bleed_mode, bleed_distance=5 if bleed_mode == capi.BLEED_REFERENCE else 3)
     m = flat.material_array[0]
     with Baker(flat, opt) as b:
         b.build_bvh(); b.rasterize(0); b.trace(0); b.resolve(0)

@@ -295,6 +295,29 @@ def test_bleed_row_aliasing_quirk(orc):
     assert out[3, 8] == 0 and out[1, 9] == 0
 
 
+def test_bleed_nearest_mode(orc):
+    """AOB_BLEED_NEAREST: no aliasing across rows, inclusive radius, the nearest covered texel wins."""
+    W, H = 16, 6
+    res = np.zeros(W * H, dtype=capi.result_dtype())
+    res["total_bits"][1 * W + 15] = 255; res["weight_bits"][1 * W + 15] = 255        # end of row 1
+    res["total_bits"][4 * W + 3] = 100; res["weight_bits"][4 * W + 3] = 255
+    out = orc.resolve(res, W, H, opts(orc, bleed_distance=3, bleed_mode=capi.BLEED_NEAREST), 1, 1).reshape(H, W)
+    assert out[1, 15] == 255 and out[1, 12] == 255 and out[1, 11] == 0               # radius 3 inclusive along the row
+    assert out[2, 0] == 0 and out[0, 0] == 0                                         # nothing leaks into the next row's start
+    assert out[4, 0] == 100 and out[4, 6] == 100 and out[4, 7] == 0                  # d = 3 reached on both sides
+    assert out[2, 5] == 100 and out[2, 4] == 100 and out[1, 5] == 0                  # d^2 = 8 and 5 <= 9; 13 > 9
+    # between two sources the nearer one wins; at equal distance the one met first scanning rows top to bottom
+    res2 = np.zeros(W * H, dtype=capi.result_dtype())
+    for (y, x, v) in ((1, 4, 50), (3, 4, 200), (2, 8, 120)):
+        res2["total_bits"][y * W + x] = v; res2["weight_bits"][y * W + x] = 255
+    out2 = orc.resolve(res2, W, H, opts(orc, bleed_distance=3, bleed_mode=capi.BLEED_NEAREST), 1, 1).reshape(H, W)
+    assert out2[2, 4] == 50                      # tie between (1,4) and (3,4): the upper row is scanned first
+    assert out2[2, 7] == 120 and out2[2, 5] == 50 and out2[3, 5] == 200
+    # the reference mode on the same cells: exclusive radius and the x-outer scan order
+    ref = orc.resolve(res2, W, H, opts(orc, bleed_distance=3), 1, 1).reshape(H, W)
+    assert ref[2, 4] == 50 and ref[2, 11] == 0 and out2[2, 11] == 120
+
+
 def test_two_sections_sum_into_the_same_cells(orc):
     sc = scenes.two_section_scene(32)
     o = opts(orc, sample_count=16)
