@@ -12,7 +12,7 @@ import importlib.util
 import os
 import sys
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # ---- enums (include/aobaker.h) ------------------------------------------------
 AOB_OK = 0
@@ -25,6 +25,8 @@ FP16_RTZ = 1
 FP16_RNE = 2
 BLEED_REFERENCE = 0
 BLEED_NEAREST = 1
+MESH_HIDDEN_FROM_SELF = 1
+MESH_HIDDEN_FROM_OTHERS = 2
 INVALID_ADDR = 0xFFFFFFFF
 UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 
@@ -47,6 +49,8 @@ class AobOptions(C.Structure):
         ("bvh_quantised", C.c_int32),
         ("bvh_builder", C.c_int32),
         ("bleed_mode", C.c_int32),
+        ("material_ranges", C.c_int32),
+        ("reserved", C.c_int32 * 3),
     ]
 
 
@@ -63,6 +67,8 @@ class AobMeshDesc(C.Structure):
         ("index_count", C.c_uint32),
         ("material", C.c_int32),
         ("model", C.c_float * 16),
+        ("flags", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 
@@ -73,6 +79,8 @@ class AobMaterialDesc(C.Structure):
         ("channels", C.c_int32),
         ("bytes_per_channel", C.c_int32),
         ("data", C.c_void_p),
+        ("ao_max_range", C.c_float),
+        ("reserved", C.c_int32),
     ]
 
 

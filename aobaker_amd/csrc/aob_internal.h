@@ -39,10 +39,12 @@ struct DeviceMesh {
     uint64_t  triangle_offset = 0;   // first global triangle
     int32_t   material = -1;
     float     model[16];
+    uint32_t  flags = 0;             // AOB_MESH_*
 };
 
 struct DeviceMaterial {
     int32_t width = 0, height = 0, channels = 0, bytes_per_channel = 0;
+    float ao_max_range = 0.0f;            // AobMaterialDesc::ao_max_range
     uint8_t* host_data = nullptr;
     uint32_t* cover = nullptr;            // W*H: winning triangle index + 1, per section pass
     uint32_t* block_sums = nullptr;       // scan partials
@@ -101,6 +103,8 @@ struct AobBake {
 
     uint32_t* gstack = nullptr;         // traversal stacks in HBM, only for trees deeper than 62 levels
     uint32_t* trace_unit_next = nullptr; // [8] per-XCD work queue heads of the trace launch
+    uint32_t* hidden_from_others = nullptr;  // bit s: shape s (mesh s-1) is hidden from the rays of other meshes
+    bool      any_mesh_flags = false;
     int cu_count = 256;
     uint64_t gstack_words = 0;
 

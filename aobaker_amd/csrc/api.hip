@@ -55,6 +55,7 @@ static int validate_options(const AobOptions* o)
     if (o->normal_fp16 < AOB_FP16_OFF || o->normal_fp16 > AOB_FP16_RNE) { set_error("unknown normal_fp16 mode %d", o->normal_fp16); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->bleed_distance < 0 || o->bleed_distance > 64) { set_error("bleed_distance %d out of range", o->bleed_distance); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->bleed_mode != AOB_BLEED_REFERENCE && o->bleed_mode != AOB_BLEED_NEAREST) { set_error("unknown bleed_mode %d", o->bleed_mode); return AOB_ERR_INVALID_ARGUMENT; }
+    if (o->material_ranges != 0 && o->material_ranges != 1) { set_error("material_ranges %d: must be 0 or 1", o->material_ranges); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->bvh_builder != 0 && o->bvh_builder != 1) { set_error("bvh_builder %d: must be 0 (LBVH) or 1 (PLOC)", o->bvh_builder); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->bvh_width != 0 && o->bvh_width != 2 && o->bvh_width != 4) { set_error("bvh_width %d: must be 0, 2 or 4", o->bvh_width); return AOB_ERR_INVALID_ARGUMENT; }
     if (!(o->falloff_distance > 0.0f)) { set_error("falloff_distance must be positive"); return AOB_ERR_INVALID_ARGUMENT; }
@@ -91,7 +92,7 @@ static void free_bake(AobBake* b)
     hipFree(b->codes[0]); hipFree(b->codes[1]); hipFree(b->prim_idx[0]); hipFree(b->prim_idx[1]);
     hipFree(b->sort_temp); hipFree(b->child_left); hipFree(b->child_right); hipFree(b->parent);
     hipFree(b->node_bounds); hipFree(b->refit_flags); hipFree(b->depth_dev); hipFree(b->ploc_sums); hipFree(b->ploc_totals); hipFree(b->nodes); hipFree(b->nodes4); hipFree(b->leaf_tris); hipFree(b->nodes2q); hipFree(b->nodes4q); hipFree(b->packed_index); hipFree(b->node4q_count_dev); hipFree(b->quant_frame);
-    hipFree(b->hemisphere); hipFree(b->gstack); hipFree(b->trace_unit_next);
+    hipFree(b->hemisphere); hipFree(b->gstack); hipFree(b->trace_unit_next); hipFree(b->hidden_from_others);
     if (b->pinned) hipHostFree(b->pinned);
     for (auto& e : b->ev) if (e) hipEventDestroy(e);
     for (auto& e : b->ev_trace) if (e) hipEventDestroy(e);
@@ -228,6 +229,9 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
         d.triangle_count = src.index_count / 3;
         d.triangle_offset = tri_total;
         d.material = src.material;
+        d.flags = src.flags;
+        if (d.flags & ~(uint32_t)(AOB_MESH_HIDDEN_FROM_SELF | AOB_MESH_HIDDEN_FROM_OTHERS)) { set_error("mesh %u: unknown flags 0x%x", i, d.flags); return fail(AOB_ERR_INVALID_ARGUMENT); }
+        if (d.flags) b->any_mesh_flags = true;
         memcpy(d.model, src.model, sizeof d.model);
         tri_total += d.triangle_count;
         AOB_C(dev_alloc(&d.positions, 3ull * src.vertex_count));
@@ -252,6 +256,14 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
     }
     b->triangle_count = tri_total;
     const uint64_t n = tri_total;
+    {
+        // shape ids start at 1 (RadeonRays/radeon_rays.h:238): bit s of the set is mesh s - 1
+        std::vector<uint32_t> bits((scene->mesh_count + 1 + 31) / 32 + 1, 0u);
+        for (uint32_t i = 0; i < scene->mesh_count; i++)
+            if (b->meshes[i].flags & AOB_MESH_HIDDEN_FROM_OTHERS) bits[(i + 1) >> 5] |= 1u << ((i + 1) & 31);
+        AOB_C(dev_alloc(&b->hidden_from_others, bits.size()));
+        AOB_CH(hipMemcpy(b->hidden_from_others, bits.data(), sizeof(uint32_t) * bits.size(), hipMemcpyHostToDevice));
+    }
 
     // BVH workspace, sized once
     AOB_C(dev_alloc(&b->tri_verts, 3 * n));
@@ -291,6 +303,7 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
         DeviceMaterial& d = b->materials[i];
         d.width = src.width; d.height = src.height; d.channels = src.channels; d.bytes_per_channel = src.bytes_per_channel;
         d.host_data = src.data;
+        d.ao_max_range = src.ao_max_range;
         const uint64_t cells = (uint64_t)d.width * d.height;
         d.scan_blocks = (uint32_t)((cells + 2047) / 2048);
         AOB_C(dev_alloc(&d.cover, cells));

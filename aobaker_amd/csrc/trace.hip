@@ -71,6 +71,10 @@ struct TraceParams {
     uint32_t band_row;             // fully covered atlas: tiles per tile row (chunk = a band of 8 tile rows), else 0
     uint32_t units_per_xcd;        // (xcd_chunk_tiles + rest_per_xcd) * parts
     uint32_t* unit_next;           // [8] next unit of each XCD's queue (zeroed before the launch)
+    // MASKED: section visibility (AOB_MESH_*)
+    const uint32_t* hidden_from_others;    // bit s: the triangles of shape s are ignored by rays of other shapes
+    uint32_t self_shape;           // shape id of the section whose surfels this launch traces (mesh index + 1)
+    uint32_t self_hidden;          // ... and whether its rays ignore its own triangles
     int32_t refill_idle;           // lanes without a ray that trigger the refill section
     int32_t leaf_wait;             // lanes parked at a leaf that trigger the leaf section
 };
@@ -92,7 +96,7 @@ __device__ __forceinline__ long long f2fix(float v)
 #define AOB_TRACE_WAVES 8          // waves per SIMD the register allocator must leave room for (<= 64 VGPRs):
                                    // measured 4.98 / 5.14 / 5.55 Grays/s at 6 / 7 / 8 — latency hiding beats the few spills
 #endif
-template <int SAMPLER, int ANYHIT, int ACCUM, int LDS_N, int QUANT>
+template <int SAMPLER, int ANYHIT, int ACCUM, int LDS_N, int QUANT, int MASKED>
 __global__ __launch_bounds__(kWave, AOB_TRACE_WAVES)
 void k_trace(TraceParams p)
 {
@@ -313,8 +317,15 @@ void k_trace(TraceParams p)
             if (at_leaf) {
                 const float4* np = QUANT ? p.leaf_tris + 3ull * (addr - p.leaf_base) : p.nodes + 4ull * addr;
                 const float4 n0 = np[0], n1 = np[1], n2 = np[2];
-                const float t = intersect_triangle(org, dir, make_f3(n0.x, n0.y, n0.z), make_f3(n1.x, n1.y, n1.z),
-                                                   make_f3(n2.x, n2.y, n2.z), closest_t);
+                float t = intersect_triangle(org, dir, make_f3(n0.x, n0.y, n0.z), make_f3(n1.x, n1.y, n1.z),
+                                             make_f3(n2.x, n2.y, n2.z), closest_t);
+                if (MASKED) {
+                    // the ray mask of intersect_bvh2_lds.cl:163-166, by section: skip the triangles this ray must not see
+                    const uint32_t shape = __float_as_uint(QUANT ? n0.w : n1.w);
+                    const bool skip = shape == p.self_shape ? p.self_hidden != 0u
+                                                            : ((p.hidden_from_others[shape >> 5] >> (shape & 31u)) & 1u) != 0u;
+                    if (skip) t = closest_t;
+                }
                 const bool closer = t < closest_t;
                 if (closer) { closest_t = t; hit = true; }
                 addr = (ANYHIT && closer) ? kInvalid : pop();
@@ -457,25 +468,31 @@ void k_trace(TraceParams p)
 
 constexpr int lds_stack_entries(int sampler, int anyhit) { return sampler == AOB_SAMPLER_COSINE && anyhit ? kLdsStackCount : kLdsStack; }
 
-template <int SAMPLER, int ANYHIT, int ACCUM>
+template <int SAMPLER, int ANYHIT, int ACCUM, int MASKED>
 static void launch_stack(int quant, dim3 grid, hipStream_t s, const TraceParams& p)
 {
     constexpr int N = lds_stack_entries(SAMPLER, ANYHIT);
-    if (quant == 2) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 2>), grid, dim3(kWave), 0, s, p);
-    else if (quant == 1) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 1>), grid, dim3(kWave), 0, s, p);
-    else hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 0>), grid, dim3(kWave), 0, s, p);
+    if (quant == 2) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 2, MASKED>), grid, dim3(kWave), 0, s, p);
+    else if (quant == 1) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 1, MASKED>), grid, dim3(kWave), 0, s, p);
+    else hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 0, MASKED>), grid, dim3(kWave), 0, s, p);
 }
-template <int SAMPLER, int ANYHIT>
+template <int SAMPLER, int ANYHIT, int MASKED>
 static void launch_acc(int accum, int quant, dim3 grid, hipStream_t s, const TraceParams& p)
 {
-    if (accum == AOB_ACCUMULATE_QUANTISED) launch_stack<SAMPLER, ANYHIT, AOB_ACCUMULATE_QUANTISED>(quant, grid, s, p);
-    else launch_stack<SAMPLER, ANYHIT, AOB_ACCUMULATE_FLOAT>(quant, grid, s, p);
+    if (accum == AOB_ACCUMULATE_QUANTISED) launch_stack<SAMPLER, ANYHIT, AOB_ACCUMULATE_QUANTISED, MASKED>(quant, grid, s, p);
+    else launch_stack<SAMPLER, ANYHIT, AOB_ACCUMULATE_FLOAT, MASKED>(quant, grid, s, p);
 }
-template <int SAMPLER>
+template <int SAMPLER, int MASKED>
 static void launch_hit(int anyhit, int accum, int quant, dim3 grid, hipStream_t s, const TraceParams& p)
 {
-    if (anyhit) launch_acc<SAMPLER, 1>(accum, quant, grid, s, p);
-    else launch_acc<SAMPLER, 0>(accum, quant, grid, s, p);
+    if (anyhit) launch_acc<SAMPLER, 1, MASKED>(accum, quant, grid, s, p);
+    else launch_acc<SAMPLER, 0, MASKED>(accum, quant, grid, s, p);
+}
+template <int SAMPLER>
+static void launch_masked(int masked, int anyhit, int accum, int quant, dim3 grid, hipStream_t s, const TraceParams& p)
+{
+    if (masked) launch_hit<SAMPLER, 1>(anyhit, accum, quant, grid, s, p);
+    else launch_hit<SAMPLER, 0>(anyhit, accum, quant, grid, s, p);
 }
 
 uint64_t chunk_texel_max(const AobOptions& opt)
@@ -502,6 +519,7 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
     hipStream_t s = b->stream;
     AOB_HIP(hipEventRecord(b->ev_trace[0], s));
     if (begin < end && o.bvh_width == 4 && !o.bvh_quantised) {
+        if (b->any_mesh_flags) { set_error("section visibility flags need a lane-per-ray structure (bvh_quantised 1 or bvh_width 2)"); return AOB_ERR_UNSUPPORTED; }
         AOB_TRY(trace4_range(b, material, begin, end));        // quad-per-ray, 4-ary nodes (trace4.hip)
     } else if (begin < end) {
         // a lane's stack holds the sentinel plus at most one deferred sibling per tree level
@@ -522,10 +540,15 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
         if (quant == 2) p.leaf_base = 0x80000000u;          // 4-ary refs: leaf = 0x80000000 | triangle, inner = node index
         p.spp = o.sample_count;
         p.seed_hash = host_pcg(o.seed);
-        p.tmax = o.ray_tmax;
-        if (!o.use_any_hit && o.clamp_tmax_to_falloff && o.falloff_distance < p.tmax) p.tmax = o.falloff_distance;
+        p.tmax = o.ray_tmax; p.falloff = o.falloff_distance;
+        if (o.material_ranges && m.ao_max_range > 0.0f) {          // MaterialObject::AOMaxRange (AobMaterialDesc::ao_max_range)
+            if (m.ao_max_range < p.tmax) p.tmax = m.ao_max_range;
+            p.falloff = m.ao_max_range;
+        }
+        if (!o.use_any_hit && o.clamp_tmax_to_falloff && p.falloff < p.tmax) p.tmax = p.falloff;
         p.inv_tmax = 1.0f / p.tmax;
-        p.bias = o.ray_bias; p.falloff = o.falloff_distance;
+        p.bias = o.ray_bias;
+        p.hidden_from_others = b->hidden_from_others;
         p.refill_idle = max(1, env_int("AOB_TRACE_REFILL_IDLE", 24));
         p.leaf_wait = max(1, env_int("AOB_TRACE_LEAF_WAIT", 12));
         cosine_grid(o.sample_count, p.grid);
@@ -567,8 +590,10 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
                 b->gstack_words = words;
             }
             p.gstack = b->gstack;
-            if (o.sampler == AOB_SAMPLER_REFERENCE_COMPAT) launch_hit<AOB_SAMPLER_REFERENCE_COMPAT>(o.use_any_hit, o.accumulate, quant, grid, s, p);
-            else launch_hit<AOB_SAMPLER_COSINE>(o.use_any_hit, o.accumulate, quant, grid, s, p);
+            p.self_shape = m.section_mesh[si] + 1u;
+            p.self_hidden = (b->meshes[m.section_mesh[si]].flags & AOB_MESH_HIDDEN_FROM_SELF) ? 1u : 0u;
+            if (o.sampler == AOB_SAMPLER_REFERENCE_COMPAT) launch_masked<AOB_SAMPLER_REFERENCE_COMPAT>(b->any_mesh_flags, o.use_any_hit, o.accumulate, quant, grid, s, p);
+            else launch_masked<AOB_SAMPLER_COSINE>(b->any_mesh_flags, o.use_any_hit, o.accumulate, quant, grid, s, p);
         }
         AOB_HIP(hipGetLastError());
     }

@@ -308,9 +308,13 @@ int trace4_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
     p.spp = o.sample_count;
     p.block_samples = (o.sample_count + kBlocksPerSurfel - 1) / kBlocksPerSurfel;
     p.seed_hash = host_pcg(o.seed);
-    p.tmax = o.ray_tmax;
-    if (!o.use_any_hit && o.clamp_tmax_to_falloff && o.falloff_distance < p.tmax) p.tmax = o.falloff_distance;
-    p.bias = o.ray_bias; p.falloff = o.falloff_distance;
+    p.tmax = o.ray_tmax; p.falloff = o.falloff_distance;
+    if (o.material_ranges && m.ao_max_range > 0.0f) {          // MaterialObject::AOMaxRange, as in trace.hip
+        if (m.ao_max_range < p.tmax) p.tmax = m.ao_max_range;
+        p.falloff = m.ao_max_range;
+    }
+    if (!o.use_any_hit && o.clamp_tmax_to_falloff && p.falloff < p.tmax) p.tmax = p.falloff;
+    p.bias = o.ray_bias;
     p.refill_idle = max(1, env_int4("AOB_TRACE4_REFILL_IDLE", 4));
     p.leaf_wait = max(1, env_int4("AOB_TRACE4_LEAF_WAIT", 4));
     cosine_grid(o.sample_count, p.grid);

@@ -42,6 +42,9 @@ void flatten(Scene* scene, std::vector<AobMeshDesc>& meshes, std::vector<AobMate
 			// material <-> section association is by pointer equality (BakeEngine.cpp:523)
 			d.material = scene->FindMaterial(section->GetMaterial());
 			std::memcpy(d.model, transform.m, sizeof d.model);
+			// BakeObject.h:28-31: declared by the reference, never read by its Bake; here they mask rays (aobaker.h)
+			d.flags = (section->IsVisibleToSelf() ? 0u : (uint32_t)AOB_MESH_HIDDEN_FROM_SELF) |
+			          (section->IsVisibleToOthers() ? 0u : (uint32_t)AOB_MESH_HIDDEN_FROM_OTHERS);
 			meshes.push_back(d);
 		}
 	}
@@ -49,6 +52,8 @@ void flatten(Scene* scene, std::vector<AobMeshDesc>& meshes, std::vector<AobMate
 	{
 		BakeTexture* tex = scene->GetMaterial(i)->GetAOTexture();
 		AobMaterialDesc d;
+		std::memset(&d, 0, sizeof d);
+		d.ao_max_range = scene->GetMaterial(i)->GetAOMaxRange();     // used only with AobOptions::material_ranges
 		d.width = tex->GetWidth();
 		d.height = tex->GetHeight();
 		d.channels = tex->GetChannelCount();

@@ -61,8 +61,11 @@ class MaterialObject:
         # MaterialObject.cpp:7 hard-codes BakeTexture(512, 512, 1, 1); here it is a parameter
         self.Name = name
         self.AOTexture = BakeTexture(width, height, channelCount, bytesPerChannel)
+        self.AOMaxRange = 1.0           # MaterialObject.cpp:4; read by Bake only when AobOptions.material_ranges is set
 
     def GetAOTexture(self): return self.AOTexture
+    def GetAOMaxRange(self): return self.AOMaxRange
+    def SetAOMaxRange(self, v): self.AOMaxRange = float(v)
 
 
 class RenderMesh:
@@ -94,9 +97,15 @@ def make_vertices(positions, normals, uvs):
 class Section:
     def __init__(self, name, mesh: RenderMesh, material: MaterialObject | None):
         self.Name, self.PreviewMesh, self.Material = name, mesh, material
+        self.VisibleToSelf = True       # BakeObject.cpp:20: both default to true
+        self.VisibleToOthers = True
 
     def GetPreviewMesh(self): return self.PreviewMesh
     def GetMaterial(self): return self.Material
+    def IsVisibleToSelf(self): return self.VisibleToSelf
+    def SetVisibleToSelf(self, v): self.VisibleToSelf = bool(v)
+    def IsVisibleToOthers(self): return self.VisibleToOthers
+    def SetVisibleToOthers(self, v): self.VisibleToOthers = bool(v)
 
 
 def _quat_yaw_pitch_roll(yaw, pitch, roll):
@@ -203,6 +212,8 @@ class FlatScene:
                 # material <-> section association is by identity (BakeEngine.cpp:523)
                 d.material = scene.FindMaterial(sec.GetMaterial()) if sec.GetMaterial() is not None else -1
                 d.model = (C.c_float * 16)(*model.reshape(-1).tolist())
+                d.flags = (0 if sec.IsVisibleToSelf() else capi.MESH_HIDDEN_FROM_SELF) | \
+                          (0 if sec.IsVisibleToOthers() else capi.MESH_HIDDEN_FROM_OTHERS)
                 meshes.append(d)
         mats = []
         for i in range(scene.GetMaterialCount()):
@@ -211,6 +222,7 @@ class FlatScene:
             d.width, d.height = tex.GetWidth(), tex.GetHeight()
             d.channels, d.bytes_per_channel = tex.GetChannelCount(), tex.GetBytesPerChannel()
             d.data = tex.GetData().ctypes.data
+            d.ao_max_range = scene.GetMaterial(i).GetAOMaxRange()
             mats.append(d)
         self.mesh_array = (capi.AobMeshDesc * max(1, len(meshes)))(*meshes)
         self.material_array = (capi.AobMaterialDesc * max(1, len(mats)))(*mats)

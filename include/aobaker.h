@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AOB_ABI_VERSION 1
+#define AOB_ABI_VERSION 2
 
 typedef enum AobStatus {
     AOB_OK = 0,
@@ -80,6 +80,8 @@ typedef struct AobOptions {
                                      1: PLOC (locally-ordered agglomerative clustering over the same Morton
                                      order) — same node layouts, cheaper trees, ~1.5 ms more build time   */
     int32_t  bleed_mode;          /* AOB_BLEED_*: how uncovered texels borrow a neighbour's value     */
+    int32_t  material_ranges;     /* 1: honour AobMaterialDesc::ao_max_range; default 0 (the reference ignores it) */
+    int32_t  reserved[3];
 } AobOptions;
 
 /* ---- scene description ----------------------------------------------------
@@ -100,7 +102,16 @@ typedef struct AobMeshDesc {
     int32_t         material;         /* index into AobSceneDesc::materials, or -1: occluder only */
     float           model[16];        /* row-major, row-vector: world = [p 1] * model
                                          (TransformObject.cpp:21-24, RasterizeVertexShader.hlsl:30-32) */
+    uint32_t        flags;            /* AOB_MESH_*; 0 = the reference's behaviour */
+    uint32_t        reserved;
 } AobMeshDesc;
+
+/* Section visibility (BakeObject.h:28-31,49-50: `VisibleToSelf`, `VisibleToOthers` — declared by the reference, shown
+ * in its property grid, never read by its Bake).  Here they act as RadeonRays' ray masks would
+ * (common.cl:76-80, intersect_bvh2_lds.cl:163-166 skip the triangles of one mesh id): a ray cast from a surfel of
+ * mesh A ignores the triangles of mesh B when B == A and A is hidden from itself, or B != A and B is hidden from
+ * others.  Hidden triangles still get their own texels baked. */
+enum { AOB_MESH_HIDDEN_FROM_SELF = 1u, AOB_MESH_HIDDEN_FROM_OTHERS = 2u };
 
 /* The output side: BakeTexture's data contract (Scene/BakeTexture.cpp:7-67,
  * write-back BakeEngine.cpp:705-709): row-major, top row first, tightly
@@ -111,6 +122,11 @@ typedef struct AobMaterialDesc {
     int32_t  channels;            /* 1,2,4 (1- and 2-byte) or 1..4 (4-byte) */
     int32_t  bytes_per_channel;   /* 1: UNORM8, 2: fp16, 4: fp32 */
     uint8_t* data;                /* host memory, written by aob_bake / aob_bake_download */
+    float    ao_max_range;        /* MaterialObject::AOMaxRange (MaterialObject.h:10-11,18; never read by the reference's
+                                     Bake).  Used only with AobOptions::material_ranges: rays cast from this material's
+                                     texels end at min(ray_tmax, ao_max_range) and, in falloff mode, fall off over
+                                     ao_max_range instead of falloff_distance.  <= 0: the options' values */
+    int32_t  reserved;
 } AobMaterialDesc;
 
 typedef struct AobSceneDesc {

@@ -104,9 +104,13 @@ public:
         : Name(name), AOTexture(new BakeTexture(width, height, channelCount, bytesPerChannel)) {}
     BakeTexture* GetAOTexture() const { return AOTexture.get(); }
     const std::wstring& GetName() const { return Name; }
+    // MaterialObject.h:10-11, default 1.0f (MaterialObject.cpp:4); Bake reads it only with AobOptions::material_ranges
+    float GetAOMaxRange() const { return AOMaxRange; }
+    void SetAOMaxRange(const float& aoMaxRange) { AOMaxRange = aoMaxRange; }
 private:
     std::wstring Name;
     std::unique_ptr<BakeTexture> AOTexture;
+    float AOMaxRange = 1.0f;
 };
 
 // Scene/Objects/TransformObject.cpp:16-24
@@ -137,10 +141,16 @@ public:
         void SetMaterial(MaterialObject* m) { Material = m; }
         const std::wstring& GetName() const { return Name; }
         RenderMesh* GetPreviewMesh() const { return PreviewMesh.get(); }
+        // BakeObject.h:28-31, both default to true (BakeObject.cpp:20)
+        bool IsVisibleToSelf() const { return VisibleToSelf; }
+        void SetVisibleToSelf(const bool& value) { VisibleToSelf = value; }
+        bool IsVisibleToOthers() const { return VisibleToOthers; }
+        void SetVisibleToOthers(const bool& value) { VisibleToOthers = value; }
     private:
         std::wstring Name;
         std::unique_ptr<RenderMesh> PreviewMesh;
         MaterialObject* Material;
+        bool VisibleToSelf = true, VisibleToOthers = true;
     };
     explicit BakeObject(const std::wstring& name) : Name(name) {}
     // BakeObject.cpp:170-195 (assimp there).  Wavefront OBJ only, with the reference's import conventions:

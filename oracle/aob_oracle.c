@@ -589,6 +589,12 @@ static inline float quantise_fp16(float v, int mode)
 uint64_t orc_rasterize(const AobSceneDesc* scene, int32_t material, const AobOptions* opt,
                        AobSurfel* surfels, uint32_t* section_index, uint64_t capacity)
 {
+    return orc_rasterize_ex(scene, material, opt, surfels, section_index, NULL, capacity);
+}
+
+uint64_t orc_rasterize_ex(const AobSceneDesc* scene, int32_t material, const AobOptions* opt,
+                          AobSurfel* surfels, uint32_t* section_index, uint32_t* surfel_mesh, uint64_t capacity)
+{
     if (material < 0 || (uint32_t)material >= scene->material_count) return 0;
     const int32_t W = scene->materials[material].width, H = scene->materials[material].height;
     if (W <= 0 || H <= 0) return 0;
@@ -679,6 +685,7 @@ uint64_t orc_rasterize(const AobSceneDesc* scene, int32_t material, const AobOpt
                     s->normal[1] = quantise_fp16(LERP(wnrm.y), opt->normal_fp16);
                     s->normal[2] = quantise_fp16(LERP(wnrm.z), opt->normal_fp16);
                     if (section_index) section_index[total] = local;
+                    if (surfel_mesh) surfel_mesh[total] = mi;
                 }
 #undef LERP
                 total++; local++;
@@ -766,6 +773,17 @@ uint64_t orc_bvh4_build(const AobBvhNode* nodes2, uint64_t node_count2, AobBvh4N
 
 #define ORC_STACK 128
 
+/* Section visibility (AOB_MESH_*): the ray mask of intersect_bvh2_lds.cl:163-166 by section.  A ray cast from a
+ * surfel of shape `self` ignores the triangles of shape s when s == self and self is hidden from itself, or
+ * s != self and s is hidden from others.  Shape ids are mesh index + 1.  NULL: nothing is hidden. */
+typedef struct { const uint32_t* mesh_flags; uint32_t mesh_count; uint32_t self_shape; } OrcMask;
+static inline int mask_skips(const OrcMask* mask, uint32_t shape)
+{
+    if (!mask || shape == 0 || shape > mask->mesh_count) return 0;
+    const uint32_t flags = mask->mesh_flags[shape - 1];
+    return shape == mask->self_shape ? (flags & AOB_MESH_HIDDEN_FROM_SELF) != 0 : (flags & AOB_MESH_HIDDEN_FROM_OTHERS) != 0;
+}
+
 /* ---- quantised BVH2 nodes (AobBvh2QNode) ------------------------------------------------- */
 /* A 15-bit grid (the 4-ary nodes keep the 16th bit of each plane set, see orc_bvh4q_build).
  * frame: origin = scene min, scale = extent/32767 nudged up until origin + 32767*scale >= max;
@@ -827,7 +845,7 @@ uint64_t orc_bvh2q_build(const AobBvhNode* nodes2, uint64_t node_count2, AobBvh2
  * (origin + q*scale - o)*invdir = q*(scale*invdir) + (origin*invdir + oxinvdir), so the slab test of
  * :54-63 runs on the raw grid values. */
 static inline int traverse2q(const AobBvh2QNode* nq, uint64_t n, const AobQuantFrame* fr, const AobLeafTri* tris,
-                             f3 o, f3 d, float t_max, int any_hit, float* t_out, OrcTraceStats* st, int* error)
+                             f3 o, f3 d, float t_max, int any_hit, float* t_out, OrcTraceStats* st, int* error, const OrcMask* mask)
 {
     if (n == 0) { *t_out = t_max; return 0; }
     f3 invdir = safe_invdir(d);
@@ -869,6 +887,7 @@ static inline int traverse2q(const AobBvh2QNode* nq, uint64_t n, const AobQuantF
             st->leaf_visits++;
             float t = intersect_triangle(o, d, f3_make(tr->v0[0], tr->v0[1], tr->v0[2]), f3_make(tr->v1[0], tr->v1[1], tr->v1[2]),
                                          f3_make(tr->v2[0], tr->v2[1], tr->v2[2]), closest_t);
+            if (mask) { uint32_t shape; memcpy(&shape, &tr->v0[3], 4); if (mask_skips(mask, shape)) t = closest_t; }
             if (t < closest_t) {
                 closest_t = t; hit = 1;
                 if (any_hit) break;
@@ -928,7 +947,7 @@ static inline float min3n(float a, float b, float c) { return fminf(fminf(a, b),
  *     passes, which is harmless because the triangle test has the last word;
  *   - closest hit: intersect_bvh2_lds.cl:54-63 as before, near clamped at 0 and far at closest_t. */
 static inline int traverse4q(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const AobLeafTri* tris,
-                             f3 o, f3 d, float t_max, int any_hit, float* t_out, OrcTraceStats* st, int* error)
+                             f3 o, f3 d, float t_max, int any_hit, float* t_out, OrcTraceStats* st, int* error, const OrcMask* mask)
 {
     if (count4 == 0) { *t_out = t_max; return 0; }
     f3 invdir = safe_invdir(d);
@@ -994,6 +1013,7 @@ static inline int traverse4q(const AobBvh4QNode* nq, uint64_t count4, const AobQ
             st->leaf_visits++;
             float t = intersect_triangle(o, d, f3_make(tr->v0[0], tr->v0[1], tr->v0[2]), f3_make(tr->v1[0], tr->v1[1], tr->v1[2]),
                                          f3_make(tr->v2[0], tr->v2[1], tr->v2[2]), closest_t);
+            if (mask) { uint32_t shape; memcpy(&shape, &tr->v0[3], 4); if (mask_skips(mask, shape)) t = closest_t; }
             if (t < closest_t) {
                 closest_t = t; hit = 1;
                 if (any_hit) break;
@@ -1011,7 +1031,7 @@ static inline int traverse4q(const AobBvh4QNode* nq, uint64_t count4, const AobQ
  * farthest first (the 4-ary form of the near-child-first order of :123-153); leaves are single
  * triangles (common.cl:177-218). */
 static inline int traverse4(const AobBvh4Node* nodes4, uint64_t count4, const AobLeafTri* tris, f3 o, f3 d, float t_max,
-                            int any_hit, float* t_out, OrcTraceStats* st, int* error)
+                            int any_hit, float* t_out, OrcTraceStats* st, int* error, const OrcMask* mask)
 {
     if (count4 == 0) { *t_out = t_max; return 0; }
     f3 invdir = safe_invdir(d);
@@ -1052,6 +1072,7 @@ static inline int traverse4(const AobBvh4Node* nodes4, uint64_t count4, const Ao
             st->leaf_visits++;
             float t = intersect_triangle(o, d, f3_make(tr->v0[0], tr->v0[1], tr->v0[2]), f3_make(tr->v1[0], tr->v1[1], tr->v1[2]),
                                          f3_make(tr->v2[0], tr->v2[1], tr->v2[2]), closest_t);
+            if (mask) { uint32_t shape; memcpy(&shape, &tr->v0[3], 4); if (mask_skips(mask, shape)) t = closest_t; }
             if (t < closest_t) {
                 closest_t = t; hit = 1;
                 if (any_hit) break;
@@ -1073,6 +1094,8 @@ typedef struct {
     const AobBvh2QNode* nodes2q; AobQuantFrame frame; uint64_t tri_count;        /* bvh_width 2, bvh_quantised */
     const AobBvh4QNode* nodes4q;                                                 /* bvh_width 4, bvh_quantised */
     const AobSurfel* surfels; const uint32_t* section_index;
+    const uint32_t* surfel_mesh; const uint32_t* mesh_flags; uint32_t mesh_count;   /* section visibility, or NULL */
+    float ao_max_range;                                                             /* material range, or 0 */
     const AobOptions* opt; const float* hemisphere;
     int32_t width, height; AobResult* results;
     uint64_t begin, end;
@@ -1085,7 +1108,7 @@ typedef struct {
 /* intersect_bvh2_lds.cl:65-226 (closest) / :228-363 (any hit): near child first,
  * deferred child on a stack, leaf = inlined triangle. Returns hit flag, *t_out. */
 static inline int traverse(const AobBvhNode* nodes, uint64_t node_count, f3 o, f3 d, float t_max,
-                           int any_hit, float* t_out, OrcTraceStats* st, int* error)
+                           int any_hit, float* t_out, OrcTraceStats* st, int* error, const OrcMask* mask)
 {
     if (node_count == 0) { *t_out = t_max; return 0; }
     f3 invdir = safe_invdir(d);
@@ -1122,6 +1145,7 @@ static inline int traverse(const AobBvhNode* nodes, uint64_t node_count, f3 o, f
                                          f3_make(n->lmax_or_v1[0], n->lmax_or_v1[1], n->lmax_or_v1[2]),
                                          f3_make(n->rmin_or_v2[0], n->rmin_or_v2[1], n->rmin_or_v2[2]),
                                          closest_t);
+            if (mask && mask_skips(mask, n->shape_id)) t = closest_t;
             if (t < closest_t) {
                 closest_t = t; hit = 1;
                 if (any_hit) break;
@@ -1169,8 +1193,14 @@ static void trace_surfel(const TraceJob* job, uint64_t k, OrcTraceStats* st, int
     const int compat = opt->sampler == AOB_SAMPLER_REFERENCE_COMPAT;
     const int any_hit = opt->use_any_hit != 0;
     float t_max = opt->ray_tmax;
-    if (!any_hit && opt->clamp_tmax_to_falloff && opt->falloff_distance < t_max) t_max = opt->falloff_distance;
-    const float F = opt->falloff_distance;
+    float F = opt->falloff_distance;
+    if (opt->material_ranges && job->ao_max_range > 0.0f) {       /* MaterialObject::AOMaxRange */
+        if (job->ao_max_range < t_max) t_max = job->ao_max_range;
+        F = job->ao_max_range;
+    }
+    if (!any_hit && opt->clamp_tmax_to_falloff && F < t_max) t_max = F;
+    OrcMask mask_store = { job->mesh_flags, job->mesh_count, job->surfel_mesh ? job->surfel_mesh[k] + 1u : 0u };
+    const OrcMask* mask = job->mesh_flags && job->surfel_mesh ? &mask_store : NULL;
     uint32_t texel = (uint32_t)s->texel_y * (uint32_t)job->width + (uint32_t)s->texel_x;
     uint32_t base = pcg_hash(texel + pcg_hash(opt->seed));
     /* GenerateRaysComputeShader.hlsl:45 Hemisphere[DTid.x * SampleCount + i], DTid.x chunk-local */
@@ -1189,10 +1219,10 @@ static void trace_surfel(const TraceJob* job, uint64_t k, OrcTraceStats* st, int
         f3 org = f3_make(fmaf(dir.x, opt->ray_bias, P.x), fmaf(dir.y, opt->ray_bias, P.y), fmaf(dir.z, opt->ray_bias, P.z));
         float t;
         st->rays++;
-        int hit = job->nodes4q ? traverse4q(job->nodes4q, job->node4_count, &job->frame, job->tris, org, dir, t_max, any_hit, &t, st, error)
-                : job->nodes2q ? traverse2q(job->nodes2q, job->tri_count, &job->frame, job->tris, org, dir, t_max, any_hit, &t, st, error)
-                : job->nodes4 ? traverse4(job->nodes4, job->node4_count, job->tris, org, dir, t_max, any_hit, &t, st, error)
-                              : traverse(job->nodes, job->node_count, org, dir, t_max, any_hit, &t, st, error);
+        int hit = job->nodes4q ? traverse4q(job->nodes4q, job->node4_count, &job->frame, job->tris, org, dir, t_max, any_hit, &t, st, error, mask)
+                : job->nodes2q ? traverse2q(job->nodes2q, job->tri_count, &job->frame, job->tris, org, dir, t_max, any_hit, &t, st, error, mask)
+                : job->nodes4 ? traverse4(job->nodes4, job->node4_count, job->tris, org, dir, t_max, any_hit, &t, st, error, mask)
+                              : traverse(job->nodes, job->node_count, org, dir, t_max, any_hit, &t, st, error, mask);
         st->hits += (uint64_t)hit;
         /* ProcessIntersectionsComputeShader.hlsl:52-85 */
         float w = compat ? f3_dot(N, dir) : 1.0f;
@@ -1250,9 +1280,20 @@ int orc_trace(const AobBvhNode* nodes, uint64_t node_count,
               uint64_t begin, uint64_t end, const AobOptions* opt, const float* hemisphere,
               int32_t width, int32_t height, AobResult* results, int32_t threads, OrcTraceStats* stats)
 {
+    return orc_trace_ex(nodes, node_count, surfels, section_index, NULL, NULL, 0, 0.0f, begin, end, opt, hemisphere, width, height,
+                        results, threads, stats);
+}
+
+int orc_trace_ex(const AobBvhNode* nodes, uint64_t node_count,
+                 const AobSurfel* surfels, const uint32_t* section_index,
+                 const uint32_t* surfel_mesh, const uint32_t* mesh_flags, uint32_t mesh_count, float ao_max_range,
+                 uint64_t begin, uint64_t end, const AobOptions* opt, const float* hemisphere,
+                 int32_t width, int32_t height, AobResult* results, int32_t threads, OrcTraceStats* stats)
+{
     if (opt->sampler == AOB_SAMPLER_REFERENCE_COMPAT && !hemisphere && end > begin) return AOB_ERR_INVALID_ARGUMENT;
     TraceJob job;
     memset(&job, 0, sizeof job);
+    job.surfel_mesh = surfel_mesh; job.mesh_flags = mesh_flags; job.mesh_count = mesh_count; job.ao_max_range = ao_max_range;
     job.nodes = nodes; job.node_count = node_count; job.surfels = surfels; job.section_index = section_index;
     job.opt = opt; job.hemisphere = hemisphere; job.width = width; job.height = height; job.results = results;
     job.begin = begin; job.end = end; job.next = begin;
@@ -1419,9 +1460,15 @@ int orc_bake(const AobSceneDesc* scene, const AobOptions* opt, int32_t threads, 
         uint64_t cnt = orc_rasterize(scene, (int32_t)mi, opt, NULL, NULL, 0);
         AobSurfel* surfels = (AobSurfel*)malloc(sizeof(AobSurfel) * (cnt ? cnt : 1));
         uint32_t* sidx = (uint32_t*)malloc(sizeof(uint32_t) * (cnt ? cnt : 1));
-        orc_rasterize(scene, (int32_t)mi, opt, surfels, sidx, cnt);
+        uint32_t* smesh = (uint32_t*)malloc(sizeof(uint32_t) * (cnt ? cnt : 1));
+        orc_rasterize_ex(scene, (int32_t)mi, opt, surfels, sidx, smesh, cnt);
         AobResult* results = (AobResult*)calloc(cells, sizeof(AobResult));
-        rc = orc_trace(nodes, node_count, surfels, sidx, 0, cnt, opt, hemi, mat->width, mat->height, results, threads, stats);
+        uint32_t* flags = (uint32_t*)malloc(sizeof(uint32_t) * (scene->mesh_count ? scene->mesh_count : 1));
+        int any_flags = 0;
+        for (uint32_t k = 0; k < scene->mesh_count; k++) { flags[k] = scene->meshes[k].flags; any_flags |= flags[k] != 0; }
+        rc = orc_trace_ex(nodes, node_count, surfels, sidx, any_flags ? smesh : NULL, any_flags ? flags : NULL, scene->mesh_count,
+                          mat->ao_max_range, 0, cnt, opt, hemi, mat->width, mat->height, results, threads, stats);
+        free(flags); free(smesh);
         if (rc == 0 && mat->data) orc_resolve(results, mat->width, mat->height, opt, mat->channels, mat->bytes_per_channel, mat->data);
         free(results); free(sidx); free(surfels);
     }

@@ -95,6 +95,10 @@ uint64_t orc_bvh4q_build(const AobBvh4Node* nodes4, uint64_t count4, const AobQu
 uint64_t orc_rasterize(const AobSceneDesc* scene, int32_t material, const AobOptions* opt,
                        AobSurfel* surfels, uint32_t* section_index, uint64_t capacity);
 
+/* ... and, per surfel, the index of the mesh (section) it was rasterised from. */
+uint64_t orc_rasterize_ex(const AobSceneDesc* scene, int32_t material, const AobOptions* opt,
+                          AobSurfel* surfels, uint32_t* section_index, uint32_t* surfel_mesh, uint64_t capacity);
+
 typedef struct OrcTraceStats {
     uint64_t rays;
     uint64_t inner_visits;    /* inner-node fetches (64 B BVH2 nodes, or 128 B 4-ary nodes) */
@@ -113,6 +117,16 @@ int orc_trace(const AobBvhNode* nodes, uint64_t node_count,
               const AobOptions* opt, const float* hemisphere,
               int32_t width, int32_t height, AobResult* results,
               int32_t threads, OrcTraceStats* stats);
+
+/* orc_trace with section visibility (AOB_MESH_* flags per mesh + the mesh of every surfel; NULL: none) and the
+ * material's ao_max_range (used when AobOptions::material_ranges is set; 0: none). */
+int orc_trace_ex(const AobBvhNode* nodes, uint64_t node_count,
+                 const AobSurfel* surfels, const uint32_t* section_index,
+                 const uint32_t* surfel_mesh, const uint32_t* mesh_flags, uint32_t mesh_count, float ao_max_range,
+                 uint64_t begin, uint64_t end,
+                 const AobOptions* opt, const float* hemisphere,
+                 int32_t width, int32_t height, AobResult* results,
+                 int32_t threads, OrcTraceStats* stats);
 
 /* PostprocessPixelShader.hlsl:31-86 + the render-target format conversion
  * (BakeEngine.cpp:482) + write-back layout (:705-709). */

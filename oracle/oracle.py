@@ -62,6 +62,9 @@ def load():
         "orc_rasterize": (u64, [P(capi.AobSceneDesc), i32, P(capi.AobOptions), vp, vp, u64]),
         "orc_trace": (C.c_int, [vp, u64, vp, vp, u64, u64, P(capi.AobOptions), vp, i32, i32, vp, i32,
                                 P(OrcTraceStats)]),
+        "orc_rasterize_ex": (u64, [P(capi.AobSceneDesc), i32, P(capi.AobOptions), vp, vp, vp, u64]),
+        "orc_trace_ex": (C.c_int, [vp, u64, vp, vp, vp, vp, u32, f32, u64, u64, P(capi.AobOptions), vp, i32, i32, vp, i32,
+                                   P(OrcTraceStats)]),
         "orc_resolve": (None, [vp, i32, i32, P(capi.AobOptions), i32, i32, vp]),
         "orc_bake": (C.c_int, [P(capi.AobSceneDesc), P(capi.AobOptions), i32, P(OrcTraceStats)]),
     }
@@ -192,9 +195,28 @@ def rasterize(desc, material, opt):
     return surfels[:n], sidx[:n]
 
 
-def trace(nodes, surfels, section_index, opt, width, height, hemisphere=None, begin=0, end=None,
-          threads=1, results=None):
+def rasterize_ex(desc, material, opt):
+    """(surfels, section_index, surfel_mesh): also the mesh (section) every surfel came from."""
     lib = load()
+    n = int(lib.orc_rasterize(C.byref(desc), material, C.byref(opt), None, None, 0))
+    surfels = np.zeros(max(n, 1), dtype=capi.surfel_dtype())
+    sidx = np.zeros(max(n, 1), dtype=np.uint32)
+    smesh = np.zeros(max(n, 1), dtype=np.uint32)
+    lib.orc_rasterize_ex(C.byref(desc), material, C.byref(opt), surfels.ctypes.data, sidx.ctypes.data, smesh.ctypes.data, n)
+    return surfels[:n], sidx[:n], smesh[:n]
+
+
+def trace(nodes, surfels, section_index, opt, width, height, hemisphere=None, begin=0, end=None,
+          threads=1, results=None, surfel_mesh=None, mesh_flags=None, ao_max_range=0.0):
+    """surfel_mesh + mesh_flags: section visibility (AOB_MESH_*); ao_max_range: the material's range
+    (honoured when opt.material_ranges is set)."""
+    lib = load()
+    if mesh_flags is not None and surfel_mesh is not None:
+        return _trace_ex(nodes, surfels, section_index, opt, width, height, hemisphere, begin, end, threads, results,
+                         surfel_mesh, mesh_flags, ao_max_range)
+    if ao_max_range:
+        return _trace_ex(nodes, surfels, section_index, opt, width, height, hemisphere, begin, end, threads, results,
+                         None, None, ao_max_range)
     if end is None:
         end = len(surfels)
     if results is None:
@@ -211,6 +233,32 @@ def trace(nodes, surfels, section_index, opt, width, height, hemisphere=None, be
                        width, height, results.ctypes.data, threads, C.byref(stats))
     if rc != 0:
         raise RuntimeError(f"orc_trace failed: {rc}")
+    return results, stats
+
+
+def _trace_ex(nodes, surfels, section_index, opt, width, height, hemisphere, begin, end, threads, results,
+              surfel_mesh, mesh_flags, ao_max_range):
+    lib = load()
+    if end is None:
+        end = len(surfels)
+    if results is None:
+        results = np.zeros(width * height, dtype=capi.result_dtype())
+    stats = OrcTraceStats()
+    nodes = np.ascontiguousarray(nodes)
+    surfels = np.ascontiguousarray(surfels)
+    sidx = None if section_index is None else np.ascontiguousarray(section_index, dtype=np.uint32)
+    hemi = None if hemisphere is None else np.ascontiguousarray(hemisphere, dtype=np.float32)
+    smesh = None if surfel_mesh is None else np.ascontiguousarray(surfel_mesh, dtype=np.uint32)
+    flags = None if mesh_flags is None else np.ascontiguousarray(mesh_flags, dtype=np.uint32)
+    rc = lib.orc_trace_ex(nodes.ctypes.data if len(nodes) else None, len(nodes),
+                          surfels.ctypes.data if len(surfels) else None,
+                          None if sidx is None or not len(sidx) else sidx.ctypes.data,
+                          None if smesh is None or not len(smesh) else smesh.ctypes.data,
+                          None if flags is None else flags.ctypes.data, 0 if flags is None else len(flags), float(ao_max_range),
+                          begin, end, C.byref(opt), None if hemi is None else hemi.ctypes.data,
+                          width, height, results.ctypes.data, threads, C.byref(stats))
+    if rc != 0:
+        raise RuntimeError(f"orc_trace_ex failed: {rc}")
     return results, stats
 
 

@@ -243,6 +243,61 @@ def test_floor_under_ceiling_falloff_closed_form(orc):
     assert np.abs(ao - expect).max() < 0.02
 
 
+# ---- section visibility and material range -----------------------------------
+def _ao(orc, sc, **kw):
+    o = opts(orc, sample_count=64, sampler=capi.SAMPLER_COSINE, accumulate=capi.ACCUMULATE_FLOAT, normal_fp16=capi.FP16_OFF, **kw)
+    orc.bake(FlatScene(sc).desc, o, threads=4)
+    return sc.GetMaterial(0).GetAOTexture().as_array()[..., 0]
+
+
+def test_section_hidden_from_others_occludes_nobody(orc):
+    sc = scenes.floor_ceiling_scene(8, height=0.5, bpc=4)
+    assert (_ao(orc, sc) == 0.0).all()                                    # any hit: every ray meets the ceiling
+    sc = scenes.floor_ceiling_scene(8, height=0.5, bpc=4)
+    sc.GetObject(1).GetSection(0).SetVisibleToOthers(False)               # the ceiling
+    assert (_ao(orc, sc) == 1.0).all()
+    sc = scenes.floor_ceiling_scene(8, height=0.5, bpc=4)
+    sc.GetObject(1).GetSection(0).SetVisibleToSelf(False)                 # hidden only from its own rays: still occludes the floor
+    assert (_ao(orc, sc) == 0.0).all()
+
+
+def test_section_hidden_from_self_does_not_occlude_itself(orc):
+    def covered(sc):
+        w = FlatScene(sc)       # keeps the arrays alive
+        return w
+    sc = scenes.cube_scene(32, inward=True, bpc=4)
+    closed = _ao(orc, sc)
+    sc2 = scenes.cube_scene(32, inward=True, bpc=4)
+    sc2.GetObject(0).GetSection(0).SetVisibleToSelf(False)
+    open_ = _ao(orc, sc2)
+    sc3 = scenes.cube_scene(32, inward=True, bpc=4)
+    sc3.GetObject(0).GetSection(0).SetVisibleToOthers(False)              # no other section: nothing changes
+    assert np.array_equal(_ao(orc, sc3), closed)
+    assert closed.max() < 0.05 and (open_[closed < 0.05] >= 0.999).mean() > 0.8 and open_.max() == 1.0
+
+
+def test_material_range_ends_the_rays(orc):
+    h = 0.5
+    for rng, use, want in ((0.25, 1, 1.0), (0.25, 0, 0.0), (0.0, 1, 0.0)):
+        sc = scenes.floor_ceiling_scene(8, height=h, bpc=4)
+        sc.GetMaterial(0).SetAOMaxRange(rng)
+        assert (_ao(orc, sc, material_ranges=use) == want).all(), (rng, use)
+    sc = scenes.floor_ceiling_scene(8, height=h, bpc=4)
+    sc.GetMaterial(0).SetAOMaxRange(10.0)                  # only rays within 2.9 degrees of the horizon reach 10 units
+    ao = _ao(orc, sc, material_ranges=1)
+    assert ao.max() <= 2 / 64 and ao.mean() < 0.01
+    # falloff mode: the range replaces the falloff distance, so the closed form of test (3) holds with F = range
+    F = 1.0
+    sc = scenes.floor_ceiling_scene(8, height=h, bpc=4)
+    sc.GetMaterial(0).SetAOMaxRange(F)
+    o = opts(orc, sample_count=4096, sampler=capi.SAMPLER_COSINE, accumulate=capi.ACCUMULATE_FLOAT, use_any_hit=0,
+             falloff_distance=7.0, normal_fp16=capi.FP16_OFF, material_ranges=1)
+    orc.bake(FlatScene(sc).desc, o, threads=4)
+    ao = sc.GetMaterial(0).GetAOTexture().as_array()[..., 0]
+    c0 = h / F
+    assert abs(ao.mean() - (c0 * c0 + (2 * h / F) * (1 - c0))) < 3e-3
+
+
 # ---- (4) floor next to a long wall ------------------------------------------------------------
 def test_floor_wall_form_factor(orc):
     H = 1.0
