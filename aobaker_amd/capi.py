@@ -50,7 +50,8 @@ class AobOptions(C.Structure):
         ("bvh_builder", C.c_int32),
         ("bleed_mode", C.c_int32),
         ("material_ranges", C.c_int32),
-        ("reserved", C.c_int32 * 3),
+        ("morton_adaptive", C.c_int32),
+        ("reserved", C.c_int32 * 2),
     ]
 
 

@@ -121,6 +121,12 @@ __device__ __forceinline__ uint32_t morton_axis(float c, float smin, float exten
     return (uint32_t)q;
 }
 
+// ADAPTIVE: the 63 bits are dealt to the axes in the order a spatial-median builder would split them — always the axis
+// whose cell is currently longest, halving that cell (the rule of the reference library's default builder,
+// radeon_rays.h:283-287, applied to the scene box) — instead of strictly x, y, z in turn.  On a cube-shaped scene the
+// two orders coincide; on a flat one (a terrain: 1 x 0.15 x 1) the strict order spends every third split on a plane
+// that separates nothing: 8 % fewer node visits per ray on the 1 M-triangle terrain, 3 - 15 % on the instanced rocks.
+template <int ADAPTIVE>
 __global__ __launch_bounds__(kBlock)
 void k_morton(const Box* __restrict__ prim_bounds, uint32_t n, const uint32_t* __restrict__ scene_enc,
               uint64_t* __restrict__ codes, uint32_t* __restrict__ idx)
@@ -129,13 +135,32 @@ void k_morton(const Box* __restrict__ prim_bounds, uint32_t n, const uint32_t* _
     if (i >= n) return;
     Box b = prim_bounds[i];
     uint32_t q[3];
+    float ext[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         float smin = dec_float(scene_enc[k]), smax = dec_float(scene_enc[3 + k]);
         float c = (b.pmax[k] + b.pmin[k]) * 0.5f;                 // build_hlbvh.cl:118
-        q[k] = morton_axis(c, smin, smax - smin);
+        ext[k] = smax - smin;
+        q[k] = morton_axis(c, smin, ext[k]);
     }
-    codes[i] = (expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]);
+    if (ADAPTIVE) {
+        uint64_t code = 0;
+        int used0 = 0, used1 = 0, used2 = 0;                      // bits of q[k] consumed, from the top
+        float e0 = ext[0], e1 = ext[1], e2 = ext[2];
+        for (int bit = 0; bit < 63; bit++) {
+            // the longest cell among the axes with bits left; ties go to the lower axis
+            int ax = -1; float best = -1.0f;
+            if (used0 < 21 && e0 > best) { best = e0; ax = 0; }
+            if (used1 < 21 && e1 > best) { best = e1; ax = 1; }
+            if (used2 < 21 && e2 > best) { best = e2; ax = 2; }
+            if (ax == 0) { code = code << 1 | ((q[0] >> (20 - used0)) & 1u); used0++; e0 *= 0.5f; }
+            else if (ax == 1) { code = code << 1 | ((q[1] >> (20 - used1)) & 1u); used1++; e1 *= 0.5f; }
+            else { code = code << 1 | ((q[2] >> (20 - used2)) & 1u); used2++; e2 *= 0.5f; }
+        }
+        codes[i] = code;
+    } else {
+        codes[i] = (expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]);
+    }
     idx[i] = i;
 }
 
@@ -630,8 +655,10 @@ int build_bvh(AobBake* b)
                            b->tri_verts + 3ull * m.triangle_offset, b->prim_bounds + m.triangle_offset,
                            b->scene_bounds_enc);
     }
-    hipLaunchKernelGGL(k_morton, dim3(blocks_for(n)), dim3(kBlock), 0, s, b->prim_bounds, (uint32_t)n,
-                       b->scene_bounds_enc, b->codes[0], b->prim_idx[0]);
+    if (b->opt.morton_adaptive) hipLaunchKernelGGL(k_morton<1>, dim3(blocks_for(n)), dim3(kBlock), 0, s, b->prim_bounds, (uint32_t)n,
+                                                   b->scene_bounds_enc, b->codes[0], b->prim_idx[0]);
+    else hipLaunchKernelGGL(k_morton<0>, dim3(blocks_for(n)), dim3(kBlock), 0, s, b->prim_bounds, (uint32_t)n,
+                            b->scene_bounds_enc, b->codes[0], b->prim_idx[0]);
     // stable LSD radix sort of (code, index) pairs: equal codes stay in index order
     size_t temp = b->sort_temp_bytes;
     AOB_HIP(rocprim::radix_sort_pairs(b->sort_temp, temp, b->codes[0], b->codes[1], b->prim_idx[0], b->prim_idx[1],

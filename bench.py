@@ -185,7 +185,7 @@ def main():
 def _oracle_inputs(flat, opts):
     from oracle import oracle as orc
     tris = orc.scene_triangles(flat.desc)
-    nodes, _ = orc.bvh_build(tris, opts.bvh_builder)
+    nodes, _ = orc.bvh_build(tris, opts.bvh_builder, opts.morton_adaptive)
     surfels, _ = orc.rasterize(flat.desc, 0, opts)
     return orc, nodes, surfels
 

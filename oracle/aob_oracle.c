@@ -399,10 +399,10 @@ static inline float merged_area(const Box* a, const Box* b)
 
 uint64_t orc_bvh_build(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes, uint32_t* depth_out)
 {
-    return orc_bvh_build_ex(tris, n, nodes, depth_out, 0);
+    return orc_bvh_build_ex(tris, n, nodes, depth_out, 0, 0);
 }
 
-uint64_t orc_bvh_build_ex(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes, uint32_t* depth_out, int builder)
+uint64_t orc_bvh_build_ex(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes, uint32_t* depth_out, int builder, int adaptive)
 {
     if (depth_out) *depth_out = 0;
     if (n == 0) return 0;
@@ -426,6 +426,20 @@ uint64_t orc_bvh_build_ex(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes
             float c = (pb[i].pmax[k] + pb[i].pmin[k]) * 0.5f;        /* build_hlbvh.cl:118 */
             q[k] = morton_axis(c, scene.pmin[k], ext[k]);
         }
+        if (adaptive) {
+            /* AobOptions::morton_adaptive: the bits go to the axes in the order a spatial-median builder would split
+             * them (radeon_rays.h:283-287) — always the axis whose cell is currently longest, ties to the lower axis */
+            float e[3] = { ext[0], ext[1], ext[2] };
+            int used[3] = { 0, 0, 0 };
+            uint64_t code = 0;
+            for (int bit = 0; bit < 63; bit++) {
+                int ax = -1; float best = -1.0f;
+                for (int k = 0; k < 3; k++) if (used[k] < 21 && e[k] > best) { best = e[k]; ax = k; }
+                code = code << 1 | ((q[ax] >> (20 - used[ax])) & 1u);
+                used[ax]++; e[ax] *= 0.5f;
+            }
+            keys[i].code = code;
+        } else
         keys[i].code = (expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]);
         keys[i].idx = (uint32_t)i;
     }
@@ -1445,7 +1459,7 @@ int orc_bake(const AobSceneDesc* scene, const AobOptions* opt, int32_t threads, 
     orc_scene_triangles(scene, tris);
     AobBvhNode* nodes = (AobBvhNode*)malloc(sizeof(AobBvhNode) * (ntri ? 2 * ntri : 1));
     uint32_t depth = 0;
-    uint64_t node_count = orc_bvh_build_ex(tris, ntri, nodes, &depth, opt->bvh_builder);
+    uint64_t node_count = orc_bvh_build_ex(tris, ntri, nodes, &depth, opt->bvh_builder, opt->morton_adaptive);
     float* hemi = NULL;
     if (opt->sampler == AOB_SAMPLER_REFERENCE_COMPAT) {
         uint64_t n = orc_compat_table_entries(opt);

@@ -72,7 +72,7 @@ void orc_scene_triangles(const AobSceneDesc* scene, OrcTriangle* out);
  * (root = depth 0). */
 uint64_t orc_bvh_build(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes, uint32_t* depth);
 /* builder 0: the LBVH above; 1: PLOC (AobOptions::bvh_builder), same layout and id conventions. */
-uint64_t orc_bvh_build_ex(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes, uint32_t* depth, int builder);
+uint64_t orc_bvh_build_ex(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes, uint32_t* depth, int builder, int adaptive);
 
 /* The 4-ary collapse of that BVH2 (every second level removed, boxes unchanged) which the
  * default GPU kernel walks with four lanes per ray; orc_trace uses it unless

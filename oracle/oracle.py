@@ -55,7 +55,7 @@ def load():
         "orc_scene_triangle_count": (u64, [P(capi.AobSceneDesc)]),
         "orc_scene_triangles": (None, [P(capi.AobSceneDesc), vp]),
         "orc_bvh_build": (u64, [vp, u64, vp, P(u32)]),
-        "orc_bvh_build_ex": (u64, [vp, u64, vp, P(u32), C.c_int]),
+        "orc_bvh_build_ex": (u64, [vp, u64, vp, P(u32), C.c_int, C.c_int]),
         "orc_bvh4_build": (u64, [vp, u64, vp, vp]),
         "orc_bvh2q_build": (u64, [vp, u64, vp, vp]),
         "orc_bvh4q_build": (u64, [vp, u64, vp, vp]),
@@ -143,16 +143,19 @@ def scene_triangles(desc):
     return out[:n]
 
 
-def bvh_build(tris, builder=None):
-    """builder: 0 = LBVH (build_hlbvh.cl), 1 = PLOC; None = the default options' builder."""
+def bvh_build(tris, builder=None, adaptive=None):
+    """builder: 0 = LBVH (build_hlbvh.cl), 1 = PLOC; adaptive: extent-adaptive Morton bit order
+    (AobOptions.morton_adaptive); None = the default options' values."""
     lib = load()
     if builder is None:
         builder = default_options().bvh_builder
+    if adaptive is None:
+        adaptive = default_options().morton_adaptive
     n = len(tris)
     tris = np.ascontiguousarray(tris)
     nodes = np.zeros(max(1, 2 * n), dtype=capi.node_dtype())
     depth = C.c_uint32()
-    cnt = int(lib.orc_bvh_build_ex(tris.ctypes.data, n, nodes.ctypes.data, C.byref(depth), builder))
+    cnt = int(lib.orc_bvh_build_ex(tris.ctypes.data, n, nodes.ctypes.data, C.byref(depth), builder, adaptive))
     return nodes[:cnt], depth.value
 
 
@@ -295,4 +298,5 @@ def default_options():
     o.bvh_width = 4
     o.bvh_quantised = 1
     o.bvh_builder = 1
+    o.morton_adaptive = 1
     return o

@@ -29,7 +29,7 @@ def options(mode):
     o = orc.default_options()
     o.sample_count = 16
     o.seed = 1
-    o.bvh_width, o.bvh_quantised, o.bvh_builder = 2, 0, 0      # the reference stack's own builder (build_hlbvh.cl) and node layout (intersect_bvh2_lds.cl:40-52)
+    o.bvh_width, o.bvh_quantised, o.bvh_builder, o.morton_adaptive = 2, 0, 0, 0      # the reference stack's own builder (build_hlbvh.cl) and node layout (intersect_bvh2_lds.cl:40-52)
     if mode == "cosine":
         o.sampler, o.accumulate, o.normal_fp16 = capi.SAMPLER_COSINE, capi.ACCUMULATE_FLOAT, capi.FP16_OFF
     return o
@@ -47,7 +47,7 @@ def main():
             sc = make(bpc)
             flat = FlatScene(sc)
             o = options(mode)
-            nodes, depth = orc.bvh_build(orc.scene_triangles(flat.desc), 0)
+            nodes, depth = orc.bvh_build(orc.scene_triangles(flat.desc), 0, 0)
             surfels, sidx = orc.rasterize(flat.desc, 0, o)
             hemi = orc.compat_table(o) if mode == "compat" else None
             results, stats = orc.trace(nodes, surfels, sidx, o, size, size, hemi, threads=os.cpu_count() or 1)

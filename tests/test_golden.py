@@ -35,8 +35,8 @@ def test_oracle_reproduces_golden(orc, mode, bpc, case):
     sc = make(bpc)
     flat = FlatScene(sc)
     o = options(orc.default_options(), mode)
-    o.bvh_width, o.bvh_quantised, o.bvh_builder = 2, 0, 0          # the vectors were made with the LBVH on the reference's node layout
-    nodes, depth = orc.bvh_build(orc.scene_triangles(flat.desc), 0)
+    o.bvh_width, o.bvh_quantised, o.bvh_builder, o.morton_adaptive = 2, 0, 0, 0   # the vectors were made with build_hlbvh.cl's LBVH on the reference's node layout
+    nodes, depth = orc.bvh_build(orc.scene_triangles(flat.desc), 0, 0)
     surfels, sidx = orc.rasterize(flat.desc, 0, o)
     assert digest(nodes) == str(GOLD[f"{mode}_nodes_sha256"])
     assert digest(surfels) == str(GOLD[f"{mode}_surfels_sha256"])
@@ -91,7 +91,7 @@ def test_gpu_reproduces_golden(engine, mode, bpc, case, structure):
     flat = FlatScene(sc)
     o = options(capi.default_options(), mode)
     if structure == "reference":
-        o.bvh_width, o.bvh_quantised, o.bvh_builder = 2, 0, 0
+        o.bvh_width, o.bvh_quantised, o.bvh_builder, o.morton_adaptive = 2, 0, 0, 0
     with Baker(flat, o) as b:
         b.build_bvh(); b.rasterize(0); b.trace(0); b.resolve(0); b.download(0)
         if structure == "reference":

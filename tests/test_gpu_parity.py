@@ -38,13 +38,14 @@ SCENES = {
 }
 
 
+@pytest.mark.parametrize("adaptive", [0, 1])
 @pytest.mark.parametrize("builder", [0, 1])
 @pytest.mark.parametrize("name", ["cube", "two_section", "sphere", "terrain", "floor_wall", "plane"])
-def test_bvh_nodes_bit_exact(engine, orc, name, builder):
-    """builder 0: LBVH (build_hlbvh.cl); builder 1: PLOC.  Topology, boxes, leaf order, depth."""
+def test_bvh_nodes_bit_exact(engine, orc, name, builder, adaptive):
+    """builder 0: LBVH (build_hlbvh.cl); builder 1: PLOC; adaptive: the Morton bit order.  Topology, boxes, leaf order, depth."""
     flat = FlatScene(SCENES[name]())
-    ref_nodes, ref_depth = orc.bvh_build(orc.scene_triangles(flat.desc), builder)
-    with Baker(flat, make_options(orc, bvh_builder=builder)) as b:
+    ref_nodes, ref_depth = orc.bvh_build(orc.scene_triangles(flat.desc), builder, adaptive)
+    with Baker(flat, make_options(orc, bvh_builder=builder, morton_adaptive=adaptive)) as b:
         b.build_bvh()
         nodes = b.nodes()
         st = b.stats()
@@ -358,7 +359,12 @@ def test_ploc_builder_end_to_end(engine, orc, name, mode):
     if opt.use_any_hit:
         assert np.array_equal(ref0["total_bits"], ref["total_bits"])
     if name != "cube_inward":
-        assert st1.inner_visits < st0.inner_visits
+        assert st1.inner_visits < 1.02 * st0.inner_visits      # with the adaptive Morton order the two builders are level on flat scenes
+        # ... and that order is what helps a flat scene: the strict x, y, z interleave visits more nodes
+        if name == "terrain":
+            nodes_xyz, _ = orc.bvh_build(orc.scene_triangles(flat.desc), 1, 0)
+            _, st_xyz = orc.trace(nodes_xyz, surfels, sidx, opt, m.width, m.height, hemi, threads=8)
+            assert st1.inner_visits < st_xyz.inner_visits
 
 
 # ---- section visibility and material range ---------------------------------------------------
