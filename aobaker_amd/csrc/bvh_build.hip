@@ -472,13 +472,10 @@ void k_ploc_init(uint32_t n, uint32_t* __restrict__ cl)
     if (i < n) cl[i] = n - 1 + i;
 }
 
-__global__ __launch_bounds__(kBlock)
-void k_ploc_nn(const uint32_t* __restrict__ cl, uint32_t m, const Box* __restrict__ bounds, int radius, int forced,
-               uint32_t* __restrict__ nn)
+// the position of cluster i's nearest neighbour within `radius` places (merged surface area; ties: the lower position)
+__device__ __forceinline__ uint32_t ploc_nearest(const uint32_t* cl, uint32_t m, const Box* bounds, int radius, int forced, uint32_t i)
 {
-    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= m) return;
-    if (forced) { nn[i] = (i ^ 1u) < m ? (i ^ 1u) : i; return; }      // safety net: plain pairing halves the list
+    if (forced) return (i ^ 1u) < m ? (i ^ 1u) : i;                   // safety net: plain pairing halves the list
     const Box me = bounds[cl[i]];
     const uint32_t lo = i > (uint32_t)radius ? i - (uint32_t)radius : 0u;
     const uint32_t hi = i + (uint32_t)radius < m - 1 ? i + (uint32_t)radius : m - 1;
@@ -488,7 +485,15 @@ void k_ploc_nn(const uint32_t* __restrict__ cl, uint32_t m, const Box* __restric
         const float a = merged_area(me, bounds[cl[j]]);
         if (a < best || bj == i) { best = a; bj = j; }
     }
-    nn[i] = bj;
+    return bj;
+}
+
+__global__ __launch_bounds__(kBlock)
+void k_ploc_nn(const uint32_t* __restrict__ cl, uint32_t m, const Box* __restrict__ bounds, int radius, int forced,
+               uint32_t* __restrict__ nn)
+{
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < m) nn[i] = ploc_nearest(cl, m, bounds, radius, forced, i);
 }
 
 // alive: the cluster survives (possibly as the new merged node); merge: it is the lower half of a mutual pair
@@ -557,19 +562,16 @@ void k_ploc_scan(uint2* sums, uint32_t nblocks, uint32_t* __restrict__ totals_ho
     if (threadIdx.x == 0) { sums[nblocks] = carry_s; totals_host_visible[0] = carry_s.x; totals_host_visible[1] = carry_s.y; }
 }
 
-__global__ __launch_bounds__(kBlock)
-void k_ploc_emit(const uint32_t* __restrict__ cl, const uint32_t* __restrict__ nn, uint32_t m, const uint2* __restrict__ offsets,
-                 uint32_t created, uint32_t n, uint32_t* __restrict__ nxt, uint32_t* __restrict__ child_left,
-                 uint32_t* __restrict__ child_right, uint32_t* __restrict__ parent, Box* __restrict__ bounds)
+// one tile of the compaction: survivors keep their order, the lower half of a mutual pair becomes the merged node
+__device__ __forceinline__ void ploc_emit_tile(const uint32_t* cl, const uint32_t* nn, uint32_t m, uint32_t base, uint2 off,
+                                               uint32_t created, uint32_t n, uint32_t* nxt, uint32_t* child_left,
+                                               uint32_t* child_right, uint32_t* parent, Box* bounds, uint2* total_out)
 {
-    const uint32_t base = blockIdx.x * kPlocTile + threadIdx.x * kPlocItems;
     uint32_t al[kPlocItems], mg[kPlocItems];
     uint2 c = make_uint2(0, 0);
 #pragma unroll
     for (int k = 0; k < kPlocItems; k++) { ploc_flags(nn, m, base + k, al[k], mg[k]); c.x += al[k]; c.y += mg[k]; }
-    uint2 total;
-    uint2 ex = block_exclusive_scan2(c, &total);
-    const uint2 off = offsets[blockIdx.x];
+    const uint2 ex = block_exclusive_scan2(c, total_out);
     uint32_t pos = off.x + ex.x, mk = off.y + ex.y;
 #pragma unroll
     for (int k = 0; k < kPlocItems; k++) {
@@ -589,6 +591,85 @@ void k_ploc_emit(const uint32_t* __restrict__ cl, const uint32_t* __restrict__ n
             parent[a] = id; parent[b2] = id;
         }
         nxt[pos++] = id;
+    }
+}
+
+__global__ __launch_bounds__(kBlock)
+void k_ploc_emit(const uint32_t* __restrict__ cl, const uint32_t* __restrict__ nn, uint32_t m, const uint2* __restrict__ offsets,
+                 uint32_t created, uint32_t n, uint32_t* __restrict__ nxt, uint32_t* __restrict__ child_left,
+                 uint32_t* __restrict__ child_right, uint32_t* __restrict__ parent, Box* __restrict__ bounds)
+{
+    uint2 total;
+    ploc_emit_tile(cl, nn, m, blockIdx.x * kPlocTile + threadIdx.x * kPlocItems, offsets[blockIdx.x], created, n, nxt,
+                   child_left, child_right, parent, bounds, &total);
+}
+
+// The last rounds — once the list fits one tile — in ONE launch: the same three steps per round, separated by
+// workgroup barriers instead of launches and a host read-back, with the cluster list, its boxes and the neighbour
+// indices in LDS (on the 1 M-triangle terrain two thirds of the rounds work on fewer than 1024 clusters).
+__global__ __launch_bounds__(kBlock)
+void k_ploc_tail(const uint32_t* __restrict__ cl_in, uint32_t m, uint32_t created, uint32_t n, int iter, int radius,
+                 uint32_t* __restrict__ child_left, uint32_t* __restrict__ child_right, uint32_t* __restrict__ parent,
+                 Box* __restrict__ bounds)
+{
+    __shared__ Box s_box[2][kPlocTile];
+    __shared__ uint32_t s_cl[2][kPlocTile];
+    __shared__ uint32_t s_nn[kPlocTile];
+    for (uint32_t i = threadIdx.x; i < m; i += kBlock) { const uint32_t id = cl_in[i]; s_cl[0][i] = id; s_box[0][i] = bounds[id]; }
+    __syncthreads();
+    int cur = 0;
+    while (m > 1) {
+        const int forced = iter >= 256;
+#pragma unroll
+        for (int k = 0; k < kPlocItems; k++) {
+            const uint32_t i = threadIdx.x * kPlocItems + k;
+            if (i >= m) continue;
+            uint32_t bj = (i ^ 1u) < m ? (i ^ 1u) : i;                 // forced: plain pairing (ploc_nearest)
+            if (!forced) {
+                const Box me = s_box[cur][i];
+                const uint32_t lo = i > (uint32_t)radius ? i - (uint32_t)radius : 0u;
+                const uint32_t hi = i + (uint32_t)radius < m - 1 ? i + (uint32_t)radius : m - 1;
+                float best = INFINITY; bj = i;
+                for (uint32_t j = lo; j <= hi; j++) {
+                    if (j == i) continue;
+                    const float a = merged_area(me, s_box[cur][j]);
+                    if (a < best || bj == i) { best = a; bj = j; }
+                }
+            }
+            s_nn[i] = bj;
+        }
+        __syncthreads();
+        const uint32_t base = threadIdx.x * kPlocItems;
+        uint32_t al[kPlocItems], mg[kPlocItems];
+        uint2 c = make_uint2(0, 0);
+#pragma unroll
+        for (int k = 0; k < kPlocItems; k++) { ploc_flags(s_nn, m, base + k, al[k], mg[k]); c.x += al[k]; c.y += mg[k]; }
+        uint2 total;
+        const uint2 ex = block_exclusive_scan2(c, &total);
+        uint32_t pos = ex.x, mk = ex.y;
+#pragma unroll
+        for (int k = 0; k < kPlocItems; k++) {
+            const uint32_t i = base + k;
+            if (!al[k]) continue;
+            uint32_t id = s_cl[cur][i];
+            Box u = s_box[cur][i];
+            if (mg[k]) {
+                const uint32_t j = s_nn[i], a = id, b2 = s_cl[cur][j];
+                id = n - 2u - (created + mk);                          // as ploc_emit_tile
+                mk++;
+                const Box bb = s_box[cur][j];
+#pragma unroll
+                for (int q = 0; q < 3; q++) { u.pmin[q] = fminf(u.pmin[q], bb.pmin[q]); u.pmax[q] = fmaxf(u.pmax[q], bb.pmax[q]); }
+                bounds[id] = u;
+                child_left[id] = a; child_right[id] = b2;
+                parent[a] = id; parent[b2] = id;
+            }
+            s_cl[cur ^ 1][pos] = id; s_box[cur ^ 1][pos] = u;
+            pos++;
+        }
+        __syncthreads();
+        if (total.x >= m || total.y == 0) iter = 256;                  // no progress (never observed): pair up next round
+        else { m = total.x; created += total.y; cur ^= 1; iter++; }
     }
 }
 
@@ -613,7 +694,7 @@ static int build_ploc(AobBake* b, uint32_t n)
     hipLaunchKernelGGL(k_ploc_init, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, cl[0]);
     uint32_t m = n, created = 0;
     int cur = 0, iter = 0;
-    while (m > 1) {
+    while (m > (uint32_t)kPlocTile) {
         const int forced = iter >= 256;                                 // never observed; guarantees termination
         const uint32_t tiles = (m + kPlocTile - 1) / kPlocTile;
         hipLaunchKernelGGL(k_ploc_nn, dim3(blocks_for(m)), dim3(kBlock), 0, s, cl[cur], m, b->node_bounds, kPlocRadius, forced, nn);
@@ -627,6 +708,8 @@ static int build_ploc(AobBake* b, uint32_t n)
         if (alive >= m || merged == 0) { set_error("PLOC made no progress (m=%u)", m); return AOB_ERR_DEVICE; }
         m = alive; created += merged; cur ^= 1; iter++;
     }
+    if (m > 1) hipLaunchKernelGGL(k_ploc_tail, dim3(1), dim3(kBlock), 0, s, cl[cur], m, created, n, iter, kPlocRadius,
+                                  b->child_left, b->child_right, b->parent, b->node_bounds);
     hipLaunchKernelGGL(k_set_root_parent, dim3(1), dim3(64), 0, s, b->parent);
     hipLaunchKernelGGL(k_leaf_depth, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, b->parent, b->depth_dev);
     return AOB_OK;
