@@ -468,7 +468,7 @@ uint64_t orc_bvh_build_ex(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes
          * `radius` places left and right for the neighbour with the smallest merged surface area (ties: the
          * lower position); mutual nearest neighbours merge; the list is compacted; repeat.  Node ids are final
          * from the start: leaf at position p is n-1+p, the k-th inner node created is n-2-k (root = 0). */
-        const int64_t radius = 8;
+        const int64_t radius = 2;       /* kPlocRadius of the library */
         for (int64_t p = 0; p < N; p++) bounds[N - 1 + p] = pb[keys[p].idx];
         uint32_t* cl = (uint32_t*)malloc(4 * n); uint32_t* nxt = (uint32_t*)malloc(4 * n); uint32_t* nn = (uint32_t*)malloc(4 * n);
         for (int64_t p = 0; p < N; p++) cl[p] = (uint32_t)(N - 1 + p);
