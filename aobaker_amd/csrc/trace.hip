@@ -9,9 +9,10 @@
 // (intersect_bvh2_lds.cl:78,123-153), are scored in registers and added to per-surfel
 // LDS accumulators; each texel's result cell is written once.
 //
-// Work distribution.  A workgroup is ONE wavefront and owns 64 consecutive surfels of the
-// trace order (an 8x8 texel tile, raster.hip).  Three sections of one loop are entered on
-// wave-wide votes:
+// Work distribution.  The launch is as many one-wavefront workgroups as the chip holds; each takes
+// work units off a per-XCD queue until the queues are dry.  A unit is 64 consecutive surfels of the
+// trace order (an 8x8 texel tile, raster.hip) x one part of the samples.  Three sections of one loop
+// are entered on wave-wide votes:
 //   refill   once `refill_idle` lanes have no ray, they pop rays from the wave's queue; when
 //            the queue runs dry ALL 64 lanes generate the next sample of the 64 surfels —
 //            lane = surfel, every lane produces a ray — so the sampler (a hash, a sincos
@@ -21,9 +22,10 @@
 //            Möller–Trumbore once `leaf_wait` are waiting;
 //   inner    every lane at an inner node does its slab tests each iteration.
 // A ray is traced by whichever lane pops it; it carries its surfel's slot and adds its score
-// to that surfel's 64-bit LDS accumulators (int32-range quantised sums in the reference's
-// mode, exact Q32.32 sums in float mode), so the result does not depend on which lane traced
-// which ray and is bit-identical to the oracle's sequential loop.  Each ray still visits its
+// to that surfel's LDS accumulators (int32-range quantised sums in the reference's mode, exact
+// Q32.32 sums in float mode, a plain count of unoccluded samples when every weight is 1), so the
+// result does not depend on which lane traced which ray and is bit-identical to the oracle's
+// sequential loop.  Each ray still visits its
 // nodes in exactly the reference's depth-first order.
 //
 // The hot data is the node array (64 B per inner visit, 48 B per leaf visit, shared by
@@ -93,8 +95,8 @@ __device__ __forceinline__ long long f2fix(float v)
 // instead of four) and the 48-byte leaf triangles.  QUANT 2: the same boxes in 4-ary nodes (AobBvh4QNode,
 // every second level collapsed): fewer slab tests per ray and half the loop iterations.
 #ifndef AOB_TRACE_WAVES
-#define AOB_TRACE_WAVES 8          // waves per SIMD the register allocator must leave room for (<= 64 VGPRs):
-                                   // measured 4.98 / 5.14 / 5.55 Grays/s at 6 / 7 / 8 — latency hiding beats the few spills
+#define AOB_TRACE_WAVES 8          // waves per SIMD the register allocator must leave room for (<= 64 VGPRs): the walk
+                                   // lives on latency hiding — 27 instead of 32 wavefronts per CU cost 11 %
 #endif
 template <int SAMPLER, int ANYHIT, int ACCUM, int LDS_N, int QUANT, int MASKED>
 __global__ __launch_bounds__(kWave, AOB_TRACE_WAVES)
