@@ -415,3 +415,37 @@ def test_section_visibility_needs_a_lane_per_ray_structure(engine, orc):
     engine.Options = opt
     with pytest.raises(capi.AobError):
         engine.Bake(_flagged_scene(1))
+
+
+# ---- deep traversal stacks: entries beyond the 8 / 11 kept in LDS go to the HBM array -----------------------------
+def _hairball_scene(bpc, n=3000, seed=11):
+    """A floor patch under a ball of long thin triangles in random directions: their boxes all overlap, so a ray
+    defers many children at once (the oracle's walk of the same tree reaches stack depths far beyond 11)."""
+    from aobaker_amd.scene import BakeObject, RenderMesh, Section, make_vertices
+    rng = np.random.default_rng(seed)
+    sc = scenes.plane_scene(24, bpc=bpc)
+    c = np.float32([0.5, 0.6, 0.5])
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    w = rng.normal(size=(n, 3)); w -= (w * d).sum(1, keepdims=True) * d; w /= np.linalg.norm(w, axis=1, keepdims=True)
+    o = c + rng.normal(scale=0.05, size=(n, 3))
+    v = np.stack([o - 0.45 * d, o + 0.45 * d, o + 0.02 * w], axis=1).astype(np.float32).reshape(-1, 3)
+    nrm = np.repeat(np.cross(d, w).astype(np.float32), 3, axis=0)
+    uv = np.zeros((3 * n, 2), dtype=np.float32)
+    obj = sc.AddObject(BakeObject("hairball"))
+    obj.AddSection(Section("Geometry", RenderMesh(make_vertices(v, nrm, uv), np.arange(3 * n, dtype=np.uint32)), None))
+    return sc
+
+
+@pytest.mark.parametrize("structure", [(4, 1), (2, 1), (2, 0), (4, 0)])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_deep_stacks_spill_to_hbm_and_come_back(engine, orc, mode, structure):
+    opt = make_options(orc, sample_count=16, bvh_width=structure[0], bvh_quantised=structure[1], **MODES[mode])
+    bpc = 1 if opt.accumulate == capi.ACCUMULATE_QUANTISED else 4
+    gpu_scene, cpu_scene = _hairball_scene(bpc), _hairball_scene(bpc)
+    engine.Options = opt
+    engine.Bake(gpu_scene)
+    orc.bake(FlatScene(cpu_scene).desc, opt, threads=8)
+    g, c = gpu_scene.GetMaterial(0).GetAOTexture(), cpu_scene.GetMaterial(0).GetAOTexture()
+    assert np.array_equal(g.GetData(), c.GetData())
+    ao = g.ao()
+    assert 0.02 < ao.mean() < 0.9          # the ball occludes a good part of the sky, not all of it
