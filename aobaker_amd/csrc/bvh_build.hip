@@ -292,6 +292,20 @@ void k_emit_nodes(uint32_t n, const uint32_t* __restrict__ child_left, const uin
 // BVH2 boxes, unchanged, so a ray tests a subset of the boxes the BVH2 walk would test.
 // Layout (AobBvh4Node): lo[j] = {min, ref_j}, hi[j] = {max, 0}; the quad of lanes that traces a
 // ray fetches lo[0..3] with one 64-byte access and hi[0..3] with another.
+// PAIRS (the lane-per-ray quantised walk): a BVH2 node whose children are the leaves at Morton positions p and p + 1
+// is not a node of its own but ONE child slot, ref = AOB_LEAF_FLAG | AOB_PAIR_FLAG | p — a leaf of two triangles that
+// lie next to each other in AobLeafTri[].  96 % of the terrain's triangles, 87 % of the sphere's and 82 % of the
+// rocks' come in such pairs (the two halves of a grid cell): 39 % fewer leaf visits and 3 % fewer node visits per ray
+// for 4 % more triangle tests.
+__device__ __forceinline__ bool is_leaf_pair(uint32_t c, uint32_t leaf_base, const uint32_t* __restrict__ child_left,
+                                             const uint32_t* __restrict__ child_right)
+{
+    if (c >= leaf_base) return false;
+    const uint32_t l = child_left[c], r = child_right[c];
+    return l >= leaf_base && r == l + 1u;
+}
+
+template <int PAIRS>
 __global__ __launch_bounds__(kBlock)
 void k_collapse4(uint32_t n, const uint32_t* __restrict__ parent, const uint32_t* __restrict__ child_left,
                  const uint32_t* __restrict__ child_right, const Box* __restrict__ node_bounds,
@@ -303,12 +317,13 @@ void k_collapse4(uint32_t n, const uint32_t* __restrict__ parent, const uint32_t
     for (uint32_t a = i; parent[a] != 0xffffffffu; a = parent[a]) depth++;
     if (depth & 1u) return;
     const uint32_t leaf_base = n - 1;
+    if (PAIRS && i != 0u && is_leaf_pair(i, leaf_base, child_left, child_right)) return;     // a child slot of its grandparent
     uint32_t kids[4]; int k = 0;
     const uint32_t c2[2] = { child_left[i], child_right[i] };
 #pragma unroll
     for (int s = 0; s < 2; s++) {
         uint32_t c = c2[s];
-        if (c < leaf_base) { kids[k++] = child_left[c]; kids[k++] = child_right[c]; }
+        if (c < leaf_base && !(PAIRS && is_leaf_pair(c, leaf_base, child_left, child_right))) { kids[k++] = child_left[c]; kids[k++] = child_right[c]; }
         else kids[k++] = c;
     }
     float4* out = nodes4 + 8ull * i;
@@ -316,7 +331,8 @@ void k_collapse4(uint32_t n, const uint32_t* __restrict__ parent, const uint32_t
         if (j < k) {
             const uint32_t c = kids[j];
             const Box b = node_bounds[c];
-            const uint32_t ref = c < leaf_base ? c : (0x80000000u | (c - leaf_base));
+            uint32_t ref = c < leaf_base ? c : (0x80000000u | (c - leaf_base));
+            if (PAIRS && is_leaf_pair(c, leaf_base, child_left, child_right)) ref = 0xC0000000u | (child_left[c] - leaf_base);
             out[j] = make_float4(b.pmin[0], b.pmin[1], b.pmin[2], __uint_as_float(ref));
             out[4 + j] = make_float4(b.pmax[0], b.pmax[1], b.pmax[2], 0.0f);
         } else {
@@ -769,7 +785,10 @@ int build_bvh(AobBake* b)
     b->node4_count = n == 1 ? 1 : n - 1;
     AOB_HIP(hipMemsetAsync(b->nodes4, 0, sizeof(float4) * 8 * b->node4_count, s));
     if (n == 1) hipLaunchKernelGGL(k_single_leaf4, dim3(1), dim3(64), 0, s, b->prim_bounds, b->nodes4);
-    else hipLaunchKernelGGL(k_collapse4, dim3(blocks_for(n - 1)), dim3(kBlock), 0, s, (uint32_t)n, b->parent, b->child_left,
+    else if (b->opt.bvh_width == 4 && b->opt.bvh_quantised)
+        hipLaunchKernelGGL(k_collapse4<1>, dim3(blocks_for(n - 1)), dim3(kBlock), 0, s, (uint32_t)n, b->parent, b->child_left,
+                           b->child_right, b->node_bounds, b->nodes4);
+    else hipLaunchKernelGGL(k_collapse4<0>, dim3(blocks_for(n - 1)), dim3(kBlock), 0, s, (uint32_t)n, b->parent, b->child_left,
                             b->child_right, b->node_bounds, b->nodes4);
     hipLaunchKernelGGL(k_quant_frame, dim3(1), dim3(64), 0, s, b->scene_bounds_enc, b->quant_frame);
     if (n > 1) hipLaunchKernelGGL(k_emit_nodes_q, dim3(blocks_for(n - 1)), dim3(kBlock), 0, s, (uint32_t)n, b->child_left,

@@ -317,16 +317,36 @@ void k_trace(TraceParams p)
         const uint64_t inner_m = __ballot(inner);
         if (__popcll(__ballot(at_leaf)) >= p.leaf_wait || inner_m == 0ull) {
             if (at_leaf) {
-                const float4* np = QUANT ? p.leaf_tris + 3ull * (addr - p.leaf_base) : p.nodes + 4ull * addr;
-                const float4 n0 = np[0], n1 = np[1], n2 = np[2];
-                float t = intersect_triangle(org, dir, make_f3(n0.x, n0.y, n0.z), make_f3(n1.x, n1.y, n1.z),
-                                             make_f3(n2.x, n2.y, n2.z), closest_t);
-                if (MASKED) {
-                    // the ray mask of intersect_bvh2_lds.cl:163-166, by section: skip the triangles this ray must not see
-                    const uint32_t shape = __float_as_uint(QUANT ? n0.w : n1.w);
-                    const bool skip = shape == p.self_shape ? p.self_hidden != 0u
-                                                            : ((p.hidden_from_others[shape >> 5] >> (shape & 31u)) & 1u) != 0u;
-                    if (skip) t = closest_t;
+                // QUANT 2: the ref may name a PAIR of triangles, p and p + 1 (AOB_PAIR_FLAG): both are fetched in one go
+                const uint32_t lref = addr - p.leaf_base;
+                const bool pair = QUANT == 2 && (lref & 0x40000000u) != 0u;
+                const float4* np = QUANT ? p.leaf_tris + 3ull * (lref & 0x3fffffffu) : p.nodes + 4ull * addr;
+                float t;
+                {
+                    const float4 n0 = np[0], n1 = np[1], n2 = np[2];
+                    t = intersect_triangle(org, dir, make_f3(n0.x, n0.y, n0.z), make_f3(n1.x, n1.y, n1.z),
+                                           make_f3(n2.x, n2.y, n2.z), closest_t);
+                    if (MASKED) {
+                        // the ray mask of intersect_bvh2_lds.cl:163-166, by section: skip the triangles this ray must not see
+                        const uint32_t shape = __float_as_uint(QUANT ? n0.w : n1.w);
+                        const bool skip = shape == p.self_shape ? p.self_hidden != 0u
+                                                                : ((p.hidden_from_others[shape >> 5] >> (shape & 31u)) & 1u) != 0u;
+                        if (skip) t = closest_t;
+                    }
+                }
+                if (QUANT == 2 && pair) {
+                    // the second triangle against the same bound: min(t, t2) is what testing them one after the other gives.
+                    // (Fetched after the first test, not with it: 18 vertex registers at once spill the ray.)
+                    const float4 m0 = np[3], m1 = np[4], m2 = np[5];
+                    float t2 = intersect_triangle(org, dir, make_f3(m0.x, m0.y, m0.z), make_f3(m1.x, m1.y, m1.z),
+                                                  make_f3(m2.x, m2.y, m2.z), closest_t);
+                    if (MASKED) {
+                        const uint32_t shape = __float_as_uint(m0.w);
+                        const bool skip = shape == p.self_shape ? p.self_hidden != 0u
+                                                                : ((p.hidden_from_others[shape >> 5] >> (shape & 31u)) & 1u) != 0u;
+                        if (skip) t2 = closest_t;
+                    }
+                    t = fminf(t, t2);
                 }
                 const bool closer = t < closest_t;
                 if (closer) { closest_t = t; hit = true; }
@@ -552,7 +572,7 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
         p.bias = o.ray_bias;
         p.hidden_from_others = b->hidden_from_others;
         p.refill_idle = max(1, env_int("AOB_TRACE_REFILL_IDLE", 24));
-        p.leaf_wait = max(1, env_int("AOB_TRACE_LEAF_WAIT", 12));
+        p.leaf_wait = max(1, env_int("AOB_TRACE_LEAF_WAIT", 16));
         cosine_grid(o.sample_count, p.grid);
         // one launch per section: two sections of a material may cover the same texel, and
         // their contributions are added in section order (BakeEngine.cpp:473,659)

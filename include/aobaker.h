@@ -192,6 +192,10 @@ typedef struct AobBvhNode {
  * The two 64-byte halves are what the four lanes of a ray's quad fetch with one access each. */
 typedef struct AobBvh4Node { float lo[4][4]; float hi[4][4]; } AobBvh4Node;
 #define AOB_LEAF_FLAG 0x80000000u
+/* With bvh_width 4 and bvh_quantised 1 a leaf ref may also carry AOB_PAIR_FLAG: ref = AOB_LEAF_FLAG | AOB_PAIR_FLAG | p
+ * names the two triangles p and p + 1 of AobLeafTri[] (a BVH2 node whose children are those two leaves takes one
+ * child slot instead of being a node of its own).  AobBvh4Node[] and AobBvh4QNode[] of such a bake both carry them. */
+#define AOB_PAIR_FLAG 0x40000000u
 /* 32 B BVH2 node with quantised child boxes: q = 15-bit fixed point on the scene box (0..32767,
  * scale = extent / 32767), box.min rounded down, box.max rounded up; decode: frame.origin + q * frame.scale.
  * One word per axis and box, min in the low half: w0 = lmin.x | lmax.x<<16, w1 = lmin.y | lmax.y<<16,

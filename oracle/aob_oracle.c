@@ -719,6 +719,17 @@ uint64_t orc_rasterize_ex(const AobSceneDesc* scene, int32_t material, const Aob
  * BVH2 inner index; entries of collapsed-away levels stay zero), tris needs n entries. */
 uint64_t orc_bvh4_build(const AobBvhNode* nodes2, uint64_t node_count2, AobBvh4Node* nodes4, AobLeafTri* tris)
 {
+    return orc_bvh4_build_ex(nodes2, node_count2, nodes4, tris, 0);
+}
+
+/* a BVH2 node whose children are the leaves at Morton positions p and p + 1 (AOB_PAIR_FLAG) */
+static inline int is_leaf_pair(const AobBvhNode* nodes2, uint32_t c, uint32_t leaf_base)
+{
+    return c < leaf_base && nodes2[c].addr_left >= leaf_base && nodes2[c].addr_right == nodes2[c].addr_left + 1u;
+}
+
+uint64_t orc_bvh4_build_ex(const AobBvhNode* nodes2, uint64_t node_count2, AobBvh4Node* nodes4, AobLeafTri* tris, int pairs)
+{
     if (node_count2 == 0) return 0;
     const uint64_t n = (node_count2 + 1) / 2;
     const uint32_t leaf_base = (uint32_t)(n - 1);
@@ -760,19 +771,21 @@ uint64_t orc_bvh4_build(const AobBvhNode* nodes2, uint64_t node_count2, AobBvh4N
         const float* cmax[2] = { me->lmax_or_v1, me->rmax };
         for (int s2 = 0; s2 < 2; s2++) {
             const uint32_t c = c2[s2];
-            if (c < leaf_base) {
+            if (c < leaf_base && !(pairs && is_leaf_pair(nodes2, c, leaf_base))) {
                 const AobBvhNode* ch = &nodes2[c];
                 const uint32_t g[2] = { ch->addr_left, ch->addr_right };
                 const float* gmin[2] = { ch->lmin_or_v0, ch->rmin_or_v2 };
                 const float* gmax[2] = { ch->lmax_or_v1, ch->rmax };
                 for (int t = 0; t < 2; t++, k++) {
                     uint32_t ref = g[t] < leaf_base ? g[t] : (AOB_LEAF_FLAG | (g[t] - leaf_base));
+                    const int pair = pairs && is_leaf_pair(nodes2, g[t], leaf_base);
+                    if (pair) ref = AOB_LEAF_FLAG | AOB_PAIR_FLAG | (nodes2[g[t]].addr_left - leaf_base);
                     memcpy(nd->lo[k], gmin[t], 12); memcpy(&nd->lo[k][3], &ref, 4);
                     memcpy(nd->hi[k], gmax[t], 12); nd->hi[k][3] = 0.0f;
-                    if (g[t] < leaf_base) todo[top++] = g[t];
+                    if (g[t] < leaf_base && !pair) todo[top++] = g[t];
                 }
             } else {
-                uint32_t ref = AOB_LEAF_FLAG | (c - leaf_base);
+                uint32_t ref = c < leaf_base ? (AOB_LEAF_FLAG | AOB_PAIR_FLAG | (nodes2[c].addr_left - leaf_base)) : (AOB_LEAF_FLAG | (c - leaf_base));
                 memcpy(nd->lo[k], cmin[s2], 12); memcpy(&nd->lo[k][3], &ref, 4);
                 memcpy(nd->hi[k], cmax[s2], 12); nd->hi[k][3] = 0.0f;
                 k++;
@@ -1023,11 +1036,20 @@ static inline int traverse4q(const AobBvh4QNode* nq, uint64_t count4, const AobQ
             sp += nhit - 1;
             node = first;
         } else {
-            const AobLeafTri* tr = &tris[node & ~AOB_LEAF_FLAG];
+            /* a leaf is one triangle or — AOB_PAIR_FLAG — the two at p and p + 1, both tested against the same bound */
+            const AobLeafTri* tr = &tris[node & ~(AOB_LEAF_FLAG | AOB_PAIR_FLAG)];
             st->leaf_visits++;
             float t = intersect_triangle(o, d, f3_make(tr->v0[0], tr->v0[1], tr->v0[2]), f3_make(tr->v1[0], tr->v1[1], tr->v1[2]),
                                          f3_make(tr->v2[0], tr->v2[1], tr->v2[2]), closest_t);
             if (mask) { uint32_t shape; memcpy(&shape, &tr->v0[3], 4); if (mask_skips(mask, shape)) t = closest_t; }
+            if (node & AOB_PAIR_FLAG) {
+                const AobLeafTri* tr2 = tr + 1;
+                st->leaf_visits++;
+                float t2 = intersect_triangle(o, d, f3_make(tr2->v0[0], tr2->v0[1], tr2->v0[2]), f3_make(tr2->v1[0], tr2->v1[1], tr2->v1[2]),
+                                              f3_make(tr2->v2[0], tr2->v2[1], tr2->v2[2]), closest_t);
+                if (mask) { uint32_t shape; memcpy(&shape, &tr2->v0[3], 4); if (mask_skips(mask, shape)) t2 = closest_t; }
+                t = fminf(t, t2);
+            }
             if (t < closest_t) {
                 closest_t = t; hit = 1;
                 if (any_hit) break;
@@ -1316,7 +1338,7 @@ int orc_trace_ex(const AobBvhNode* nodes, uint64_t node_count,
         const uint64_t n = (node_count + 1) / 2;
         nodes4 = (AobBvh4Node*)malloc(sizeof(AobBvh4Node) * (n > 1 ? n - 1 : 1));
         tris = (AobLeafTri*)malloc(sizeof(AobLeafTri) * n);
-        job.node4_count = orc_bvh4_build(nodes, node_count, nodes4, tris);
+        job.node4_count = orc_bvh4_build_ex(nodes, node_count, nodes4, tris, opt->bvh_quantised != 0);
         job.nodes4 = nodes4; job.tris = tris;
     }
     AobBvh4QNode* nodes4q = NULL;

@@ -78,6 +78,9 @@ uint64_t orc_bvh_build_ex(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes
  * default GPU kernel walks with four lanes per ray; orc_trace uses it unless
  * AobOptions::bvh_width == 2.  nodes4: max(1, n-1) entries, tris: n entries. */
 uint64_t orc_bvh4_build(const AobBvhNode* nodes2, uint64_t node_count2, AobBvh4Node* nodes4, AobLeafTri* tris);
+/* pairs: BVH2 nodes whose children are the leaves p and p + 1 become one child slot (AOB_PAIR_FLAG) — what the library
+ * builds for bvh_width 4 with bvh_quantised 1 */
+uint64_t orc_bvh4_build_ex(const AobBvhNode* nodes2, uint64_t node_count2, AobBvh4Node* nodes4, AobLeafTri* tris, int pairs);
 
 /* The same BVH2 with 16-bit quantised child boxes (AobBvh2QNode, 32 B) that the lane-per-ray GPU
  * kernel walks when AobOptions::bvh_quantised is set (bvh_width 2).  out: max(1, n-1) entries. */

@@ -57,6 +57,7 @@ def load():
         "orc_bvh_build": (u64, [vp, u64, vp, P(u32)]),
         "orc_bvh_build_ex": (u64, [vp, u64, vp, P(u32), C.c_int, C.c_int]),
         "orc_bvh4_build": (u64, [vp, u64, vp, vp]),
+        "orc_bvh4_build_ex": (u64, [vp, u64, vp, vp, C.c_int]),
         "orc_bvh2q_build": (u64, [vp, u64, vp, vp]),
         "orc_bvh4q_build": (u64, [vp, u64, vp, vp]),
         "orc_rasterize": (u64, [P(capi.AobSceneDesc), i32, P(capi.AobOptions), vp, vp, u64]),
@@ -159,13 +160,17 @@ def bvh_build(tris, builder=None, adaptive=None):
     return nodes[:cnt], depth.value
 
 
-def bvh4_build(nodes2):
+def bvh4_build(nodes2, pairs=None):
+    """pairs: leaf pairs take one child slot (AOB_PAIR_FLAG); None = what the default options build (quantised 4-ary: yes)."""
     lib = load()
+    if pairs is None:
+        d = default_options()
+        pairs = d.bvh_width == 4 and d.bvh_quantised != 0
     nodes2 = np.ascontiguousarray(nodes2)
     n = (len(nodes2) + 1) // 2
     nodes4 = np.zeros(max(1, n - 1), dtype=capi.node4_dtype())
     tris = np.zeros(max(1, n), dtype=capi.leaf_tri_dtype())
-    cnt = int(lib.orc_bvh4_build(nodes2.ctypes.data if len(nodes2) else None, len(nodes2), nodes4.ctypes.data, tris.ctypes.data))
+    cnt = int(lib.orc_bvh4_build_ex(nodes2.ctypes.data if len(nodes2) else None, len(nodes2), nodes4.ctypes.data, tris.ctypes.data, int(bool(pairs))))
     return nodes4[:cnt], tris[:n]
 
 

@@ -388,15 +388,16 @@ def test_two_sections_sum_into_the_same_cells(orc):
 # ---- the 4-ary collapse --------------------------------------------------------------------
 @pytest.mark.parametrize("make", [lambda: scenes.terrain_scene(grid=48, atlas=64), lambda: scenes.sphere_scene(n=24, atlas=64),
                                   lambda: scenes.cube_scene(64), lambda: scenes.plane_scene(8)])
-def test_bvh4_is_a_collapse_of_the_bvh2(orc, make):
+@pytest.mark.parametrize("pairs", [False, True])
+def test_bvh4_is_a_collapse_of_the_bvh2(orc, make, pairs):
     flat = FlatScene(make())
     nodes2, depth = orc.bvh_build(orc.scene_triangles(flat.desc))
-    nodes4, tris = orc.bvh4_build(nodes2)
+    nodes4, tris = orc.bvh4_build(nodes2, pairs=pairs)
     n = (len(nodes2) + 1) // 2
     assert len(tris) == n and len(nodes4) == max(1, n - 1)
     refs = nodes4["lo"][:, :, 3].view(np.uint32)
     # walk from the root: every triangle is reached exactly once, every visited node is non-empty
-    seen, stack, visited = [], [0], 0
+    seen, stack, visited, n_pairs = [], [0], 0, 0
     while stack:
         i = stack.pop(); visited += 1
         for j in range(4):
@@ -406,14 +407,24 @@ def test_bvh4_is_a_collapse_of_the_bvh2(orc, make):
             lo, hi = nodes4["lo"][i, j, :3], nodes4["hi"][i, j, :3]
             assert (lo <= hi).all()
             if r & 0x80000000:
-                p = r & 0x7fffffff
-                seen.append(p)
-                v = np.stack([tris["v0"][p, :3], tris["v1"][p, :3], tris["v2"][p, :3]])
+                p = r & 0x3fffffff
+                ps = [p, p + 1] if r & 0x40000000 else [p]          # AOB_PAIR_FLAG: the triangles p and p + 1
+                n_pairs += len(ps) - 1
+                seen += ps
+                v = np.concatenate([np.stack([tris["v0"][q, :3], tris["v1"][q, :3], tris["v2"][q, :3]]) for q in ps])
                 assert np.array_equal(lo, v.min(axis=0)) and np.array_equal(hi, v.max(axis=0))
             else:
                 stack.append(r)
     assert sorted(seen) == list(range(n))
-    if n > 1:
+    assert (n_pairs > 0) == (pairs and n > 2)
+    if pairs and n > 2:
+        # a pair is a BVH2 node whose children are adjacent leaves, and never a node of its own
+        inner = nodes2[:n - 1]
+        is_pair = (inner["addr_left"] >= n - 1) & (inner["addr_right"] == inner["addr_left"] + 1)
+        is_pair[0] = False
+        assert n_pairs == int(is_pair.sum())
+        assert (refs[is_pair][:, 0] == 0).all()                          # their own records stay empty
+    if n > 1 and not pairs:
         # the boxes are BVH2 boxes: the root's four children are the root's grandchildren
         root2 = nodes2[0]
         kids = []
