@@ -106,3 +106,18 @@ def test_scene_file_roundtrip(tmp_path):
     assert raw[:4] == b"AOBS" and struct.unpack("<III", raw[4:16]) == (1, 1, 1)
     mesh = sc.GetObject(0).GetSection(0).GetPreviewMesh()
     assert len(raw) == 16 + 16 + 36 + 4 + 12 + 48 * mesh.GetVertexCount() + 4 * mesh.GetIndexCount()
+
+
+def test_bench_helpers_and_committed_traffic():
+    """bench.py's roofline inputs that do not need a GPU: the committed PMC traffic figure and the texel subsample."""
+    import json
+    import os
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    traffic = bench.measured_traffic()
+    committed = json.load(open(os.path.join(root, "profiles", "traffic.json")))
+    assert traffic == committed["k_trace_hbm_bytes_per_launch"] and 1e9 < traffic < 1e12
+    surfels = np.zeros(64 * 64, dtype=capi.surfel_dtype())
+    surfels["texel_x"], surfels["texel_y"] = np.tile(np.arange(64), 64), np.repeat(np.arange(64), 64)
+    sub = bench._subsample(surfels, 32)
+    assert len(sub) == 4 and set(zip(sub["texel_x"].tolist(), sub["texel_y"].tolist())) == {(0, 0), (32, 0), (0, 32), (32, 32)}
