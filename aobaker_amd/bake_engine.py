@@ -43,7 +43,12 @@ class Baker:
 
     # stages -------------------------------------------------------------------
     def build_bvh(self): capi.check(self.lib.aob_bake_build_bvh(self.handle))
-    def rasterize(self, material=0): capi.check(self.lib.aob_bake_rasterize(self.handle, material))
+    def rasterize(self, material=0, rows=None):
+        """rows = (begin, end): only that strip of texel rows (a rank's share of a multi-GPU bake)."""
+        if rows is None:
+            capi.check(self.lib.aob_bake_rasterize(self.handle, material))
+        else:
+            capi.check(self.lib.aob_bake_rasterize_rows(self.handle, material, int(rows[0]), int(rows[1])))
     def trace(self, material=0, begin=0, end=capi.UINT64_MAX):
         capi.check(self.lib.aob_bake_trace(self.handle, material, begin, end))
     def resolve(self, material=0): capi.check(self.lib.aob_bake_resolve(self.handle, material))

@@ -162,7 +162,7 @@ EXPORTED_SYMBOLS = [
     "aob_bake_copy_surfels", "aob_bake_copy_results", "aob_bake_results_device_ptr",
     "aob_bake_image_device_ptr", "aob_bake_stream", "aob_bake_last_trace_ms",
     "aob_bake_shard_bounds", "aob_bake_node4_count", "aob_bake_copy_nodes4", "aob_bake_copy_leaf_tris",
-    "aob_bake_copy_nodes2q", "aob_bake_quant_frame", "aob_bake_copy_nodes4q", "aob_bake_node4q_count",
+    "aob_bake_copy_nodes2q", "aob_bake_quant_frame", "aob_bake_copy_nodes4q", "aob_bake_node4q_count", "aob_bake_rasterize_rows",
 ]
 
 
@@ -216,6 +216,7 @@ def load() -> C.CDLL:
         "aob_bake_destroy": (None, [vp]),
         "aob_bake_build_bvh": (C.c_int, [vp]),
         "aob_bake_rasterize": (C.c_int, [vp, i32]),
+        "aob_bake_rasterize_rows": (C.c_int, [vp, i32, i32, i32]),
         "aob_bake_trace": (C.c_int, [vp, i32, u64, u64]),
         "aob_bake_resolve": (C.c_int, [vp, i32]),
         "aob_bake_download": (C.c_int, [vp, i32, vp, C.c_size_t]),

@@ -45,6 +45,7 @@ struct DeviceMesh {
 struct DeviceMaterial {
     int32_t width = 0, height = 0, channels = 0, bytes_per_channel = 0;
     float ao_max_range = 0.0f;            // AobMaterialDesc::ao_max_range
+    int32_t window_rows = 0;              // texel rows the last rasterisation covered (height, or a strip of it)
     uint8_t* host_data = nullptr;
     uint32_t* cover = nullptr;            // W*H: winning triangle index + 1, per section pass
     uint32_t* block_sums = nullptr;       // scan partials
@@ -120,7 +121,7 @@ struct AobBake {
 namespace aob {
 // stage launchers (each enqueues on bake->stream; only the ones that say so synchronise)
 int build_bvh(AobBake* b);                                   // bvh_build.hip
-int rasterize_material(AobBake* b, int32_t material);        // raster.hip (syncs once per section)
+int rasterize_material(AobBake* b, int32_t material, int32_t row_begin, int32_t row_end);   // raster.hip (syncs once per section)
 int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end);   // trace.hip
 int resolve_material(AobBake* b, int32_t material);          // resolve.hip
 int trace4_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end);  // trace4.hip

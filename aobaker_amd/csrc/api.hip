@@ -371,7 +371,17 @@ int aob_bake_build_bvh(AobBake* b)
 int aob_bake_rasterize(AobBake* b, int32_t material)
 {
     AOB_TRY(check_bake(b, material, true));
-    return rasterize_material(b, material);
+    return rasterize_material(b, material, 0, b->materials[material].height);
+}
+
+int aob_bake_rasterize_rows(AobBake* b, int32_t material, int32_t row_begin, int32_t row_end)
+{
+    AOB_TRY(check_bake(b, material, true));
+    if (row_begin < 0 || row_end < row_begin || row_end > b->materials[material].height) {
+        set_error("rows [%d, %d) outside the %d-row atlas", row_begin, row_end, b->materials[material].height);
+        return AOB_ERR_INVALID_ARGUMENT;
+    }
+    return rasterize_material(b, material, row_begin, row_end);
 }
 
 int aob_bake_trace(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
@@ -419,7 +429,7 @@ int aob_bake_run_device(AobBake* b)
     float ms_r = 0.f, ms_t = 0.f, ms_p = 0.f;
     for (size_t i = 0; i < b->materials.size(); i++) {
         AOB_HIP(hipEventRecord(b->ev[4], s));
-        AOB_TRY(rasterize_material(b, (int32_t)i));
+        AOB_TRY(rasterize_material(b, (int32_t)i, 0, b->materials[i].height));
         AOB_HIP(hipEventRecord(b->ev[5], s));
         AOB_TRY(ensure_depth(b));
         AOB_TRY(trace_range(b, (int32_t)i, 0, UINT64_MAX));

@@ -48,7 +48,7 @@ __device__ __forceinline__ bool snap_uv(const float* uv, int32_t W, int32_t H, i
 // One wavefront per triangle; the 64 lanes stride over the texels of its bounding box.
 __global__ __launch_bounds__(kBlock)
 void k_cover(const float* __restrict__ uvs, const uint32_t* __restrict__ indices, uint32_t ntri,
-             int32_t W, int32_t H, uint32_t* __restrict__ cover)
+             int32_t W, int32_t H, int32_t row_begin, int32_t row_end, uint32_t* __restrict__ cover)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t t = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -64,7 +64,8 @@ void k_cover(const float* __restrict__ uvs, const uint32_t* __restrict__ indices
     int64_t minx = min(min(X[0], X[1]), X[2]), maxx = max(max(X[0], X[1]), X[2]);
     int64_t miny = min(min(Y[0], Y[1]), Y[2]), maxy = max(max(Y[0], Y[1]), Y[2]);
     int64_t px0 = max((minx - 128 + 255) >> 8, (int64_t)0), px1 = min((maxx - 128) >> 8, (int64_t)W - 1);
-    int64_t py0 = max((miny - 128 + 255) >> 8, (int64_t)0), py1 = min((maxy - 128) >> 8, (int64_t)H - 1);
+    // only the texel rows [row_begin, row_end) of the atlas are wanted (a rank's strip; the whole atlas by default)
+    int64_t py0 = max((miny - 128 + 255) >> 8, (int64_t)row_begin), py1 = min((maxy - 128) >> 8, (int64_t)row_end - 1);
     if (px1 < px0 || py1 < py0) return;
     const int64_t b0 = edge_top_left(X[0], Y[0], X[1], Y[1]) ? 0 : -1;
     const int64_t b1 = edge_top_left(X[1], Y[1], X[2], Y[2]) ? 0 : -1;
@@ -336,9 +337,10 @@ static int ensure_surfel_capacity(AobBake* b, DeviceMaterial& m, uint64_t need)
     return AOB_OK;
 }
 
-int rasterize_material(AobBake* b, int32_t material)
+int rasterize_material(AobBake* b, int32_t material, int32_t row_begin, int32_t row_end)
 {
     DeviceMaterial& m = b->materials[material];
+    m.window_rows = row_end - row_begin;
     hipStream_t s = b->stream;
     const uint64_t cells = (uint64_t)m.width * m.height;
     m.surfel_count = 0;
@@ -353,7 +355,7 @@ int rasterize_material(AobBake* b, int32_t material)
         if (mesh.triangle_count) {
             uint32_t grid = (mesh.triangle_count + (kBlock / 64) - 1) / (kBlock / 64);
             hipLaunchKernelGGL(k_cover, dim3(grid), dim3(kBlock), 0, s, mesh.uvs, mesh.indices, mesh.triangle_count,
-                               m.width, m.height, m.cover);
+                               m.width, m.height, row_begin, row_end, m.cover);
         }
         hipLaunchKernelGGL(k_scan_count, dim3(nblocks), dim3(kBlock), 0, s, m.cover, cells, m.block_sums);
         hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(kBlock), 0, s, m.block_sums, nblocks);

@@ -586,10 +586,10 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
             // CUs about that long; four parts per tile shorten both fourfold.  Only where adding the parts is exact.
             const bool split_exact = o.accumulate == AOB_ACCUMULATE_QUANTISED || (o.sampler == AOB_SAMPLER_COSINE && o.use_any_hit);
             p.parts = split_exact ? (uint32_t)max(1, min(env_int("AOB_TRACE_PARTS", 4), o.sample_count / 32)) : 1u;
-            // chunks: bands of 8 tile rows when every texel of the atlas has exactly one surfel (then the trace order is
-            // the plain tile grid), else 2048 tiles
+            // chunks: bands of 8 tile rows when every texel of the rasterised rows has exactly one surfel (then the trace
+            // order is the plain tile grid), else 2048 tiles
             p.band_row = 0;
-            if (m.section_offsets.size() == 2 && m.surfel_count == (uint64_t)m.width * m.height && m.width % 64 == 0 &&
+            if (m.section_offsets.size() == 2 && m.surfel_count == (uint64_t)m.width * m.window_rows && m.width % 64 == 0 &&
                 sb % ((uint64_t)m.width * 8u) == 0 && env_int("AOB_TRACE_BANDS", 1))
                 p.band_row = (uint32_t)m.width / 8u;
             p.chunk = p.band_row ? p.band_row * 8u : 2048u;

@@ -34,6 +34,16 @@ def weak_scaling_atlas(base: int, world: int) -> tuple[int, int]:
     return base * a, base * b
 
 
+def row_window(height: int, rank: int, world: int, align: int = 8) -> tuple[int, int]:
+    """Rank `rank`'s strip of texel rows [begin, end): the atlas's tile rows (8 texels) dealt out evenly.  With
+    `Baker.rasterize(rows=...)` a rank rasterises and traces its own strip only; its result cells are the contiguous
+    range [begin * width, end * width).  (`Baker.shard_bounds` balances by surfel count instead, at the price of every
+    rank rasterising the whole atlas.)"""
+    tile_rows = (height + align - 1) // align
+    b, e = shard_range(tile_rows, rank, world)
+    return min(b * align, height), min(e * align, height)
+
+
 def gather_strips(cells, my_range, rank: int, world: int, dst: int = 0, overlapping: bool = False):
     """Gather every rank's strip of `cells` (an [n, 2] int32 tensor aliasing the AobResult buffer)
     into rank `dst`'s buffer.  my_range = (first_cell, last_cell), first > last when empty."""

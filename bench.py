@@ -2,12 +2,12 @@
 """bench.py — AO rays/s of the bake hot path on MI355X (BASELINE.json metric).
 
 A step is one full device-side bake of the workload with the scene already resident in HBM:
-LBVH build -> UV rasterise + compact -> fused trace -> (N>1: gather of texel strips to rank 0)
+BVH build -> UV rasterise + compact -> fused trace -> (N>1: gather of texel strips to rank 0)
 -> resolve + bleed.  value = rays all ranks cast / max-over-ranks step time.
 
 N=1 workload = BASELINE configs[2]: synthetic 999 698-triangle terrain, 2048^2 atlas, 256 spp,
 COSINE sampler, any-hit scoring, float accumulation.  N>1 is weak scaling: the atlas grows to
-N x 2048^2 texels (N=4 is configs[3]'s 4096^2) and each rank traces an equal strip.
+N x 2048^2 texels (N=4 is configs[3]'s 4096^2); each rank rasterises and traces an equal strip of texel rows.
 
 The JSON line also carries
   roofline     the trace kernel against HBM peak, ALGORITHMIC bytes:
@@ -88,23 +88,24 @@ def main():
     trace_ms = []
     counts = {}
 
+    # every rank rasterises and traces its own strip of texel rows (the whole atlas at N = 1); the BVH is built by all
+    rows = aod.row_window(H, rank, world)
+    my_cells = (rows[0] * W, rows[1] * W - 1)
+
     def step():
         baker.build_bvh()
-        baker.rasterize(0)
+        baker.rasterize(0, rows if world > 1 else None)
         n = baker.surfel_count(0)
-        bounds, strips, overlapping = baker.shard_bounds(0, world)       # tile-row aligned; syncs the stream
-        begin, end = bounds[rank], bounds[rank + 1]
-        baker.trace(0, begin, end)
+        baker.trace(0, 0, n)
         if world > 1:
             baker.sync()
-            aod.gather_strips(cells, strips[rank], rank, world, 0, overlapping)
+            aod.gather_strips(cells, my_cells, rank, world, 0, False)
             torch.cuda.synchronize()
         if rank == 0:
             baker.resolve(0)
         baker.sync()
         trace_ms.append(baker.last_trace_ms())
-        counts["surfels"] = n
-        counts["mine"] = end - begin
+        counts["mine"] = n
 
     def fence():
         if world > 1:
@@ -127,8 +128,14 @@ def main():
         elapsed = float(t.item())
 
     stats = baker.stats()
-    total_rays = counts["surfels"] * args.spp                  # all ranks together
     my_rays = counts["mine"] * args.spp
+    if world > 1:
+        t = torch.tensor([counts["mine"]], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        counts["surfels"] = int(t.item())
+    else:
+        counts["surfels"] = counts["mine"]
+    total_rays = counts["surfels"] * args.spp                  # all ranks together
     ms_per_step = elapsed / args.steps * 1e3
     value = total_rays / (elapsed / args.steps)
     kernel_ms = sum(trace_ms) / len(trace_ms)

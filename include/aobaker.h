@@ -254,6 +254,10 @@ int aob_bake_rasterize(AobBake* bake, int32_t material);
  * concatenated in scene order; inside a section 8x8 texel tiles, see aob_bake_shard_bounds):
  * ray generation, traversal, scoring, accumulation into the material's
  * W*H result buffer (BakeEngine.cpp:598-675).  end = UINT64_MAX means all. */
+/* aob_bake_rasterize restricted to the texel rows [row_begin, row_end) of the atlas: the surfel list then holds that
+ * strip only (the rest of the atlas stays uncovered).  A multi-GPU bake gives every rank its own strip this way instead
+ * of rasterising the whole atlas on every rank (aob_bake_shard_bounds balances by surfel count but needs the whole list). */
+int aob_bake_rasterize_rows(AobBake* bake, int32_t material, int32_t row_begin, int32_t row_end);
 int aob_bake_trace(AobBake* bake, int32_t material, uint64_t begin, uint64_t end);
 /* S6: resolve + bleed into the device image (BakeEngine.cpp:688-704). */
 int aob_bake_resolve(AobBake* bake, int32_t material);

@@ -449,3 +449,35 @@ def test_deep_stacks_spill_to_hbm_and_come_back(engine, orc, mode, structure):
     assert np.array_equal(g.GetData(), c.GetData())
     ao = g.ao()
     assert 0.02 < ao.mean() < 0.9          # the ball occludes a good part of the sky, not all of it
+
+
+# ---- a rank's strip of texel rows (aob_bake_rasterize_rows) ------------------------------------------------------
+@pytest.mark.parametrize("parts", [2, 3])
+@pytest.mark.parametrize("name", ["cube", "terrain", "two_section"])
+def test_row_window_bakes_stitch_to_the_full_bake(engine, orc, name, parts):
+    """Rasterising and tracing the atlas strip by strip gives the cells of the whole bake (what bench.py does per rank)."""
+    from aobaker_amd import dist as aod
+    flat = FlatScene(SCENES[name]())
+    opt = make_options(orc, sample_count=16, **MODES[2])
+    m = flat.material_array[0]
+    with Baker(flat, opt) as b:
+        b.build_bvh(); b.rasterize(0); b.trace(0)
+        full = b.results(0).copy()
+        n_full = b.surfel_count(0)
+        stitched = np.zeros_like(full)
+        n_sum = 0
+        for r in range(parts):
+            y0, y1 = aod.row_window(m.height, r, parts)
+            b.rasterize(0, (y0, y1))
+            n = b.surfel_count(0)
+            n_sum += n
+            b.trace(0, 0, n)
+            part = b.results(0)
+            cells = slice(y0 * m.width, y1 * m.width)
+            outside = np.ones(len(part), dtype=bool); outside[cells] = False
+            assert not part["weight_bits"][outside].any()           # nothing outside the strip
+            stitched[cells] = part[cells]
+        with pytest.raises(capi.AobError):
+            b.rasterize(0, (8, m.height + 8))
+    assert n_sum == n_full
+    assert np.array_equal(stitched["total_bits"], full["total_bits"]) and np.array_equal(stitched["weight_bits"], full["weight_bits"])

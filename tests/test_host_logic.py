@@ -121,3 +121,14 @@ def test_bench_helpers_and_committed_traffic():
     surfels["texel_x"], surfels["texel_y"] = np.tile(np.arange(64), 64), np.repeat(np.arange(64), 64)
     sub = bench._subsample(surfels, 32)
     assert len(sub) == 4 and set(zip(sub["texel_x"].tolist(), sub["texel_y"].tolist())) == {(0, 0), (32, 0), (0, 32), (32, 32)}
+
+
+def test_row_windows_partition_the_atlas_on_tile_rows():
+    for height in (8, 64, 100, 2048, 4096):
+        for world in (1, 2, 3, 4, 8):
+            w = [aod.row_window(height, r, world) for r in range(world)]
+            assert w[0][0] == 0 and w[-1][1] == height
+            assert all(a[1] == b[0] for a, b in zip(w, w[1:]))
+            assert all(b % 8 == 0 for b, _ in w)
+            sizes = [e - b for b, e in w]
+            assert max(sizes) - min(sizes) <= 8 or height % 8
