@@ -272,7 +272,8 @@ void k_trace(TraceParams p)
                             invdir = make_f3(invdir.x * p.inv_tmax, invdir.y * p.inv_tmax, invdir.z * p.inv_tmax);
                             oxinvdir = make_f3(oxinvdir.x * p.inv_tmax, oxinvdir.y * p.inv_tmax, oxinvdir.z * p.inv_tmax);
                         }
-                        closest_t = p.tmax; hit = false; sp = 1;
+                        if (!ANYHIT) closest_t = p.tmax;            // any hit: the bound never moves off tmax, no register for it
+                        hit = false; sp = 1;
                         active = true;
                         addr = 0;
                         if (p.node_count == 0) finish();          // empty scene: every ray misses
@@ -318,6 +319,7 @@ void k_trace(TraceParams p)
         if (__popcll(__ballot(at_leaf)) >= p.leaf_wait || inner_m == 0ull) {
             if (at_leaf) {
                 // QUANT 2: the ref may name a PAIR of triangles, p and p + 1 (AOB_PAIR_FLAG): both are fetched in one go
+                const float bound = ANYHIT ? p.tmax : closest_t;
                 const uint32_t lref = addr - p.leaf_base;
                 const bool pair = QUANT == 2 && (lref & 0x40000000u) != 0u;
                 const float4* np = QUANT ? p.leaf_tris + 3ull * (lref & 0x3fffffffu) : p.nodes + 4ull * addr;
@@ -325,13 +327,13 @@ void k_trace(TraceParams p)
                 {
                     const float4 n0 = np[0], n1 = np[1], n2 = np[2];
                     t = intersect_triangle(org, dir, make_f3(n0.x, n0.y, n0.z), make_f3(n1.x, n1.y, n1.z),
-                                           make_f3(n2.x, n2.y, n2.z), closest_t);
+                                           make_f3(n2.x, n2.y, n2.z), bound);
                     if (MASKED) {
                         // the ray mask of intersect_bvh2_lds.cl:163-166, by section: skip the triangles this ray must not see
                         const uint32_t shape = __float_as_uint(QUANT ? n0.w : n1.w);
                         const bool skip = shape == p.self_shape ? p.self_hidden != 0u
                                                                 : ((p.hidden_from_others[shape >> 5] >> (shape & 31u)) & 1u) != 0u;
-                        if (skip) t = closest_t;
+                        if (skip) t = bound;
                     }
                 }
                 if (QUANT == 2 && pair) {
@@ -339,17 +341,17 @@ void k_trace(TraceParams p)
                     // (Fetched after the first test, not with it: 18 vertex registers at once spill the ray.)
                     const float4 m0 = np[3], m1 = np[4], m2 = np[5];
                     float t2 = intersect_triangle(org, dir, make_f3(m0.x, m0.y, m0.z), make_f3(m1.x, m1.y, m1.z),
-                                                  make_f3(m2.x, m2.y, m2.z), closest_t);
+                                                  make_f3(m2.x, m2.y, m2.z), bound);
                     if (MASKED) {
                         const uint32_t shape = __float_as_uint(m0.w);
                         const bool skip = shape == p.self_shape ? p.self_hidden != 0u
                                                                 : ((p.hidden_from_others[shape >> 5] >> (shape & 31u)) & 1u) != 0u;
-                        if (skip) t2 = closest_t;
+                        if (skip) t2 = bound;
                     }
                     t = fminf(t, t2);
                 }
-                const bool closer = t < closest_t;
-                if (closer) { closest_t = t; hit = true; }
+                const bool closer = t < bound;
+                if (closer) { if (!ANYHIT) closest_t = t; hit = true; }
                 addr = (ANYHIT && closer) ? kInvalid : pop();
                 if (addr == kInvalid) finish();
             }
@@ -414,6 +416,7 @@ void k_trace(TraceParams p)
                 addr = (h0 && r0 == 0) ? c0.w : ((h1 && r1 == 0) ? c1.w : ((h2 && r2 == 0) ? c2.w : c3.w));
             }
           } else {
+            const float bound = ANYHIT ? p.tmax : closest_t;
             float s0x, s0y, s1x, s1y;
             uint32_t al, ar;
             if (QUANT == 1) {
@@ -429,17 +432,17 @@ void k_trace(TraceParams p)
                 s0x = fmaxf(fmaxf(fmaxf(fmaf((float)(lx & 0xffffu), invdir.x, oxinvdir.x), fmaf((float)(ly & 0xffffu), invdir.y, oxinvdir.y)),
                                   fmaf((float)(lz & 0xffffu), invdir.z, oxinvdir.z)), 0.0f);
                 s0y = fminf(fminf(fminf(fmaf((float)(lx >> 16), invdir.x, oxinvdir.x), fmaf((float)(ly >> 16), invdir.y, oxinvdir.y)),
-                                  fmaf((float)(lz >> 16), invdir.z, oxinvdir.z)), closest_t);
+                                  fmaf((float)(lz >> 16), invdir.z, oxinvdir.z)), bound);
                 s1x = fmaxf(fmaxf(fmaxf(fmaf((float)(rx & 0xffffu), invdir.x, oxinvdir.x), fmaf((float)(ry & 0xffffu), invdir.y, oxinvdir.y)),
                                   fmaf((float)(rz & 0xffffu), invdir.z, oxinvdir.z)), 0.0f);
                 s1y = fminf(fminf(fminf(fmaf((float)(rx >> 16), invdir.x, oxinvdir.x), fmaf((float)(ry >> 16), invdir.y, oxinvdir.y)),
-                                  fmaf((float)(rz >> 16), invdir.z, oxinvdir.z)), closest_t);
+                                  fmaf((float)(rz >> 16), invdir.z, oxinvdir.z)), bound);
                 al = b.z; ar = b.w;
             } else {
                 const float4* np = p.nodes + 4ull * addr;
                 const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-                intersect_bbox(make_f3(n0.x, n0.y, n0.z), make_f3(n1.x, n1.y, n1.z), invdir, oxinvdir, closest_t, s0x, s0y);
-                intersect_bbox(make_f3(n2.x, n2.y, n2.z), make_f3(n3.x, n3.y, n3.z), invdir, oxinvdir, closest_t, s1x, s1y);
+                intersect_bbox(make_f3(n0.x, n0.y, n0.z), make_f3(n1.x, n1.y, n1.z), invdir, oxinvdir, bound, s0x, s0y);
+                intersect_bbox(make_f3(n2.x, n2.y, n2.z), make_f3(n3.x, n3.y, n3.z), invdir, oxinvdir, bound, s1x, s1y);
                 al = __float_as_uint(n0.w); ar = __float_as_uint(n2.w);
             }
             const bool c0 = s0x <= s0y, c1 = s1x <= s1y;
