@@ -133,3 +133,25 @@ def test_png_cpp_equals_python_and_decodes(tool, tmp_path, channels, bpc):
         assert img.dtype == np.uint16
         assert np.abs(img.astype(np.float64) - want).max() <= 1          # float32 vs float64 rounding of v*65535+0.5
         assert img.reshape(-1)[0] == 0 and img.reshape(-1)[1] == 65535 and img.reshape(-1)[2] == 0 and img.reshape(-1)[3] == 65535
+
+
+def test_obj_import_tolerates_real_world_files(tool, tmp_path):
+    """CRLF line ends, tabs, comments after faces, 3-component vt, blank lines, unknown statements, an unnamed group."""
+    text = ("# exported by something\r\nmtllib scene.mtl\r\n\r\ng\r\nv\t0 0 0\r\nv 1 0 0\r\nv 1 1 0\r\nv 0 1 0 0.5 0.5 0.5\r\n"
+            "vt 0 0 0\r\nvt 1 0 0\r\nvt 1 1 0\r\nvt 0 1 0\r\ns off\r\nusemtl  wall \r\nf 1/1 2/2 3/3 4/4   # a quad\r\nl 1 2\r\nf 1/1 3/3 4/4\r\n")
+    path = tmp_path / "crlf.obj"
+    path.write_bytes(text.encode())
+    py = Scene()
+    obj = assets.load_obj(str(path), py, atlas=(16, 16))
+    assert obj.GetSectionCount() == 1 and py.GetMaterial(0).Name == "wall" and obj.GetSection(0).Name == "defaultobject"
+    mesh = obj.GetSection(0).GetPreviewMesh()
+    assert mesh.GetVertexCount() == 9 and np.array_equal(mesh.GetVertices()["UV"][2], np.float32([1, 0]))
+    out = tmp_path / "crlf.aobs"
+    r = subprocess.run([tool, "obj2aobs", str(path), str(out), "16", "16", "1", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    cpp = read_scene(str(out)).GetObject(0).GetSection(0).GetPreviewMesh()
+    assert cpp.GetVertices().tobytes() == mesh.GetVertices().tobytes() and np.array_equal(cpp.GetIndices(), mesh.GetIndices())
+    # a missing file is an error in both
+    assert subprocess.run([tool, "obj2aobs", str(tmp_path / "nope.obj"), str(out), "8", "8", "1", "1"], capture_output=True).returncode == 1
+    with pytest.raises(FileNotFoundError):
+        assets.load_obj(str(tmp_path / "nope.obj"), Scene())
