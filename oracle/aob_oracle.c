@@ -1362,12 +1362,22 @@ int orc_trace_ex(const AobBvhNode* nodes, uint64_t node_count,
         job.nodes2q = nodes2q; job.tris = tris; job.tri_count = n;
     }
     pthread_mutex_init(&job.lock, NULL);
-    if (threads <= 1) trace_worker(&job);
-    else {
-        if (threads > 256) threads = 256;
-        pthread_t th[256];
-        for (int i = 0; i < threads; i++) pthread_create(&th[i], NULL, trace_worker, &job);
-        for (int i = 0; i < threads; i++) pthread_join(th[i], NULL);
+    if (threads > 256) threads = 256;
+    /* One section at a time, in scene order: two sections of a material may cover the same texel (BakeEngine.cpp:473,659),
+     * within a section every surfel has its own cell.  The reference's integer sums do not care about the order; the
+     * float sums are rounded per add, so the order is part of the result — sections in order, as the library's one
+     * launch per section.  A section starts where the surfel's index within its section is 0. */
+    for (uint64_t sb = begin; sb < end; ) {
+        uint64_t se = sb + 1;
+        while (se < end && !(section_index && section_index[se] == 0)) se++;
+        job.begin = sb; job.end = se; job.next = sb;
+        if (threads <= 1) trace_worker(&job);
+        else {
+            pthread_t th[256];
+            for (int i = 0; i < threads; i++) pthread_create(&th[i], NULL, trace_worker, &job);
+            for (int i = 0; i < threads; i++) pthread_join(th[i], NULL);
+        }
+        sb = se;
     }
     pthread_mutex_destroy(&job.lock);
     free(nodes4); free(tris); free(nodes2q); free(nodes4q);
