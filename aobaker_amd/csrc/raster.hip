@@ -45,40 +45,77 @@ __device__ __forceinline__ bool snap_uv(const float* uv, int32_t W, int32_t H, i
     return true;
 }
 
-// One wavefront per triangle; the 64 lanes stride over the texels of its bounding box.
+// One lane per triangle.  A triangle whose bounding box holds at most kSmallBox texels — nearly all of them once a mesh
+// has about as many triangles as the atlas has texels (the 1 M-triangle terrain on 2048^2: 4 texels each) — is rasterised
+// by its own lane; the others are handed round the wavefront one at a time, all 64 lanes striding over the box.
+static constexpr int kSmallBox = 16;
+
+struct CoverTri { int64_t X[3], Y[3]; int64_t px0, py0; int64_t b0, b1, b2; uint64_t bw, npix; };
+
+__device__ __forceinline__ bool cover_setup(const float* __restrict__ uvs, const uint32_t* __restrict__ indices, uint32_t t,
+                                            int32_t W, int32_t H, int32_t row_begin, int32_t row_end, CoverTri& c)
+{
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 3; k++) ok = snap_uv(uvs + 2ull * indices[3ull * t + k], W, H, c.X[k], c.Y[k]) && ok;
+    if (!ok) return false;
+    int64_t area = edge_fn(c.X[0], c.Y[0], c.X[1], c.Y[1], c.X[2], c.Y[2]);
+    if (area == 0) return false;
+    if (area < 0) { int64_t tx = c.X[1], ty = c.Y[1]; c.X[1] = c.X[2]; c.Y[1] = c.Y[2]; c.X[2] = tx; c.Y[2] = ty; }
+    int64_t minx = min(min(c.X[0], c.X[1]), c.X[2]), maxx = max(max(c.X[0], c.X[1]), c.X[2]);
+    int64_t miny = min(min(c.Y[0], c.Y[1]), c.Y[2]), maxy = max(max(c.Y[0], c.Y[1]), c.Y[2]);
+    int64_t px0 = max((minx - 128 + 255) >> 8, (int64_t)0), px1 = min((maxx - 128) >> 8, (int64_t)W - 1);
+    // only the texel rows [row_begin, row_end) of the atlas are wanted (a rank's strip; the whole atlas by default)
+    int64_t py0 = max((miny - 128 + 255) >> 8, (int64_t)row_begin), py1 = min((maxy - 128) >> 8, (int64_t)row_end - 1);
+    if (px1 < px0 || py1 < py0) return false;
+    c.b0 = edge_top_left(c.X[0], c.Y[0], c.X[1], c.Y[1]) ? 0 : -1;
+    c.b1 = edge_top_left(c.X[1], c.Y[1], c.X[2], c.Y[2]) ? 0 : -1;
+    c.b2 = edge_top_left(c.X[2], c.Y[2], c.X[0], c.Y[0]) ? 0 : -1;
+    c.px0 = px0; c.py0 = py0;
+    c.bw = (uint64_t)(px1 - px0 + 1);
+    c.npix = c.bw * (uint64_t)(py1 - py0 + 1);
+    return true;
+}
+
+__device__ __forceinline__ void cover_texel(const CoverTri& c, uint64_t p, uint32_t t, int32_t W, uint32_t* __restrict__ cover)
+{
+    const int64_t py = c.py0 + (int64_t)(p / c.bw), px = c.px0 + (int64_t)(p % c.bw);
+    const int64_t cx = px * 256 + 128, cy = py * 256 + 128;
+    if (edge_fn(c.X[0], c.Y[0], c.X[1], c.Y[1], cx, cy) + c.b0 < 0) return;
+    if (edge_fn(c.X[1], c.Y[1], c.X[2], c.Y[2], cx, cy) + c.b1 < 0) return;
+    if (edge_fn(c.X[2], c.Y[2], c.X[0], c.Y[0], cx, cy) + c.b2 < 0) return;
+    atomicMax(&cover[(uint64_t)py * W + px], t + 1);       // last fragment drawn wins
+}
+
+__device__ __forceinline__ int64_t bcast64(int64_t v, int src)
+{
+    const uint32_t lo = __shfl((uint32_t)(uint64_t)v, src), hi = __shfl((uint32_t)((uint64_t)v >> 32), src);
+    return (int64_t)((uint64_t)hi << 32 | lo);
+}
+
 __global__ __launch_bounds__(kBlock)
 void k_cover(const float* __restrict__ uvs, const uint32_t* __restrict__ indices, uint32_t ntri,
              int32_t W, int32_t H, int32_t row_begin, int32_t row_end, uint32_t* __restrict__ cover)
 {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t t = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    if (t >= ntri) return;
-    int64_t X[3], Y[3];
-    bool ok = true;
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    CoverTri c;
+    const bool live = t < ntri && cover_setup(uvs, indices, t, W, H, row_begin, row_end, c);
+    if (live && c.npix <= (uint64_t)kSmallBox)
+        for (uint64_t p = 0; p < c.npix; p++) cover_texel(c, p, t, W, cover);
+    // the big ones, one after the other, by the whole wavefront
+    uint64_t big = __ballot(live && c.npix > (uint64_t)kSmallBox);
+    while (big) {
+        const int src = __ffsll((unsigned long long)big) - 1;
+        big &= big - 1;
+        CoverTri g;
 #pragma unroll
-    for (int c = 0; c < 3; c++) ok = snap_uv(uvs + 2ull * indices[3ull * t + c], W, H, X[c], Y[c]) && ok;
-    if (!ok) return;
-    int64_t area = edge_fn(X[0], Y[0], X[1], Y[1], X[2], Y[2]);
-    if (area == 0) return;
-    if (area < 0) { int64_t tx = X[1], ty = Y[1]; X[1] = X[2]; Y[1] = Y[2]; X[2] = tx; Y[2] = ty; }
-    int64_t minx = min(min(X[0], X[1]), X[2]), maxx = max(max(X[0], X[1]), X[2]);
-    int64_t miny = min(min(Y[0], Y[1]), Y[2]), maxy = max(max(Y[0], Y[1]), Y[2]);
-    int64_t px0 = max((minx - 128 + 255) >> 8, (int64_t)0), px1 = min((maxx - 128) >> 8, (int64_t)W - 1);
-    // only the texel rows [row_begin, row_end) of the atlas are wanted (a rank's strip; the whole atlas by default)
-    int64_t py0 = max((miny - 128 + 255) >> 8, (int64_t)row_begin), py1 = min((maxy - 128) >> 8, (int64_t)row_end - 1);
-    if (px1 < px0 || py1 < py0) return;
-    const int64_t b0 = edge_top_left(X[0], Y[0], X[1], Y[1]) ? 0 : -1;
-    const int64_t b1 = edge_top_left(X[1], Y[1], X[2], Y[2]) ? 0 : -1;
-    const int64_t b2 = edge_top_left(X[2], Y[2], X[0], Y[0]) ? 0 : -1;
-    const uint64_t bw = (uint64_t)(px1 - px0 + 1), bh = (uint64_t)(py1 - py0 + 1);
-    const uint64_t npix = bw * bh;
-    for (uint64_t p = lane; p < npix; p += 64) {
-        int64_t py = py0 + (int64_t)(p / bw), px = px0 + (int64_t)(p % bw);
-        int64_t cx = px * 256 + 128, cy = py * 256 + 128;
-        if (edge_fn(X[0], Y[0], X[1], Y[1], cx, cy) + b0 < 0) continue;
-        if (edge_fn(X[1], Y[1], X[2], Y[2], cx, cy) + b1 < 0) continue;
-        if (edge_fn(X[2], Y[2], X[0], Y[0], cx, cy) + b2 < 0) continue;
-        atomicMax(&cover[(uint64_t)py * W + px], t + 1);       // last fragment drawn wins
+        for (int k = 0; k < 3; k++) { g.X[k] = bcast64(c.X[k], src); g.Y[k] = bcast64(c.Y[k], src); }
+        g.px0 = bcast64(c.px0, src); g.py0 = bcast64(c.py0, src);
+        g.b0 = bcast64(c.b0, src); g.b1 = bcast64(c.b1, src); g.b2 = bcast64(c.b2, src);
+        g.bw = (uint64_t)bcast64((int64_t)c.bw, src); g.npix = (uint64_t)bcast64((int64_t)c.npix, src);
+        const uint32_t gt = __shfl(t, src);
+        for (uint64_t p = lane; p < g.npix; p += 64) cover_texel(g, p, gt, W, cover);
     }
 }
 
@@ -353,7 +390,7 @@ int rasterize_material(AobBake* b, int32_t material, int32_t row_begin, int32_t 
         if (mesh.material != material) continue;                       // BakeEngine.cpp:523
         AOB_HIP(hipMemsetAsync(m.cover, 0, sizeof(uint32_t) * cells, s));
         if (mesh.triangle_count) {
-            uint32_t grid = (mesh.triangle_count + (kBlock / 64) - 1) / (kBlock / 64);
+            uint32_t grid = (mesh.triangle_count + kBlock - 1) / kBlock;
             hipLaunchKernelGGL(k_cover, dim3(grid), dim3(kBlock), 0, s, mesh.uvs, mesh.indices, mesh.triangle_count,
                                m.width, m.height, row_begin, row_end, m.cover);
         }
