@@ -56,3 +56,44 @@ def test_sharded_trace_gathers_to_the_single_rank_result(tmp_path, world, overla
     out = tmp_path / "result.txt"
     mp.spawn(_worker, args=(world, port, overlapping, str(out)), nprocs=world, join=True)
     assert out.read_text() == "ok"
+
+
+def _row_worker(rank, world, port, out_path):
+    """bench.py's N>1 scheme: every rank rasterises and traces its own strip of texel rows (dist.row_window), then the
+    strips are gathered to rank 0 — here with the oracle standing in for the GPU stages."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aobaker_amd import scenes
+    from aobaker_amd import dist as aod
+    from aobaker_amd.scene import FlatScene
+    from oracle import oracle as orc
+
+    flat = FlatScene(scenes.terrain_scene(grid=24, atlas=(32, 40)))
+    m = flat.material_array[0]
+    opt = orc.default_options()
+    opt.sample_count = 8
+    nodes, _ = orc.bvh_build(orc.scene_triangles(flat.desc))
+    surfels, sidx = orc.rasterize(flat.desc, 0, opt)
+    hemi = orc.compat_table(opt)
+    y0, y1 = aod.row_window(m.height, rank, world)
+    keep = (surfels["texel_y"] >= y0) & (surfels["texel_y"] < y1)            # what aob_bake_rasterize_rows leaves
+    mine, _ = orc.trace(nodes, np.ascontiguousarray(surfels[keep]), np.ascontiguousarray(sidx[keep]), opt, m.width, m.height, hemi)
+    cells = torch.from_numpy(mine.view(np.int32).reshape(-1, 2).copy())
+    aod.gather_strips(cells, (y0 * m.width, y1 * m.width - 1), rank, world, 0, False)
+    if rank == 0:
+        full, _ = orc.trace(nodes, surfels, sidx, opt, m.width, m.height, hemi)
+        ok = np.array_equal(cells.numpy(), full.view(np.int32).reshape(-1, 2))
+        with open(out_path, "w") as f:
+            f.write("ok" if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_window_strips_gather_to_the_single_rank_result(tmp_path, world):
+    port = 31500 + (os.getpid() + world * 11) % 2000
+    out = tmp_path / "result.txt"
+    mp.spawn(_row_worker, args=(world, port, str(out)), nprocs=world, join=True)
+    assert out.read_text() == "ok"
