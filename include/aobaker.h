@@ -256,7 +256,10 @@ int aob_bake_rasterize(AobBake* bake, int32_t material);
  * W*H result buffer (BakeEngine.cpp:598-675).  end = UINT64_MAX means all. */
 /* aob_bake_rasterize restricted to the texel rows [row_begin, row_end) of the atlas: the surfel list then holds that
  * strip only (the rest of the atlas stays uncovered).  A multi-GPU bake gives every rank its own strip this way instead
- * of rasterising the whole atlas on every rank (aob_bake_shard_bounds balances by surfel count but needs the whole list). */
+ * of rasterising the whole atlas on every rank (aob_bake_shard_bounds balances by surfel count but needs the whole list).
+ * Surfels are numbered within the strip: the COSINE sampler (keyed by texel) gives the cells of the whole bake, the
+ * REFERENCE_COMPAT sampler (whose table index is the surfel's number in its section's list, BakeEngine.cpp:598-628)
+ * an equally valid but different assignment of table entries — use aob_bake_shard_bounds where that must match. */
 int aob_bake_rasterize_rows(AobBake* bake, int32_t material, int32_t row_begin, int32_t row_end);
 int aob_bake_trace(AobBake* bake, int32_t material, uint64_t begin, uint64_t end);
 /* S6: resolve + bleed into the device image (BakeEngine.cpp:688-704). */
