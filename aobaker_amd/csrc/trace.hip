@@ -353,7 +353,6 @@ void k_trace(TraceParams p)
                 const bool closer = t < bound;
                 if (closer) { if (!ANYHIT) closest_t = t; hit = true; }
                 addr = (ANYHIT && closer) ? kInvalid : pop();
-                if (addr == kInvalid) finish();
             }
         }
 
@@ -390,7 +389,6 @@ void k_trace(TraceParams p)
                        h3 = slab(c3, k3) && c3.w != kInvalid;
             if (!(h0 || h1 || h2 || h3)) {
                 addr = pop();
-                if (addr == kInvalid) finish();
             } else if (ANYHIT) {
                 // any-hit: the answer does not depend on the visiting order — follow the first hit child, defer the rest
                 if (h3 && (h0 || h1 || h2)) push(c3.w);
@@ -451,10 +449,10 @@ void k_trace(TraceParams p)
             addr = right_first ? ar : al;
             if (!(c0 || c1)) {
                 addr = pop();
-                if (addr == kInvalid) finish();
             }
           }
         }
+        if (active && addr == kInvalid) finish();     // the one place a ray ends
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS atomics have landed
 
