@@ -44,9 +44,11 @@ def row_window(height: int, rank: int, world: int, align: int = 8) -> tuple[int,
     return min(b * align, height), min(e * align, height)
 
 
-def gather_strips(cells, my_range, rank: int, world: int, dst: int = 0, overlapping: bool = False):
+def gather_strips(cells, my_range, rank: int, world: int, dst: int = 0, overlapping: bool = False, ranges=None):
     """Gather every rank's strip of `cells` (an [n, 2] int32 tensor aliasing the AobResult buffer)
-    into rank `dst`'s buffer.  my_range = (first_cell, last_cell), first > last when empty."""
+    into rank `dst`'s buffer.  my_range = (first_cell, last_cell), first > last when empty.
+    ranges: every rank's (first_cell, last_cell) when the caller knows them (row windows are a pure
+    function of the rank) — saves the all-gather of the ranges and its host synchronisation."""
     import torch
     import torch.distributed as dist
 
@@ -57,10 +59,11 @@ def gather_strips(cells, my_range, rank: int, world: int, dst: int = 0, overlapp
         # disjoint-or-zero contributions; x + 0 is exact either way
         dist.reduce(cells, dst=dst, op=dist.ReduceOp.SUM)
         return
-    mine = torch.tensor([my_range[0], my_range[1]], dtype=torch.int64, device=cells.device)
-    ranges = [torch.zeros(2, dtype=torch.int64, device=cells.device) for _ in range(world)]
-    dist.all_gather(ranges, mine)
-    ranges = [tuple(int(v) for v in r.tolist()) for r in ranges]
+    if ranges is None:
+        mine = torch.tensor([my_range[0], my_range[1]], dtype=torch.int64, device=cells.device)
+        ranges = [torch.zeros(2, dtype=torch.int64, device=cells.device) for _ in range(world)]
+        dist.all_gather(ranges, mine)
+        ranges = [tuple(int(v) for v in r.tolist()) for r in ranges]
     ops = []
     if rank == dst:
         for peer, (c0, c1) in enumerate(ranges):

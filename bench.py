@@ -91,6 +91,7 @@ def main():
     # every rank rasterises and traces its own strip of texel rows (the whole atlas at N = 1); the BVH is built by all
     rows = aod.row_window(H, rank, world)
     my_cells = (rows[0] * W, rows[1] * W - 1)
+    all_cells = [(b * W, e * W - 1) for b, e in (aod.row_window(H, r, world) for r in range(world))]
 
     def step():
         baker.build_bvh()
@@ -99,7 +100,7 @@ def main():
         baker.trace(0, 0, n)
         if world > 1:
             baker.sync()
-            aod.gather_strips(cells, my_cells, rank, world, 0, False)
+            aod.gather_strips(cells, my_cells, rank, world, 0, False, all_cells)
             torch.cuda.synchronize()
         if rank == 0:
             baker.resolve(0)

@@ -81,7 +81,8 @@ def _row_worker(rank, world, port, out_path):
     keep = (surfels["texel_y"] >= y0) & (surfels["texel_y"] < y1)            # what aob_bake_rasterize_rows leaves
     mine, _ = orc.trace(nodes, np.ascontiguousarray(surfels[keep]), np.ascontiguousarray(sidx[keep]), opt, m.width, m.height, hemi)
     cells = torch.from_numpy(mine.view(np.int32).reshape(-1, 2).copy())
-    aod.gather_strips(cells, (y0 * m.width, y1 * m.width - 1), rank, world, 0, False)
+    every = [(b * m.width, e * m.width - 1) for b, e in (aod.row_window(m.height, r, world) for r in range(world))]
+    aod.gather_strips(cells, every[rank], rank, world, 0, False, every)          # as bench.py calls it: no all-gather of the ranges
     if rank == 0:
         full, _ = orc.trace(nodes, surfels, sidx, opt, m.width, m.height, hemi)
         ok = np.array_equal(cells.numpy(), full.view(np.int32).reshape(-1, 2))
