@@ -1,12 +1,13 @@
-"""Wavefront OBJ in, PNG out — the Python twin of aobaker_amd/host/Assets.cpp.
+"""Wavefront OBJ in, PNG / OpenEXR out — the Python twin of aobaker_amd/host/Assets.cpp.
 
 `load_obj` mirrors `BakeObject::LoadFromFile` (reference BakeObject.cpp:170-195: assimp with
 ConvertToLeftHanded | FixInfacingNormals | GenNormals | ImproveCacheLocality | Triangulate) with the conventions the
 C++ importer documents: one vertex per face corner, one section per (object/group, material) in order of first
 appearance, fan triangulation, flat normals for a mesh that has none, z negated, v -> 1 - v, winding reversed;
 materials found in or added to the target scene by name.  `save_png` mirrors `BakeTexture::SavePNG`
-(BakeTexture.cpp:104-116) and writes the same bytes as the C++ writer (stored deflate blocks).  The tests compare the
-two implementations bit for bit; `read_png` is the decoder those tests use.
+(BakeTexture.cpp:104-116) and writes the same bytes as the C++ writer (stored deflate blocks); `save_exr` mirrors `BakeTexture::SaveEXR` (the float image
+the reference's 8-bit PNG cannot hold).  The tests compare the two implementations bit for bit; `read_png` / `read_exr`
+are the decoders those tests use.
 """
 from __future__ import annotations
 
@@ -157,6 +158,81 @@ def png_bytes(texture: BakeTexture) -> bytes:
 def save_png(texture: BakeTexture, path: str) -> None:
     with open(path, "wb") as f:
         f.write(png_bytes(texture))
+
+
+# ---- OpenEXR ------------------------------------------------------------------------------------------------
+_EXR_NAMES = {1: ["Y"], 2: ["A", "Y"], 3: ["B", "G", "R"], 4: ["A", "B", "G", "R"]}      # alphabetical, as the format demands
+_EXR_SOURCE = {1: [0], 2: [1, 0], 3: [2, 1, 0], 4: [3, 2, 1, 0]}                           # file channel <- texture channel
+
+
+def _attr(name: str, kind: str, value: bytes) -> bytes:
+    return name.encode() + b"\0" + kind.encode() + b"\0" + struct.pack("<I", len(value)) + value
+
+
+def exr_bytes(texture: BakeTexture) -> bytes:
+    """The bytes BakeTexture::SaveEXR writes: single-part scan-line OpenEXR, no compression; FLOAT samples (v/255 for
+    1-byte channels), HALF for 2-byte channels."""
+    w, h, ch, bpc = texture.GetWidth(), texture.GetHeight(), texture.GetChannelCount(), texture.GetBytesPerChannel()
+    half = bpc == 2
+    if bpc == 1:
+        px = (texture.GetData().reshape(h, w, ch).astype(np.float32) / F(255)).astype("<f4")
+    else:
+        px = texture.GetData().view("<f2" if half else "<f4").reshape(h, w, ch)
+    chlist = b"".join(n.encode() + b"\0" + struct.pack("<IBBBBII", 1 if half else 2, 0, 0, 0, 0, 1, 1) for n in _EXR_NAMES[ch]) + b"\0"
+    window = struct.pack("<iiii", 0, 0, w - 1, h - 1)
+    head = (b"\x76\x2f\x31\x01" + struct.pack("<I", 2) + _attr("channels", "chlist", chlist) + _attr("compression", "compression", b"\0")
+            + _attr("dataWindow", "box2i", window) + _attr("displayWindow", "box2i", window) + _attr("lineOrder", "lineOrder", b"\0")
+            + _attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + _attr("screenWindowCenter", "v2f", struct.pack("<ff", 0.0, 0.0))
+            + _attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0")
+    line = w * ch * (2 if half else 4)
+    first = len(head) + 8 * h
+    offsets = (first + (8 + line) * np.arange(h, dtype=np.uint64)).astype("<u8").tobytes()
+    planar = np.ascontiguousarray(px[:, :, _EXR_SOURCE[ch]].transpose(0, 2, 1))           # [row, file channel, x]
+    rows = np.zeros((h, 8 + line), dtype=np.uint8)
+    rows[:, 0:4] = np.arange(h, dtype="<i4").view(np.uint8).reshape(h, 4)
+    rows[:, 4:8] = np.frombuffer(struct.pack("<i", line), dtype=np.uint8)
+    rows[:, 8:] = planar.view(np.uint8).reshape(h, line)
+    return head + offsets + rows.tobytes()
+
+
+def save_exr(texture: BakeTexture, path: str) -> None:
+    with open(path, "wb") as f:
+        f.write(exr_bytes(texture))
+
+
+def read_exr(path: str) -> dict[str, np.ndarray]:
+    """Decode an uncompressed single-part scan-line OpenEXR with HALF / FLOAT channels: {channel name: (H, W) array}."""
+    data = open(path, "rb").read()
+    assert data[:4] == b"\x76\x2f\x31\x01" and struct.unpack("<I", data[4:8])[0] == 2
+    at, attrs = 8, {}
+    while data[at] != 0:
+        e = data.index(b"\0", at); name = data[at:e].decode(); at = e + 1
+        e = data.index(b"\0", at); kind = data[at:e].decode(); at = e + 1
+        n = struct.unpack("<I", data[at:at + 4])[0]
+        attrs[name] = (kind, data[at + 4:at + 4 + n]); at += 4 + n
+    at += 1
+    assert attrs["compression"][1] == b"\0" and attrs["lineOrder"][1] == b"\0"
+    x0, y0, x1, y1 = struct.unpack("<iiii", attrs["dataWindow"][1])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    channels, c = [], attrs["channels"][1]
+    i = 0
+    while c[i] != 0:
+        e = c.index(b"\0", i); name = c[i:e].decode()
+        kind, _, xs, ys = struct.unpack("<I4sII", c[e + 1:e + 17])
+        assert kind in (1, 2) and xs == 1 and ys == 1
+        channels.append((name, "<f2" if kind == 1 else "<f4")); i = e + 17
+    assert [n for n, _ in channels] == sorted(n for n, _ in channels)
+    offsets = np.frombuffer(data, dtype="<u8", count=h, offset=at)
+    out = {n: np.zeros((h, w), dtype=t) for n, t in channels}
+    for row in range(h):
+        o = int(offsets[row])
+        y, size = struct.unpack("<ii", data[o:o + 8])
+        assert y == y0 + row and size == sum(w * np.dtype(t).itemsize for _, t in channels)
+        o += 8
+        for n, t in channels:
+            out[n][row] = np.frombuffer(data, dtype=t, count=w, offset=o)
+            o += w * np.dtype(t).itemsize
+    return out
 
 
 def read_png(path: str) -> np.ndarray:

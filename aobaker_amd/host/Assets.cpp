@@ -1,6 +1,6 @@
 // Assets.cpp — the data formats either side of the bake: Wavefront OBJ in,
 // PNG out, behind the reference's own entry points BakeObject::LoadFromFile (BakeObject.cpp:170-195) and
-// BakeTexture::SavePNG (BakeTexture.cpp:104-116).  Host code only — nothing here touches the GPU.
+// BakeTexture::SavePNG (BakeTexture.cpp:104-116) and its float twin SaveEXR.  Host code only — nothing here touches the GPU.
 // The Python twin, used by the tests, is aobaker_amd/assets.py: both produce the same vertices and the same bytes.
 //
 // OBJ import.  The reference hands the file to assimp with
@@ -150,6 +150,85 @@ void BakeTexture::SavePNG(const wchar_t* filename) const
 	char name[4096];
 	if (std::wcstombs(name, filename, sizeof name) == (size_t)-1) return;     // BakeTexture.cpp:112-113
 	SavePNG(name);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// OpenEXR (the float image the 8-bit SavePNG of the reference cannot hold)
+//
+// Single-part scan-line file, no compression, one scan line per chunk, increasing y.  Channels (alphabetical, as the
+// format demands): Y | A Y | B G R | A B G R for 1..4 channels, in the order the texture stores them as Y | Y A |
+// R G B | R G B A.  1-byte channels are written as FLOAT v/255, 2-byte channels as HALF (bits as stored), 4-byte
+// channels as FLOAT.
+namespace {
+
+void put_le32(std::vector<unsigned char>& v, uint32_t x) { for (int i = 0; i < 4; i++) v.push_back((unsigned char)(x >> (8 * i))); }
+void put_le64(std::vector<unsigned char>& v, uint64_t x) { for (int i = 0; i < 8; i++) v.push_back((unsigned char)(x >> (8 * i))); }
+void put_str(std::vector<unsigned char>& v, const char* t) { while (*t) v.push_back((unsigned char)*t++); v.push_back(0); }
+void put_attr(std::vector<unsigned char>& v, const char* name, const char* type, const std::vector<unsigned char>& value)
+{
+	put_str(v, name); put_str(v, type);
+	put_le32(v, (uint32_t)value.size());
+	v.insert(v.end(), value.begin(), value.end());
+}
+void put_f32(std::vector<unsigned char>& v, float f) { uint32_t u; std::memcpy(&u, &f, 4); put_le32(v, u); }
+
+} // namespace
+
+bool BakeTexture::SaveEXR(const char* filename) const
+{
+	if (ChannelCount < 1 || ChannelCount > 4 || (BytesPerChannel != 1 && BytesPerChannel != 2 && BytesPerChannel != 4)) return false;
+	// file channel k (alphabetical) <- texture channel kSource[ChannelCount][k]
+	static const char* const kNames[5][4] = { {}, { "Y" }, { "A", "Y" }, { "B", "G", "R" }, { "A", "B", "G", "R" } };
+	static const int kSource[5][4] = { {}, { 0 }, { 1, 0 }, { 2, 1, 0 }, { 3, 2, 1, 0 } };
+	const bool half = BytesPerChannel == 2;
+	const uint32_t sample = half ? 2u : 4u;
+	std::vector<unsigned char> exr = { 0x76, 0x2f, 0x31, 0x01 };
+	put_le32(exr, 2);                                                     // version 2, no flags: single-part scan lines
+	std::vector<unsigned char> v;
+	for (int k = 0; k < ChannelCount; k++)
+	{
+		put_str(v, kNames[ChannelCount][k]);
+		put_le32(v, half ? 1u : 2u);                                      // HALF / FLOAT
+		v.push_back(0); v.push_back(0); v.push_back(0); v.push_back(0);  // pLinear, reserved
+		put_le32(v, 1); put_le32(v, 1);                                   // x, y sampling
+	}
+	v.push_back(0);
+	put_attr(exr, "channels", "chlist", v);
+	put_attr(exr, "compression", "compression", { 0 });
+	v.clear(); put_le32(v, 0); put_le32(v, 0); put_le32(v, (uint32_t)(Width - 1)); put_le32(v, (uint32_t)(Height - 1));
+	put_attr(exr, "dataWindow", "box2i", v);
+	put_attr(exr, "displayWindow", "box2i", v);
+	put_attr(exr, "lineOrder", "lineOrder", { 0 });
+	v.clear(); put_f32(v, 1.0f);
+	put_attr(exr, "pixelAspectRatio", "float", v);
+	v.clear(); put_f32(v, 0.0f); put_f32(v, 0.0f);
+	put_attr(exr, "screenWindowCenter", "v2f", v);
+	v.clear(); put_f32(v, 1.0f);
+	put_attr(exr, "screenWindowWidth", "float", v);
+	exr.push_back(0);
+	const uint64_t line = (uint64_t)Width * ChannelCount * sample, chunk = 8 + line;
+	const uint64_t first = exr.size() + 8ull * (uint64_t)Height;
+	for (int y = 0; y < Height; y++) put_le64(exr, first + chunk * (uint64_t)y);
+	exr.reserve(exr.size() + chunk * (uint64_t)Height);
+	for (int y = 0; y < Height; y++)
+	{
+		put_le32(exr, (uint32_t)y); put_le32(exr, (uint32_t)line);
+		const unsigned char* src = Data.data() + (size_t)y * Width * ChannelCount * BytesPerChannel;
+		for (int k = 0; k < ChannelCount; k++)
+		{
+			const int c = kSource[ChannelCount][k];
+			for (int x = 0; x < Width; x++)
+			{
+				const unsigned char* at = src + ((size_t)x * ChannelCount + c) * BytesPerChannel;
+				if (BytesPerChannel == 1) put_f32(exr, (float)*at / 255.0f);
+				else exr.insert(exr.end(), at, at + BytesPerChannel);      // little-endian host, little-endian file
+			}
+		}
+	}
+	FILE* f = std::fopen(filename, "wb");
+	if (!f) return false;
+	const bool ok = std::fwrite(exr.data(), 1, exr.size(), f) == exr.size();
+	return std::fclose(f) == 0 && ok;
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -92,6 +92,8 @@ public:
     // (UNORM of the float value clamped to [0,1]) for the 2- and 4-byte float channels.  aobaker_amd/host/Assets.cpp
     bool SavePNG(const char* filename) const;
     void SavePNG(const wchar_t* filename) const;
+    // not in the reference: the image at full precision — an uncompressed scan-line OpenEXR (FLOAT, or HALF for 2-byte channels)
+    bool SaveEXR(const char* filename) const;
 private:
     int Width, Height, ChannelCount, BytesPerChannel;
     std::vector<unsigned char> Data;

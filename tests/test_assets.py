@@ -135,6 +135,41 @@ def test_png_cpp_equals_python_and_decodes(tool, tmp_path, channels, bpc):
         assert img.reshape(-1)[0] == 0 and img.reshape(-1)[1] == 65535 and img.reshape(-1)[2] == 0 and img.reshape(-1)[3] == 65535
 
 
+@pytest.mark.parametrize("channels,bpc", [(1, 1), (2, 1), (1, 2), (4, 2), (1, 4), (2, 4), (3, 4), (4, 4)])
+def test_exr_cpp_equals_python_and_decodes(tool, tmp_path, channels, bpc):
+    """BakeTexture::SaveEXR == assets.save_exr byte for byte; the decoded channels are the texture's values exactly
+    (FLOAT / HALF bits as stored, v/255 for 1-byte channels) under the names the format's alphabetical order gives."""
+    w, h = 19, 23
+    rng = np.random.default_rng(channels * 100 + bpc)
+    tex = BakeTexture(w, h, channels, bpc)
+    if bpc == 1:
+        tex.Data[:] = rng.integers(0, 256, tex.Data.size, dtype=np.uint8)
+    else:
+        vals = rng.uniform(-0.25, 1.25, w * h * channels).astype(np.float32)
+        vals[:4] = [np.nan, np.inf, -np.inf, 1.0]
+        tex.Data[:] = (vals.astype(np.float16) if bpc == 2 else vals).view(np.uint8)
+    raw, cpp_exr, py_exr = tmp_path / "t.raw", tmp_path / "cpp.exr", tmp_path / "py.exr"
+    tex.Data.tofile(str(raw))
+    r = subprocess.run([tool, "exr", str(raw), str(cpp_exr), str(w), str(h), str(channels), str(bpc)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assets.save_exr(tex, str(py_exr))
+    assert cpp_exr.read_bytes() == py_exr.read_bytes()
+    img = assets.read_exr(str(cpp_exr))
+    names = {1: "Y", 2: "YA", 3: "RGB", 4: "RGBA"}[channels]
+    assert sorted(img) == sorted(names)
+    stored = tex.GetData().reshape(h, w, channels) if bpc == 1 else tex.GetData().view(np.float16 if bpc == 2 else np.float32).reshape(h, w, channels)
+    for c, name in enumerate(names):
+        got = img[name]
+        assert got.shape == (h, w) and got.dtype == (np.float16 if bpc == 2 else np.float32)
+        if bpc == 1:
+            assert np.array_equal(got, stored[:, :, c].astype(np.float32) / np.float32(255))
+        else:
+            assert np.array_equal(got.view(np.uint16 if bpc == 2 else np.uint32), stored[:, :, c].view(np.uint16 if bpc == 2 else np.uint32))
+    # the fixed part of the header: magic, version, first attribute
+    head = cpp_exr.read_bytes()[:17]
+    assert head == b"\x76\x2f\x31\x01\x02\x00\x00\x00channels\x00"
+
+
 def test_obj_import_tolerates_real_world_files(tool, tmp_path):
     """CRLF line ends, tabs, comments after faces, 3-component vt, blank lines, unknown statements, an unnamed group."""
     text = ("# exported by something\r\nmtllib scene.mtl\r\n\r\ng\r\nv\t0 0 0\r\nv 1 0 0\r\nv 1 1 0\r\nv 0 1 0 0.5 0.5 0.5\r\n"

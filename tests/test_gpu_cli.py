@@ -62,7 +62,7 @@ def _grid_obj(n=24):
 
 @pytest.mark.parametrize("bpc", [1, 4])
 def test_cli_obj_to_png_matches_python_host(engine, tmp_path, bpc):
-    """OBJ -> BakeObject::LoadFromFile -> Bake -> BakeTexture::SavePNG in C++ == the same chain in Python, byte for byte."""
+    """OBJ -> BakeObject::LoadFromFile -> Bake -> BakeTexture::SavePNG / SaveEXR in C++ == the same chain in Python, byte for byte."""
     from aobaker_amd import assets
     from aobaker_amd.scene import Scene
     assert os.path.exists(CLI), "build the C++ host side: make -C aobaker_amd/host"
@@ -79,7 +79,7 @@ def test_cli_obj_to_png_matches_python_host(engine, tmp_path, bpc):
     ao = tex.ao()
     assert 0.2 < ao.mean() < 0.999 and ao.min() < 0.9          # the raised block occludes its surroundings
     out = tmp_path / "ao"
-    r = subprocess.run([CLI, "--obj", str(obj), "--atlas", "96", "--bpc", str(bpc), "--out", str(out), "--png",
+    r = subprocess.run([CLI, "--obj", str(obj), "--atlas", "96", "--bpc", str(bpc), "--out", str(out), "--png", "--exr",
                         "--spp", "32", "--seed", "5", "--sampler", "1", "--accumulate", "1", "--normal-fp16", "0"],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
@@ -87,3 +87,6 @@ def test_cli_obj_to_png_matches_python_host(engine, tmp_path, bpc):
     assert open(str(out) + "_0.png", "rb").read() == assets.png_bytes(tex)
     img = assets.read_png(str(out) + "_0.png")
     assert img.shape == (96, 96, 1) and img.dtype == (np.uint8 if bpc == 1 else np.uint16)
+    assert open(str(out) + "_0.exr", "rb").read() == assets.exr_bytes(tex)
+    y = assets.read_exr(str(out) + "_0.exr")["Y"]                  # the bake at the texture's full precision
+    assert np.array_equal(y, ao.astype(np.float32))

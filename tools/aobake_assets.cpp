@@ -5,6 +5,8 @@
 //       import the OBJ into a scene and write it in aobake_cli's scene format
 //   aobake_assets png <in.raw> <out.png> <width> <height> <channels> <bytes_per_channel>
 //       wrap raw texture bytes (BakeTexture::Data layout) in a BakeTexture and save it
+//   aobake_assets exr <in.raw> <out.exr> <width> <height> <channels> <bytes_per_channel>
+//       the same through BakeTexture::SaveEXR
 #include "../include/aobaker_scene.h"
 
 #include <cstdio>
@@ -58,14 +60,14 @@ int main(int argc, char** argv)
 		}
 		return write_scene(scene, argv[3]) ? 0 : 1;
 	}
-	if (argc == 8 && std::strcmp(argv[1], "png") == 0)
+	if (argc == 8 && (std::strcmp(argv[1], "png") == 0 || std::strcmp(argv[1], "exr") == 0))
 	{
 		BakeTexture texture(std::atoi(argv[4]), std::atoi(argv[5]), std::atoi(argv[6]), std::atoi(argv[7]));
 		FILE* f = std::fopen(argv[2], "rb");
 		if (!f || std::fread(texture.GetData(), 1, texture.GetDataLength(), f) != texture.GetDataLength()) { std::fprintf(stderr, "%s: short read\n", argv[2]); return 1; }
 		std::fclose(f);
-		return texture.SavePNG(argv[3]) ? 0 : 1;
+		return (argv[1][0] == 'p' ? texture.SavePNG(argv[3]) : texture.SaveEXR(argv[3])) ? 0 : 1;
 	}
-	std::fprintf(stderr, "usage: aobake_assets obj2aobs in.obj out.aobs W H channels bpc | png in.raw out.png W H channels bpc\n");
+	std::fprintf(stderr, "usage: aobake_assets obj2aobs in.obj out.aobs W H channels bpc | png|exr in.raw out.png|out.exr W H channels bpc\n");
 	return 2;
 }

@@ -4,10 +4,11 @@
 // 1-channel 8-bit textures).
 //
 //   aobake_cli --scene <file.aobs> --out <prefix> [--spp N] [--sampler 0|1] [--accumulate 0|1]
-//   aobake_cli --obj <file.obj> [--atlas W [--atlas-height H]] [--channels C] [--bpc B] --out <prefix> [--png] ...
+//   aobake_cli --obj <file.obj> [--atlas W [--atlas-height H]] [--channels C] [--bpc B] --out <prefix> [--png] [--exr] ...
 //
 // --obj imports a Wavefront OBJ through BakeObject::LoadFromFile (the reference's import conventions, Assets.cpp);
-// --png also saves every AO texture through BakeTexture::SavePNG, as the reference's "Save AO..." button does
+// --png also saves every AO texture through BakeTexture::SavePNG, as the reference's "Save AO..." button does;
+// --exr through BakeTexture::SaveEXR (full precision: bake with --bpc 4)
 // (Scene.cpp:215-240).
 //
 // Scene file (little endian), written by aobaker_amd/scenefile.py:
@@ -67,7 +68,7 @@ static Scene* load_scene(const char* path)
 int main(int argc, char** argv)
 {
 	const char* scene_path = nullptr; const char* obj_path = nullptr; std::string out = "ao";
-	int atlas_w = 512, atlas_h = 0, channels = 1, bpc = 1; bool png = false;
+	int atlas_w = 512, atlas_h = 0, channels = 1, bpc = 1; bool png = false, exr = false;
 	AobOptions& opt = BakeEngine::Options();
 	for (int i = 1; i < argc; i++)
 	{
@@ -80,6 +81,7 @@ int main(int argc, char** argv)
 		else if (a == "--channels") channels = std::atoi(next());
 		else if (a == "--bpc") bpc = std::atoi(next());
 		else if (a == "--png") png = true;
+		else if (a == "--exr") exr = true;
 		else if (a == "--out") out = next();
 		else if (a == "--spp") opt.sample_count = std::atoi(next());
 		else if (a == "--sampler") opt.sampler = std::atoi(next());
@@ -91,7 +93,7 @@ int main(int argc, char** argv)
 		else if (a == "--bleed-mode") opt.bleed_mode = std::atoi(next());        // 0 reference, 1 nearest (AOB_BLEED_*)
 		else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
 	}
-	if (!scene_path && !obj_path) { std::fprintf(stderr, "usage: aobake_cli (--scene file.aobs | --obj file.obj [--atlas W]) --out prefix [--png] [--spp N] ...\n"); return 2; }
+	if (!scene_path && !obj_path) { std::fprintf(stderr, "usage: aobake_cli (--scene file.aobs | --obj file.obj [--atlas W]) --out prefix [--png] [--exr] [--spp N] ...\n"); return 2; }
 	Scene* scene;
 	if (obj_path)
 	{
@@ -125,6 +127,7 @@ int main(int argc, char** argv)
 			FILE* f = std::fopen(path.c_str(), "wb");
 			if (f) { std::fwrite(tex->GetData(), 1, tex->GetDataLength(), f); std::fclose(f); }
 			if (png && !tex->SavePNG((out + "_" + std::to_string(i) + ".png").c_str())) std::fprintf(stderr, "cannot write %s_%d.png\n", out.c_str(), i);
+			if (exr && !tex->SaveEXR((out + "_" + std::to_string(i) + ".exr").c_str())) std::fprintf(stderr, "cannot write %s_%d.exr\n", out.c_str(), i);
 			if (tex->GetChannelCount() == 1 && tex->GetBytesPerChannel() == 1)
 			{
 				path = out + "_" + std::to_string(i) + ".pgm";
