@@ -25,6 +25,8 @@ FP16_RTZ = 1
 FP16_RNE = 2
 BLEED_REFERENCE = 0
 BLEED_NEAREST = 1
+RASTER_REFERENCE = 0
+RASTER_CONSERVATIVE = 1
 MESH_HIDDEN_FROM_SELF = 1
 MESH_HIDDEN_FROM_OTHERS = 2
 INVALID_ADDR = 0xFFFFFFFF
@@ -51,7 +53,8 @@ class AobOptions(C.Structure):
         ("bleed_mode", C.c_int32),
         ("material_ranges", C.c_int32),
         ("morton_adaptive", C.c_int32),
-        ("reserved", C.c_int32 * 2),
+        ("raster_mode", C.c_int32),
+        ("reserved", C.c_int32 * 1),
     ]
 
 

@@ -55,6 +55,7 @@ static int validate_options(const AobOptions* o)
     if (o->normal_fp16 < AOB_FP16_OFF || o->normal_fp16 > AOB_FP16_RNE) { set_error("unknown normal_fp16 mode %d", o->normal_fp16); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->bleed_distance < 0 || o->bleed_distance > 64) { set_error("bleed_distance %d out of range", o->bleed_distance); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->bleed_mode != AOB_BLEED_REFERENCE && o->bleed_mode != AOB_BLEED_NEAREST) { set_error("unknown bleed_mode %d", o->bleed_mode); return AOB_ERR_INVALID_ARGUMENT; }
+    if (o->raster_mode != AOB_RASTER_REFERENCE && o->raster_mode != AOB_RASTER_CONSERVATIVE) { set_error("unknown raster_mode %d", o->raster_mode); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->morton_adaptive != 0 && o->morton_adaptive != 1) { set_error("morton_adaptive %d: must be 0 or 1", o->morton_adaptive); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->material_ranges != 0 && o->material_ranges != 1) { set_error("material_ranges %d: must be 0 or 1", o->material_ranges); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->bvh_builder != 0 && o->bvh_builder != 1) { set_error("bvh_builder %d: must be 0 (LBVH) or 1 (PLOC)", o->bvh_builder); return AOB_ERR_INVALID_ARGUMENT; }
@@ -153,6 +154,7 @@ void aob_default_options(AobOptions* o)
     o->bvh_quantised = 1;
     o->bvh_builder = 1;           // PLOC: +1.3 ms build, -11 % trace on the 1 M-triangle terrain
     o->morton_adaptive = 1;
+    o->raster_mode = AOB_RASTER_REFERENCE;
 }
 
 int aob_init(const AobDeviceConfig* config)

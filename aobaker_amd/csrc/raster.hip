@@ -52,6 +52,11 @@ static constexpr int kSmallBox = 16;
 
 struct CoverTri { int64_t X[3], Y[3]; int64_t px0, py0; int64_t b0, b1, b2; uint64_t bw, npix; };
 
+// AOB_RASTER_CONSERVATIVE: a fragment whose triangle covers the texel centre carries this bit in its cover key, so it
+// beats (atomicMax) every fragment that merely overlaps the texel's square
+static constexpr uint32_t kCentreBit = 0x80000000u;
+
+template <bool CONSERVATIVE>
 __device__ __forceinline__ bool cover_setup(const float* __restrict__ uvs, const uint32_t* __restrict__ indices, uint32_t t,
                                             int32_t W, int32_t H, int32_t row_begin, int32_t row_end, CoverTri& c)
 {
@@ -64,9 +69,12 @@ __device__ __forceinline__ bool cover_setup(const float* __restrict__ uvs, const
     if (area < 0) { int64_t tx = c.X[1], ty = c.Y[1]; c.X[1] = c.X[2]; c.Y[1] = c.Y[2]; c.X[2] = tx; c.Y[2] = ty; }
     int64_t minx = min(min(c.X[0], c.X[1]), c.X[2]), maxx = max(max(c.X[0], c.X[1]), c.X[2]);
     int64_t miny = min(min(c.Y[0], c.Y[1]), c.Y[2]), maxy = max(max(c.Y[0], c.Y[1]), c.Y[2]);
-    int64_t px0 = max((minx - 128 + 255) >> 8, (int64_t)0), px1 = min((maxx - 128) >> 8, (int64_t)W - 1);
+    // texels whose centre lies in the bounding box — or, CONSERVATIVE, whose open square overlaps it
+    int64_t px0 = max(CONSERVATIVE ? minx >> 8 : (minx - 128 + 255) >> 8, (int64_t)0);
+    int64_t px1 = min(CONSERVATIVE ? (maxx - 1) >> 8 : (maxx - 128) >> 8, (int64_t)W - 1);
     // only the texel rows [row_begin, row_end) of the atlas are wanted (a rank's strip; the whole atlas by default)
-    int64_t py0 = max((miny - 128 + 255) >> 8, (int64_t)row_begin), py1 = min((maxy - 128) >> 8, (int64_t)row_end - 1);
+    int64_t py0 = max(CONSERVATIVE ? miny >> 8 : (miny - 128 + 255) >> 8, (int64_t)row_begin);
+    int64_t py1 = min(CONSERVATIVE ? (maxy - 1) >> 8 : (maxy - 128) >> 8, (int64_t)row_end - 1);
     if (px1 < px0 || py1 < py0) return false;
     c.b0 = edge_top_left(c.X[0], c.Y[0], c.X[1], c.Y[1]) ? 0 : -1;
     c.b1 = edge_top_left(c.X[1], c.Y[1], c.X[2], c.Y[2]) ? 0 : -1;
@@ -77,14 +85,30 @@ __device__ __forceinline__ bool cover_setup(const float* __restrict__ uvs, const
     return true;
 }
 
+// the largest value of the edge function a -> b over the texel square around its centre value e: e + 128 (|dx| + |dy|)
+__device__ __forceinline__ int64_t edge_reach(int64_t ax, int64_t ay, int64_t bx, int64_t by)
+{
+    const int64_t dx = bx - ax, dy = by - ay;
+    return 128 * ((dx < 0 ? -dx : dx) + (dy < 0 ? -dy : dy));
+}
+
+template <bool CONSERVATIVE>
 __device__ __forceinline__ void cover_texel(const CoverTri& c, uint64_t p, uint32_t t, int32_t W, uint32_t* __restrict__ cover)
 {
     const int64_t py = c.py0 + (int64_t)(p / c.bw), px = c.px0 + (int64_t)(p % c.bw);
     const int64_t cx = px * 256 + 128, cy = py * 256 + 128;
-    if (edge_fn(c.X[0], c.Y[0], c.X[1], c.Y[1], cx, cy) + c.b0 < 0) return;
-    if (edge_fn(c.X[1], c.Y[1], c.X[2], c.Y[2], cx, cy) + c.b1 < 0) return;
-    if (edge_fn(c.X[2], c.Y[2], c.X[0], c.Y[0], cx, cy) + c.b2 < 0) return;
-    atomicMax(&cover[(uint64_t)py * W + px], t + 1);       // last fragment drawn wins
+    const int64_t e0 = edge_fn(c.X[0], c.Y[0], c.X[1], c.Y[1], cx, cy), e1 = edge_fn(c.X[1], c.Y[1], c.X[2], c.Y[2], cx, cy),
+                  e2 = edge_fn(c.X[2], c.Y[2], c.X[0], c.Y[0], cx, cy);
+    const bool centre = e0 + c.b0 >= 0 && e1 + c.b1 >= 0 && e2 + c.b2 >= 0;
+    if (!CONSERVATIVE) {
+        if (centre) atomicMax(&cover[(uint64_t)py * W + px], t + 1);       // last fragment drawn wins
+        return;
+    }
+    // the square and the triangle share area iff no edge (nor, by the loop bounds, a side of the square) separates them
+    const bool touch = e0 + edge_reach(c.X[0], c.Y[0], c.X[1], c.Y[1]) > 0 && e1 + edge_reach(c.X[1], c.Y[1], c.X[2], c.Y[2]) > 0 &&
+                       e2 + edge_reach(c.X[2], c.Y[2], c.X[0], c.Y[0]) > 0;
+    if (centre) atomicMax(&cover[(uint64_t)py * W + px], kCentreBit | (t + 1));
+    else if (touch) atomicMax(&cover[(uint64_t)py * W + px], t + 1);
 }
 
 __device__ __forceinline__ int64_t bcast64(int64_t v, int src)
@@ -93,6 +117,7 @@ __device__ __forceinline__ int64_t bcast64(int64_t v, int src)
     return (int64_t)((uint64_t)hi << 32 | lo);
 }
 
+template <bool CONSERVATIVE>
 __global__ __launch_bounds__(kBlock)
 void k_cover(const float* __restrict__ uvs, const uint32_t* __restrict__ indices, uint32_t ntri,
              int32_t W, int32_t H, int32_t row_begin, int32_t row_end, uint32_t* __restrict__ cover)
@@ -100,9 +125,9 @@ void k_cover(const float* __restrict__ uvs, const uint32_t* __restrict__ indices
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
     CoverTri c;
-    const bool live = t < ntri && cover_setup(uvs, indices, t, W, H, row_begin, row_end, c);
+    const bool live = t < ntri && cover_setup<CONSERVATIVE>(uvs, indices, t, W, H, row_begin, row_end, c);
     if (live && c.npix <= (uint64_t)kSmallBox)
-        for (uint64_t p = 0; p < c.npix; p++) cover_texel(c, p, t, W, cover);
+        for (uint64_t p = 0; p < c.npix; p++) cover_texel<CONSERVATIVE>(c, p, t, W, cover);
     // the big ones, one after the other, by the whole wavefront
     uint64_t big = __ballot(live && c.npix > (uint64_t)kSmallBox);
     while (big) {
@@ -115,7 +140,7 @@ void k_cover(const float* __restrict__ uvs, const uint32_t* __restrict__ indices
         g.b0 = bcast64(c.b0, src); g.b1 = bcast64(c.b1, src); g.b2 = bcast64(c.b2, src);
         g.bw = (uint64_t)bcast64((int64_t)c.bw, src); g.npix = (uint64_t)bcast64((int64_t)c.npix, src);
         const uint32_t gt = __shfl(t, src);
-        for (uint64_t p = lane; p < g.npix; p += 64) cover_texel(g, p, gt, W, cover);
+        for (uint64_t p = lane; p < g.npix; p += 64) cover_texel<CONSERVATIVE>(g, p, gt, W, cover);
     }
 }
 
@@ -185,8 +210,30 @@ __device__ __forceinline__ f3 xform(const MeshXform& x, const float* p, bool poi
     return r;
 }
 
+// AOB_RASTER_CONSERVATIVE: barycentric coordinates of the point of the triangle nearest to (cx, cy), for a texel whose
+// centre the triangle does not cover: the point lies on one of the edges the centre is on the wrong side of (the
+// first of them on ties).  Integer dot products; the edge parameter in float, the squared distances in double.
+__device__ __noinline__ void nearest_point(const int64_t* X, const int64_t* Y, int64_t cx, int64_t cy, float& l0, float& l1, float& l2)
+{
+    float l[3] = { l0, l1, l2 };
+    double best = INFINITY;
+    for (int e = 0; e < 3; e++) {
+        const int a = e, bb = (e + 1) % 3, cc = (e + 2) % 3;
+        if (edge_fn(X[a], Y[a], X[bb], Y[bb], cx, cy) >= 0) continue;
+        const int64_t dx = X[bb] - X[a], dy = Y[bb] - Y[a], qx = cx - X[a], qy = cy - Y[a];
+        const int64_t num = qx * dx + qy * dy, den = dx * dx + dy * dy;
+        float t; double d2;
+        if (num <= 0) { t = 0.0f; d2 = (double)(qx * qx + qy * qy); }
+        else if (num >= den) { t = 1.0f; const int64_t rx = cx - X[bb], ry = cy - Y[bb]; d2 = (double)(rx * rx + ry * ry); }
+        else { t = (float)num / (float)den; d2 = (double)(qx * qx + qy * qy) - ((double)num * (double)num) / (double)den; }
+        if (d2 < best) { best = d2; l[a] = 1.0f - t; l[bb] = t; l[cc] = 0.0f; }      // l[k] weighs vertex k
+    }
+    l0 = l[0]; l1 = l[1]; l2 = l[2];
+}
+
 struct RasterVertex { f3 wpos, wnrm; float u, v; };
 
+template <bool CONSERVATIVE>
 __global__ __launch_bounds__(kBlock)
 void k_emit_surfels(uint32_t* __restrict__ cover, uint64_t cells, const uint32_t* __restrict__ block_offsets,
                     const float* __restrict__ positions, const float* __restrict__ normals,
@@ -205,7 +252,7 @@ void k_emit_surfels(uint32_t* __restrict__ cover, uint64_t cells, const uint32_t
 #pragma unroll 1
     for (int k = 0; k < kScanItems; k++) {
         if (!cv[k]) continue;
-        const uint32_t t = cv[k] - 1;
+        const uint32_t t = (cv[k] & ~kCentreBit) - 1;
         const uint64_t cell = base + k;
         const int32_t py = (int32_t)(cell / (uint64_t)W), px = (int32_t)(cell % (uint64_t)W);
         RasterVertex rv[3];
@@ -227,9 +274,10 @@ void k_emit_surfels(uint32_t* __restrict__ cover, uint64_t cells, const uint32_t
         }
         const int64_t cx = (int64_t)px * 256 + 128, cy = (int64_t)py * 256 + 128;
         const float fa = (float)area;
-        const float l0 = (float)edge_fn(X[1], Y[1], X[2], Y[2], cx, cy) / fa;
-        const float l1 = (float)edge_fn(X[2], Y[2], X[0], Y[0], cx, cy) / fa;
-        const float l2 = (float)edge_fn(X[0], Y[0], X[1], Y[1], cx, cy) / fa;
+        float l0 = (float)edge_fn(X[1], Y[1], X[2], Y[2], cx, cy) / fa;
+        float l1 = (float)edge_fn(X[2], Y[2], X[0], Y[0], cx, cy) / fa;
+        float l2 = (float)edge_fn(X[0], Y[0], X[1], Y[1], cx, cy) / fa;
+        if (CONSERVATIVE && !(cv[k] & kCentreBit)) nearest_point(X, Y, cx, cy, l0, l1, l2);
 #define AOB_LERP(f) fmaf(l2, rv[2].f, fmaf(l1, rv[1].f, l0 * rv[0].f))
         AobSurfel s;
         s.texel_x = px; s.texel_y = py;
@@ -391,8 +439,12 @@ int rasterize_material(AobBake* b, int32_t material, int32_t row_begin, int32_t 
         AOB_HIP(hipMemsetAsync(m.cover, 0, sizeof(uint32_t) * cells, s));
         if (mesh.triangle_count) {
             uint32_t grid = (mesh.triangle_count + kBlock - 1) / kBlock;
-            hipLaunchKernelGGL(k_cover, dim3(grid), dim3(kBlock), 0, s, mesh.uvs, mesh.indices, mesh.triangle_count,
-                               m.width, m.height, row_begin, row_end, m.cover);
+            if (b->opt.raster_mode == AOB_RASTER_CONSERVATIVE)
+                hipLaunchKernelGGL(k_cover<true>, dim3(grid), dim3(kBlock), 0, s, mesh.uvs, mesh.indices, mesh.triangle_count,
+                                   m.width, m.height, row_begin, row_end, m.cover);
+            else
+                hipLaunchKernelGGL(k_cover<false>, dim3(grid), dim3(kBlock), 0, s, mesh.uvs, mesh.indices, mesh.triangle_count,
+                                   m.width, m.height, row_begin, row_end, m.cover);
         }
         hipLaunchKernelGGL(k_scan_count, dim3(nblocks), dim3(kBlock), 0, s, m.cover, cells, m.block_sums);
         hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(kBlock), 0, s, m.block_sums, nblocks);
@@ -404,9 +456,14 @@ int rasterize_material(AobBake* b, int32_t material, int32_t row_begin, int32_t 
         if (count) {
             MeshXform xf;
             for (int k = 0; k < 16; k++) xf.m[k] = mesh.model[k];
-            hipLaunchKernelGGL(k_emit_surfels, dim3(nblocks), dim3(kBlock), 0, s, m.cover, cells, m.block_sums,
-                               mesh.positions, mesh.normals, mesh.uvs, mesh.indices, xf, m.width, m.height,
-                               b->opt.normal_fp16, m.surfels + m.surfel_count, m.section_index + m.surfel_count);
+            if (b->opt.raster_mode == AOB_RASTER_CONSERVATIVE)
+                hipLaunchKernelGGL(k_emit_surfels<true>, dim3(nblocks), dim3(kBlock), 0, s, m.cover, cells, m.block_sums,
+                                   mesh.positions, mesh.normals, mesh.uvs, mesh.indices, xf, m.width, m.height,
+                                   b->opt.normal_fp16, m.surfels + m.surfel_count, m.section_index + m.surfel_count);
+            else
+                hipLaunchKernelGGL(k_emit_surfels<false>, dim3(nblocks), dim3(kBlock), 0, s, m.cover, cells, m.block_sums,
+                                   mesh.positions, mesh.normals, mesh.uvs, mesh.indices, xf, m.width, m.height,
+                                   b->opt.normal_fp16, m.surfels + m.surfel_count, m.section_index + m.surfel_count);
             // trace order: 8x8 tiles (perm), then the per-surfel trace records in that order
             const uint32_t tiles_x = (uint32_t)(m.width + 7) / 8, tiles_y = (uint32_t)(m.height + 7) / 8;
             const uint64_t total_e = (uint64_t)tiles_x * tiles_y * 64u;

@@ -56,6 +56,14 @@ enum { AOB_FP16_OFF = 0,                   /* keep normal + V in fp32 */
  * by scan order (rows top to bottom, then left to right). */
 enum { AOB_BLEED_REFERENCE = 0, AOB_BLEED_NEAREST = 1 };
 
+/* Which texels of a UV triangle get a surfel (rasterise).  REFERENCE is the D3D11 rule the reference draws with: the
+ * texels whose CENTRE the triangle covers (top-left rule), the last triangle drawn winning a texel.  CONSERVATIVE adds
+ * the texels whose SQUARE the triangle overlaps without covering the centre — a chart thinner than a texel still gets
+ * its surfels instead of borrowing a neighbour's value from the bleed pass.  Such a surfel is sampled at the
+ * point of the triangle nearest to the texel centre; a triangle that
+ * covers the centre always wins over one that only touches the square, the last drawn winning within each class. */
+enum { AOB_RASTER_REFERENCE = 0, AOB_RASTER_CONSERVATIVE = 1 };
+
 typedef struct AobOptions {
     int32_t  sample_count;        /* rays per surfel (reference sampleCount)              */
     int32_t  sampler;             /* AOB_SAMPLER_*                                        */
@@ -85,7 +93,8 @@ typedef struct AobOptions {
                                      spatial-median builder would split them (the longest cell first, radeon_rays.h:283-287)
                                      instead of x, y, z in turn (0: build_hlbvh.cl's order).  Flat scenes gain: 8 % fewer
                                      node visits per ray on the 1 M-triangle terrain                                  */
-    int32_t  reserved[2];
+    int32_t  raster_mode;         /* AOB_RASTER_*; default REFERENCE                                  */
+    int32_t  reserved[1];
 } AobOptions;
 
 /* ---- scene description ----------------------------------------------------

@@ -593,6 +593,13 @@ static inline int edge_top_left(int64_t ax, int64_t ay, int64_t bx, int64_t by)
     return dy < 0 || (dy == 0 && dx > 0);
 }
 
+/* the largest value of the edge function a -> b over a texel square, above its value at the centre */
+static inline int64_t edge_reach(int64_t ax, int64_t ay, int64_t bx, int64_t by)
+{
+    const int64_t dx = bx - ax, dy = by - ay;
+    return 128 * ((dx < 0 ? -dx : dx) + (dy < 0 ? -dy : dy));
+}
+
 typedef struct { f3 wpos, wnrm; float u, v; } RasterVertex;
 
 static inline float quantise_fp16(float v, int mode)
@@ -639,8 +646,10 @@ uint64_t orc_rasterize_ex(const AobSceneDesc* scene, int32_t material, const Aob
             int64_t maxx = X[0] > X[1] ? X[0] : X[1]; if (X[2] > maxx) maxx = X[2];
             int64_t miny = Y[0] < Y[1] ? Y[0] : Y[1]; if (Y[2] < miny) miny = Y[2];
             int64_t maxy = Y[0] > Y[1] ? Y[0] : Y[1]; if (Y[2] > maxy) maxy = Y[2];
-            int64_t px0 = (minx - 128 + 255) >> 8, px1 = (maxx - 128) >> 8;
-            int64_t py0 = (miny - 128 + 255) >> 8, py1 = (maxy - 128) >> 8;
+            /* texels whose centre lies in the bounding box — or, conservative, whose open square overlaps it */
+            const int cons = opt->raster_mode == AOB_RASTER_CONSERVATIVE;
+            int64_t px0 = cons ? minx >> 8 : (minx - 128 + 255) >> 8, px1 = cons ? (maxx - 1) >> 8 : (maxx - 128) >> 8;
+            int64_t py0 = cons ? miny >> 8 : (miny - 128 + 255) >> 8, py1 = cons ? (maxy - 1) >> 8 : (maxy - 128) >> 8;
             if (px0 < 0) px0 = 0; if (py0 < 0) py0 = 0;
             if (px1 > W - 1) px1 = W - 1; if (py1 > H - 1) py1 = H - 1;
             int64_t b0 = edge_top_left(X[0], Y[0], X[1], Y[1]) ? 0 : -1;
@@ -649,11 +658,20 @@ uint64_t orc_rasterize_ex(const AobSceneDesc* scene, int32_t material, const Aob
             for (int64_t py = py0; py <= py1; py++) {
                 for (int64_t px = px0; px <= px1; px++) {
                     int64_t cx = px * 256 + 128, cy = py * 256 + 128;
-                    if (edge_fn(X[0], Y[0], X[1], Y[1], cx, cy) + b0 < 0) continue;
-                    if (edge_fn(X[1], Y[1], X[2], Y[2], cx, cy) + b1 < 0) continue;
-                    if (edge_fn(X[2], Y[2], X[0], Y[0], cx, cy) + b2 < 0) continue;
+                    const int64_t e0 = edge_fn(X[0], Y[0], X[1], Y[1], cx, cy), e1 = edge_fn(X[1], Y[1], X[2], Y[2], cx, cy),
+                                  e2 = edge_fn(X[2], Y[2], X[0], Y[0], cx, cy);
+                    const int centre = e0 + b0 >= 0 && e1 + b1 >= 0 && e2 + b2 >= 0;
+                    uint32_t key = t + 1;
+                    if (cons) {
+                        /* AOB_RASTER_CONSERVATIVE: the texel's square and the triangle share area iff no edge separates them
+                         * (the sides of the square: the loop bounds); a triangle covering the centre beats any that does not */
+                        const int touch = e0 + edge_reach(X[0], Y[0], X[1], Y[1]) > 0 && e1 + edge_reach(X[1], Y[1], X[2], Y[2]) > 0 &&
+                                          e2 + edge_reach(X[2], Y[2], X[0], Y[0]) > 0;
+                        if (!centre && !touch) continue;
+                        if (centre) key |= 0x80000000u;
+                    } else if (!centre) continue;
                     uint32_t* c = &cover[(size_t)py * W + px];
-                    if (t + 1 > *c) *c = t + 1;
+                    if (key > *c) *c = key;
                 }
             }
         }
@@ -663,7 +681,8 @@ uint64_t orc_rasterize_ex(const AobSceneDesc* scene, int32_t material, const Aob
             for (int32_t px = 0; px < W; px++) {
                 uint32_t c = cover[(size_t)py * W + px];
                 if (!c) continue;
-                uint32_t t = c - 1;
+                uint32_t t = (c & 0x7fffffffu) - 1;
+                const int clamp = opt->raster_mode == AOB_RASTER_CONSERVATIVE && !(c & 0x80000000u);
                 RasterVertex rv[3];
                 int64_t X[3], Y[3];
                 for (int k = 0; k < 3; k++) {
@@ -686,6 +705,24 @@ uint64_t orc_rasterize_ex(const AobSceneDesc* scene, int32_t material, const Aob
                 float l0 = (float)edge_fn(X[1], Y[1], X[2], Y[2], cx, cy) / fa;
                 float l1 = (float)edge_fn(X[2], Y[2], X[0], Y[0], cx, cy) / fa;
                 float l2 = (float)edge_fn(X[0], Y[0], X[1], Y[1], cx, cy) / fa;
+                if (clamp) {
+                    /* the centre is outside: sample at the point of the triangle nearest to it, which lies on one of the
+                     * edges the centre is on the wrong side of (first such edge on ties) */
+                    float l[3] = { l0, l1, l2 };
+                    double best = INFINITY;
+                    for (int e = 0; e < 3; e++) {
+                        const int a = e, bb = (e + 1) % 3, cc = (e + 2) % 3;
+                        if (edge_fn(X[a], Y[a], X[bb], Y[bb], cx, cy) >= 0) continue;
+                        const int64_t dx = X[bb] - X[a], dy = Y[bb] - Y[a], qx = cx - X[a], qy = cy - Y[a];
+                        const int64_t num = qx * dx + qy * dy, den = dx * dx + dy * dy;
+                        float t; double d2;
+                        if (num <= 0) { t = 0.0f; d2 = (double)(qx * qx + qy * qy); }
+                        else if (num >= den) { t = 1.0f; const int64_t rx = cx - X[bb], ry = cy - Y[bb]; d2 = (double)(rx * rx + ry * ry); }
+                        else { t = (float)num / (float)den; d2 = (double)(qx * qx + qy * qy) - ((double)num * (double)num) / (double)den; }
+                        if (d2 < best) { best = d2; l[a] = 1.0f - t; l[bb] = t; l[cc] = 0.0f; }
+                    }
+                    l0 = l[0]; l1 = l[1]; l2 = l[2];
+                }
 #define LERP(f) fmaf(l2, rv[2].f, fmaf(l1, rv[1].f, l0 * rv[0].f))
                 if (total < capacity) {
                     AobSurfel* s = &surfels[total];

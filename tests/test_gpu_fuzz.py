@@ -1,7 +1,7 @@
 """Randomised GPU-vs-oracle parity: random scenes (triangle soups with random UVs, bumpy grids, degenerate and duplicate
 triangles, several objects / sections / materials with random transforms, visibility flags and ranges) baked with random
 options (every sampler, scoring, accumulation, structure, builder, Morton order, bleed mode, fp16 mode, odd sample counts,
-short rays, zero bias) must give the oracle's textures byte for byte.  Seeds are fixed: the cases are the same every run."""
+short rays, zero bias, both raster modes) must give the oracle's textures byte for byte.  Seeds are fixed: the cases are the same every run."""
 import numpy as np
 import pytest
 
@@ -55,6 +55,7 @@ def random_options(rng):
     o.ray_tmax = float(rng.choice([1e6, 0.7, 3.0])); o.ray_bias = float(rng.choice([0.001, 0.0, 0.01]))
     o.bvh_width, o.bvh_quantised = [(4, 1), (4, 1), (2, 1), (2, 0)][int(rng.integers(0, 4))]
     o.bvh_builder = int(rng.integers(0, 2)); o.morton_adaptive = int(rng.integers(0, 2))
+    o.raster_mode = int(rng.integers(0, 2))       # drawn last: the cases keep the options they had before it existed
     return o
 
 

@@ -124,6 +124,61 @@ def test_surfels_bit_exact(engine, orc, name, fp16):
     assert bits(got).tobytes() == bits(ref).tobytes()
 
 
+def _soup_scene(seed=11, n=300, atlas=96):
+    """Random small triangles with random UVs: slivers, overlaps, charts thinner than a texel."""
+    from aobaker_amd.scene import BakeObject, MaterialObject, RenderMesh, Scene, Section, make_vertices
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(0, 1, (n, 1, 3)); v = (c + rng.normal(scale=0.05, size=(n, 3, 3))).astype(np.float32).reshape(-1, 3)
+    uvc = rng.uniform(0, 1, (n, 1, 2)); uv = (uvc + rng.normal(scale=0.02, size=(n, 3, 2)) * rng.uniform(0.02, 1.0, (n, 1, 2))).astype(np.float32).reshape(-1, 2)
+    nrm = rng.normal(size=(3 * n, 3)).astype(np.float32); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    sc = Scene(); m = sc.AddMaterial(MaterialObject("A", atlas, atlas))
+    o = sc.AddObject(BakeObject("O")); o.AddSection(Section("s", RenderMesh(make_vertices(v, nrm, uv), np.arange(3 * n, dtype=np.uint32)), m))
+    return sc
+
+
+@pytest.mark.parametrize("fp16", [capi.FP16_OFF, capi.FP16_RNE])
+@pytest.mark.parametrize("name", ["cube", "two_section", "sphere", "terrain", "soup", "soup_large", "sphere_large"])
+def test_conservative_surfels_bit_exact(engine, orc, name, fp16):
+    """AOB_RASTER_CONSERVATIVE: texels whose square a triangle overlaps get a surfel at the triangle's nearest point."""
+    make = {"soup": _soup_scene, "soup_large": lambda: _soup_scene(seed=3, n=20000, atlas=512),
+            "sphere_large": lambda: scenes.sphere_scene(n=187, atlas=1024, seed=2)}.get(name) or SCENES[name]
+    flat = FlatScene(make())
+    opt = make_options(orc, normal_fp16=fp16, raster_mode=capi.RASTER_CONSERVATIVE)
+    ref, _ = orc.rasterize(flat.desc, 0, opt)
+    plain, _ = orc.rasterize(flat.desc, 0, make_options(orc, normal_fp16=fp16))
+    with Baker(flat, opt) as b:
+        b.rasterize(0)
+        got = b.surfels(0)
+    assert len(got) == len(ref) >= len(plain) > 0
+    assert bits(got).tobytes() == bits(ref).tobytes()
+    if name == "soup":
+        assert len(ref) > 1.2 * len(plain)                 # the slivers matter here
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_conservative_bake_equals_oracle_and_stitches(engine, orc, mode):
+    """A whole bake in conservative mode == oracle; strips of texel rows stitch to it (a triangle straddling two strips
+    gives each strip its texels)."""
+    from aobaker_amd import dist as aod
+    flat = FlatScene(_soup_scene(seed=5, n=200, atlas=64))
+    opt = make_options(orc, sample_count=8, raster_mode=capi.RASTER_CONSERVATIVE, **MODES[mode])
+    m = flat.material_array[0]
+    nodes, _ = orc.bvh_build(orc.scene_triangles(flat.desc))
+    surfels, sidx = orc.rasterize(flat.desc, 0, opt)
+    want, _ = orc.trace(nodes, surfels, sidx, opt, m.width, m.height, orc.compat_table(opt))
+    with Baker(flat, opt) as b:
+        b.build_bvh(); b.rasterize(0); b.trace(0)
+        full = b.results(0).copy()
+        assert np.array_equal(full["total_bits"], want["total_bits"]) and np.array_equal(full["weight_bits"], want["weight_bits"])
+        if mode == 2:                                       # the texel-keyed sampler: strips give the cells of the whole bake
+            stitched = np.zeros_like(full)
+            for r in range(3):
+                y0, y1 = aod.row_window(m.height, r, 3)
+                b.rasterize(0, (y0, y1)); b.trace(0, 0, b.surfel_count(0))
+                stitched[y0 * m.width:y1 * m.width] = b.results(0)[y0 * m.width:y1 * m.width]
+            assert np.array_equal(stitched["total_bits"], full["total_bits"]) and np.array_equal(stitched["weight_bits"], full["weight_bits"])
+
+
 MODES = [
     dict(sampler=capi.SAMPLER_REFERENCE_COMPAT, accumulate=capi.ACCUMULATE_QUANTISED, use_any_hit=1),
     dict(sampler=capi.SAMPLER_REFERENCE_COMPAT, accumulate=capi.ACCUMULATE_QUANTISED, use_any_hit=0),

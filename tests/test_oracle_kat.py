@@ -205,6 +205,121 @@ def test_raster_edge_on_texel_centre(orc):
     assert len(surfels) == 4 * 8
 
 
+def _quads_scene(quads, atlas=8):
+    """quads: [(x0, y0, x1, y1, height)] in texel units, each two triangles of a horizontal rectangle at world y = height."""
+    from aobaker_amd.scene import BakeObject, MaterialObject, RenderMesh, Scene, Section, make_vertices
+    pos, uvs, idx = [], [], []
+    for x0, y0, x1, y1, hgt in quads:
+        b = len(pos)
+        for x, y in ((x0, y0), (x1, y0), (x1, y1), (x0, y1)):
+            pos.append([x, hgt, y]); uvs.append([x / atlas, y / atlas])
+        idx += [b, b + 1, b + 2, b, b + 2, b + 3]
+    sc = Scene(); m = sc.AddMaterial(MaterialObject("A", atlas, atlas))
+    o = sc.AddObject(BakeObject("O"))
+    o.AddSection(Section("s", RenderMesh(make_vertices(np.float32(pos), np.tile(np.float32([0, 1, 0]), (len(pos), 1)), np.float32(uvs)), np.uint32(idx)), m))
+    return FlatScene(sc)
+
+
+def test_conservative_raster_gives_a_sliver_its_texels(orc):
+    """AOB_RASTER_CONSERVATIVE: a chart thinner than a texel covers no texel centre — REFERENCE finds nothing, CONSERVATIVE
+    every texel whose square it overlaps, sampled inside the chart."""
+    flat = _quads_scene([(1.1, 3.6, 6.9, 3.9, 2.0)])
+    ref, _ = orc.rasterize(flat.desc, 0, opts(orc, normal_fp16=capi.FP16_OFF))
+    assert len(ref) == 0
+    got, sidx = orc.rasterize(flat.desc, 0, opts(orc, normal_fp16=capi.FP16_OFF, raster_mode=capi.RASTER_CONSERVATIVE))
+    assert list(zip(got["texel_x"].tolist(), got["texel_y"].tolist())) == [(x, 3) for x in range(1, 7)]
+    assert np.array_equal(sidx, np.arange(6))
+    # the sample lies in the chart: world (x, z) = (u, v) in texels here
+    assert (got["position"][:, 0] >= 1.1 - 1e-5).all() and (got["position"][:, 0] <= 6.9 + 1e-5).all()
+    assert (got["position"][:, 2] >= 3.6 - 1e-5).all() and (got["position"][:, 2] <= 3.9 + 1e-5).all()
+    assert np.allclose(got["position"][:, 1], 2.0, atol=1e-6)
+    # the nearest point of the winning (last drawn) triangle: on its diagonal, all but straight below the texel centre
+    assert np.allclose(got["position"][:, 0], got["texel_x"] + 0.5, atol=0.02)
+
+
+def test_conservative_raster_touching_is_not_overlapping(orc):
+    """A chart whose edges lie on texel boundaries gains no ring of extra texels, and the surfels of the texels whose
+    centre it covers are the REFERENCE ones, bit for bit."""
+    flat = _quads_scene([(2, 2, 6, 6, 0.0)])
+    ref, _ = orc.rasterize(flat.desc, 0, opts(orc))
+    got, _ = orc.rasterize(flat.desc, 0, opts(orc, raster_mode=capi.RASTER_CONSERVATIVE))
+    assert len(ref) == 16 and got.tobytes() == ref.tobytes()
+    # half a texel further out on every side: one ring more, 36 texels
+    flat = _quads_scene([(1.5, 1.5, 6.5, 6.5, 0.0)])
+    ref, _ = orc.rasterize(flat.desc, 0, opts(orc))
+    got, _ = orc.rasterize(flat.desc, 0, opts(orc, raster_mode=capi.RASTER_CONSERVATIVE))
+    assert len(ref) == 25 and len(got) == 36            # REFERENCE: the centres on the left and top edges are in (top-left rule)
+    inner = (got["texel_x"] >= 1) & (got["texel_x"] < 6) & (got["texel_y"] >= 1) & (got["texel_y"] < 6)
+    assert got[inner].tobytes() == ref.tobytes()
+    # the ring's samples lie on the chart's border, nearest to their texel centres
+    ring = got[~inner]
+    assert np.allclose(ring["position"][:, [0, 2]], np.clip(np.stack([ring["texel_x"], ring["texel_y"]], 1) + 0.5, 1.5, 6.5), atol=1e-5)
+
+
+def test_conservative_raster_centre_coverage_wins(orc):
+    """A triangle that covers a texel's centre keeps the texel against a LATER triangle that only overlaps its square."""
+    flat = _quads_scene([(2, 2, 6, 6, 0.0), (1.0, 4.1, 7.0, 4.3, 9.0)])         # the sliver is drawn last, at height 9
+    got, _ = orc.rasterize(flat.desc, 0, opts(orc, normal_fp16=capi.FP16_OFF, raster_mode=capi.RASTER_CONSERVATIVE))
+    by_texel = {(int(s["texel_x"]), int(s["texel_y"])): float(s["position"][1]) for s in got}
+    assert len(by_texel) == 16 + 2
+    assert all(by_texel[(x, y)] == 0.0 for x in range(2, 6) for y in range(2, 6))
+    assert by_texel[(1, 4)] == 9.0 and by_texel[(6, 4)] == 9.0
+    # among the triangles that only overlap, the last drawn wins (REFERENCE's rule within the class)
+    flat = _quads_scene([(1.0, 4.1, 7.0, 4.3, 9.0), (1.0, 4.6, 7.0, 4.8, 5.0)])
+    got, _ = orc.rasterize(flat.desc, 0, opts(orc, normal_fp16=capi.FP16_OFF, raster_mode=capi.RASTER_CONSERVATIVE))
+    assert len(got) == 6 and np.allclose(got["position"][:, 1], 5.0, atol=1e-5)
+
+
+def test_conservative_coverage_equals_brute_force(orc):
+    """Which texels get a surfel, against an exact restatement in Python integers: open texel square vs triangle by the
+    separating-axis test, centre coverage by the top-left rule."""
+    from aobaker_amd.scene import BakeObject, MaterialObject, RenderMesh, Scene, Section, make_vertices
+    rng = np.random.default_rng(11)
+    n, W = 60, 32
+    uvc = rng.uniform(0, 1, (n, 1, 2)); uv = (uvc + rng.normal(scale=0.03, size=(n, 3, 2)) * rng.uniform(0.02, 1.0, (n, 1, 2))).astype(np.float32).reshape(-1, 2)
+    pos = np.concatenate([uv, np.zeros((3 * n, 1), np.float32)], axis=1)
+    sc = Scene(); m = sc.AddMaterial(MaterialObject("A", W, W))
+    o = sc.AddObject(BakeObject("O")); o.AddSection(Section("s", RenderMesh(make_vertices(pos, np.tile(np.float32([0, 0, 1]), (3 * n, 1)), uv), np.arange(3 * n, dtype=np.uint32)), m))
+    got, _ = orc.rasterize(FlatScene(sc).desc, 0, opts(orc, raster_mode=capi.RASTER_CONSERVATIVE))
+    plain, _ = orc.rasterize(FlatScene(sc).desc, 0, opts(orc))
+    snap = lambda v: int(np.rint(np.float32(np.float32(v) * np.float32(W)) * np.float32(256)))
+    edge = lambda a, b, p: (b[0] - a[0]) * (p[1] - a[1]) - (b[1] - a[1]) * (p[0] - a[0])
+    touched, centred = set(), set()
+    for t in range(n):
+        P = [(snap(uv[3 * t + k][0]), snap(uv[3 * t + k][1])) for k in range(3)]
+        area = edge(P[0], P[1], P[2])
+        if area == 0:
+            continue
+        if area < 0:
+            P[1], P[2] = P[2], P[1]
+        xs, ys = [p[0] for p in P], [p[1] for p in P]
+        for py in range(W):
+            for px in range(W):
+                c = (px * 256 + 128, py * 256 + 128)
+                es = [edge(P[k], P[(k + 1) % 3], c) for k in range(3)]
+                d = [(P[(k + 1) % 3][0] - P[k][0], P[(k + 1) % 3][1] - P[k][1]) for k in range(3)]
+                if all(e >= (0 if (dy < 0 or (dy == 0 and dx > 0)) else 1) for e, (dx, dy) in zip(es, d)):
+                    centred.add((py, px))
+                box = min(xs) < c[0] + 128 and max(xs) > c[0] - 128 and min(ys) < c[1] + 128 and max(ys) > c[1] - 128
+                if box and all(e + 128 * (abs(dx) + abs(dy)) > 0 for e, (dx, dy) in zip(es, d)):
+                    touched.add((py, px))
+    assert sorted(zip(plain["texel_y"].tolist(), plain["texel_x"].tolist())) == sorted(centred)
+    assert list(zip(got["texel_y"].tolist(), got["texel_x"].tolist())) == sorted(touched | centred) and len(touched) > 1.5 * len(centred)
+
+
+@pytest.mark.parametrize("make", [lambda: scenes.sphere_scene(n=24, atlas=96), lambda: scenes.terrain_scene(grid=40, atlas=64),
+                                  lambda: scenes.cube_scene(64)])
+def test_conservative_raster_extends_the_reference_coverage(orc, make):
+    flat = FlatScene(make())
+    ref, _ = orc.rasterize(flat.desc, 0, opts(orc))
+    got, _ = orc.rasterize(flat.desc, 0, opts(orc, raster_mode=capi.RASTER_CONSERVATIVE))
+    W = flat.material_array[0].width
+    cell = lambda a: a["texel_y"].astype(np.int64) * W + a["texel_x"]
+    keep = np.isin(cell(got), cell(ref))
+    assert keep.sum() == len(ref) and got[keep].tobytes() == ref.tobytes() and len(got) >= len(ref)
+    assert np.all(np.diff(cell(got)) > 0)                                       # row-major, one surfel per texel
+
+
 # ---- (1)(2) trivial scenes -------------------------------------------------------------------
 @pytest.mark.parametrize("mode", ["compat", "cosine"])
 def test_open_plane_is_white(orc, mode):
