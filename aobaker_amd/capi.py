@@ -27,6 +27,8 @@ BLEED_REFERENCE = 0
 BLEED_NEAREST = 1
 RASTER_REFERENCE = 0
 RASTER_CONSERVATIVE = 1
+LAYERS_LAST = 0
+LAYERS_ALL = 1
 MESH_HIDDEN_FROM_SELF = 1
 MESH_HIDDEN_FROM_OTHERS = 2
 INVALID_ADDR = 0xFFFFFFFF
@@ -54,7 +56,7 @@ class AobOptions(C.Structure):
         ("material_ranges", C.c_int32),
         ("morton_adaptive", C.c_int32),
         ("raster_mode", C.c_int32),
-        ("reserved", C.c_int32 * 1),
+        ("raster_layers", C.c_int32),
     ]
 
 

@@ -48,6 +48,7 @@ struct DeviceMaterial {
     int32_t window_rows = 0;              // texel rows the last rasterisation covered (height, or a strip of it)
     uint8_t* host_data = nullptr;
     uint32_t* cover = nullptr;            // W*H: winning triangle index + 1, per section pass
+    uint32_t* prev_layer = nullptr;       // W*H, AOB_LAYERS_ALL only: triangle index + 1 of the texel's fragment in the layer before
     uint32_t* block_sums = nullptr;       // scan partials
     uint32_t  scan_blocks = 0;
     AobSurfel* surfels = nullptr;         // concatenated, row-major per section

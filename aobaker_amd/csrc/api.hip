@@ -56,6 +56,8 @@ static int validate_options(const AobOptions* o)
     if (o->bleed_distance < 0 || o->bleed_distance > 64) { set_error("bleed_distance %d out of range", o->bleed_distance); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->bleed_mode != AOB_BLEED_REFERENCE && o->bleed_mode != AOB_BLEED_NEAREST) { set_error("unknown bleed_mode %d", o->bleed_mode); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->raster_mode != AOB_RASTER_REFERENCE && o->raster_mode != AOB_RASTER_CONSERVATIVE) { set_error("unknown raster_mode %d", o->raster_mode); return AOB_ERR_INVALID_ARGUMENT; }
+    if (o->raster_layers != AOB_LAYERS_LAST && o->raster_layers != AOB_LAYERS_ALL) { set_error("unknown raster_layers %d", o->raster_layers); return AOB_ERR_INVALID_ARGUMENT; }
+    if (o->raster_layers == AOB_LAYERS_ALL && o->raster_mode == AOB_RASTER_CONSERVATIVE) { set_error("raster_layers ALL needs raster_mode REFERENCE"); return AOB_ERR_UNSUPPORTED; }
     if (o->morton_adaptive != 0 && o->morton_adaptive != 1) { set_error("morton_adaptive %d: must be 0 or 1", o->morton_adaptive); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->material_ranges != 0 && o->material_ranges != 1) { set_error("material_ranges %d: must be 0 or 1", o->material_ranges); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->bvh_builder != 0 && o->bvh_builder != 1) { set_error("bvh_builder %d: must be 0 (LBVH) or 1 (PLOC)", o->bvh_builder); return AOB_ERR_INVALID_ARGUMENT; }
@@ -86,7 +88,7 @@ static void free_bake(AobBake* b)
     if (!b) return;
     for (auto& m : b->meshes) { hipFree(m.positions); hipFree(m.normals); hipFree(m.uvs); hipFree(m.indices); }
     for (auto& m : b->materials) {
-        hipFree(m.cover); hipFree(m.block_sums); hipFree(m.surfels); hipFree(m.section_index); hipFree(m.frames); hipFree(m.perm); hipFree(m.tile_sums); hipFree(m.tile_row_prefix);
+        hipFree(m.cover); hipFree(m.prev_layer); hipFree(m.block_sums); hipFree(m.surfels); hipFree(m.section_index); hipFree(m.frames); hipFree(m.perm); hipFree(m.tile_sums); hipFree(m.tile_row_prefix);
         if (m.tile_row_prefix_host) hipHostFree(m.tile_row_prefix_host);
         hipFree(m.results); hipFree(m.image);
     }
@@ -155,6 +157,7 @@ void aob_default_options(AobOptions* o)
     o->bvh_builder = 1;           // PLOC: +1.3 ms build, -11 % trace on the 1 M-triangle terrain
     o->morton_adaptive = 1;
     o->raster_mode = AOB_RASTER_REFERENCE;
+    o->raster_layers = AOB_LAYERS_LAST;
 }
 
 int aob_init(const AobDeviceConfig* config)

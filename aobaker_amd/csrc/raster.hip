@@ -92,14 +92,22 @@ __device__ __forceinline__ int64_t edge_reach(int64_t ax, int64_t ay, int64_t bx
     return 128 * ((dx < 0 ? -dx : dx) + (dy < 0 ? -dy : dy));
 }
 
-template <bool CONSERVATIVE>
-__device__ __forceinline__ void cover_texel(const CoverTri& c, uint64_t p, uint32_t t, int32_t W, uint32_t* __restrict__ cover)
+// AOB_LAYERS_ALL (PEEL): one pass per layer of the reference's stencil peel.  The pass keeps, per texel, the FIRST triangle
+// (in index order) after the one the previous pass kept: cover holds 0xffffffff - t, so atomicMax finds the smallest t
+// and 0 still means "no fragment"; prev holds the previous layer's t + 1 (0: none yet).
+template <bool CONSERVATIVE, bool PEEL>
+__device__ __forceinline__ void cover_texel(const CoverTri& c, uint64_t p, uint32_t t, int32_t W, uint32_t* __restrict__ cover,
+                                            const uint32_t* __restrict__ prev)
 {
     const int64_t py = c.py0 + (int64_t)(p / c.bw), px = c.px0 + (int64_t)(p % c.bw);
     const int64_t cx = px * 256 + 128, cy = py * 256 + 128;
     const int64_t e0 = edge_fn(c.X[0], c.Y[0], c.X[1], c.Y[1], cx, cy), e1 = edge_fn(c.X[1], c.Y[1], c.X[2], c.Y[2], cx, cy),
                   e2 = edge_fn(c.X[2], c.Y[2], c.X[0], c.Y[0], cx, cy);
     const bool centre = e0 + c.b0 >= 0 && e1 + c.b1 >= 0 && e2 + c.b2 >= 0;
+    if (PEEL) {
+        if (centre && t + 1 > prev[(uint64_t)py * W + px]) atomicMax(&cover[(uint64_t)py * W + px], 0xffffffffu - t);
+        return;
+    }
     if (!CONSERVATIVE) {
         if (centre) atomicMax(&cover[(uint64_t)py * W + px], t + 1);       // last fragment drawn wins
         return;
@@ -117,17 +125,17 @@ __device__ __forceinline__ int64_t bcast64(int64_t v, int src)
     return (int64_t)((uint64_t)hi << 32 | lo);
 }
 
-template <bool CONSERVATIVE>
+template <bool CONSERVATIVE, bool PEEL>
 __global__ __launch_bounds__(kBlock)
 void k_cover(const float* __restrict__ uvs, const uint32_t* __restrict__ indices, uint32_t ntri,
-             int32_t W, int32_t H, int32_t row_begin, int32_t row_end, uint32_t* __restrict__ cover)
+             int32_t W, int32_t H, int32_t row_begin, int32_t row_end, uint32_t* __restrict__ cover, const uint32_t* __restrict__ prev)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
     CoverTri c;
     const bool live = t < ntri && cover_setup<CONSERVATIVE>(uvs, indices, t, W, H, row_begin, row_end, c);
     if (live && c.npix <= (uint64_t)kSmallBox)
-        for (uint64_t p = 0; p < c.npix; p++) cover_texel<CONSERVATIVE>(c, p, t, W, cover);
+        for (uint64_t p = 0; p < c.npix; p++) cover_texel<CONSERVATIVE, PEEL>(c, p, t, W, cover, prev);
     // the big ones, one after the other, by the whole wavefront
     uint64_t big = __ballot(live && c.npix > (uint64_t)kSmallBox);
     while (big) {
@@ -140,7 +148,7 @@ void k_cover(const float* __restrict__ uvs, const uint32_t* __restrict__ indices
         g.b0 = bcast64(c.b0, src); g.b1 = bcast64(c.b1, src); g.b2 = bcast64(c.b2, src);
         g.bw = (uint64_t)bcast64((int64_t)c.bw, src); g.npix = (uint64_t)bcast64((int64_t)c.npix, src);
         const uint32_t gt = __shfl(t, src);
-        for (uint64_t p = lane; p < g.npix; p += 64) cover_texel<CONSERVATIVE>(g, p, gt, W, cover);
+        for (uint64_t p = lane; p < g.npix; p += 64) cover_texel<CONSERVATIVE, PEEL>(g, p, gt, W, cover, prev);
     }
 }
 
@@ -233,13 +241,13 @@ __device__ __noinline__ void nearest_point(const int64_t* X, const int64_t* Y, i
 
 struct RasterVertex { f3 wpos, wnrm; float u, v; };
 
-template <bool CONSERVATIVE>
+template <bool CONSERVATIVE, bool PEEL>
 __global__ __launch_bounds__(kBlock)
 void k_emit_surfels(uint32_t* __restrict__ cover, uint64_t cells, const uint32_t* __restrict__ block_offsets,
                     const float* __restrict__ positions, const float* __restrict__ normals,
                     const float* __restrict__ uvs, const uint32_t* __restrict__ indices,
                     MeshXform xf, int32_t W, int32_t H, int fp16_mode,
-                    AobSurfel* __restrict__ surfels, uint32_t* __restrict__ section_index)
+                    AobSurfel* __restrict__ surfels, uint32_t* __restrict__ section_index, uint32_t* __restrict__ prev)
 {
     uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
     uint32_t cv[kScanItems];
@@ -252,7 +260,7 @@ void k_emit_surfels(uint32_t* __restrict__ cover, uint64_t cells, const uint32_t
 #pragma unroll 1
     for (int k = 0; k < kScanItems; k++) {
         if (!cv[k]) continue;
-        const uint32_t t = (cv[k] & ~kCentreBit) - 1;
+        const uint32_t t = PEEL ? 0xffffffffu - cv[k] : (cv[k] & ~kCentreBit) - 1;
         const uint64_t cell = base + k;
         const int32_t py = (int32_t)(cell / (uint64_t)W), px = (int32_t)(cell % (uint64_t)W);
         RasterVertex rv[3];
@@ -293,6 +301,7 @@ void k_emit_surfels(uint32_t* __restrict__ cover, uint64_t cells, const uint32_t
         surfels[local] = s;
         section_index[local] = local;
         cover[cell] = local + 1;            // from here on: row-major rank + 1 (read by the tile-order pass)
+        if (PEEL) prev[cell] = t + 1;       // the next layer starts after this triangle
         local++;
     }
 }
@@ -433,18 +442,28 @@ int rasterize_material(AobBake* b, int32_t material, int32_t row_begin, int32_t 
     m.section_offsets.push_back(0);
     AOB_HIP(hipMemsetAsync(m.results, 0, sizeof(AobResult) * cells, s));
     const uint32_t nblocks = m.scan_blocks;
+    const bool conservative = b->opt.raster_mode == AOB_RASTER_CONSERVATIVE;
+    const bool peel = b->opt.raster_layers == AOB_LAYERS_ALL;
+    if (peel && !m.prev_layer) AOB_HIP(hipMalloc((void**)&m.prev_layer, sizeof(uint32_t) * cells));
     for (size_t mi = 0; mi < b->meshes.size(); mi++) {
         const DeviceMesh& mesh = b->meshes[mi];
         if (mesh.material != material) continue;                       // BakeEngine.cpp:523
+        if (peel) AOB_HIP(hipMemsetAsync(m.prev_layer, 0, sizeof(uint32_t) * cells, s));
+        // one pass per section — or, AOB_LAYERS_ALL, one per layer of the section's stencil peel (BakeEngine.cpp:531-532),
+        // each layer a section of its own from here on
+        for (int layer = 0; layer < (peel ? 255 : 1); layer++) {
         AOB_HIP(hipMemsetAsync(m.cover, 0, sizeof(uint32_t) * cells, s));
         if (mesh.triangle_count) {
             uint32_t grid = (mesh.triangle_count + kBlock - 1) / kBlock;
-            if (b->opt.raster_mode == AOB_RASTER_CONSERVATIVE)
-                hipLaunchKernelGGL(k_cover<true>, dim3(grid), dim3(kBlock), 0, s, mesh.uvs, mesh.indices, mesh.triangle_count,
-                                   m.width, m.height, row_begin, row_end, m.cover);
+            if (peel)
+                hipLaunchKernelGGL((k_cover<false, true>), dim3(grid), dim3(kBlock), 0, s, mesh.uvs, mesh.indices, mesh.triangle_count,
+                                   m.width, m.height, row_begin, row_end, m.cover, m.prev_layer);
+            else if (conservative)
+                hipLaunchKernelGGL((k_cover<true, false>), dim3(grid), dim3(kBlock), 0, s, mesh.uvs, mesh.indices, mesh.triangle_count,
+                                   m.width, m.height, row_begin, row_end, m.cover, (const uint32_t*)nullptr);
             else
-                hipLaunchKernelGGL(k_cover<false>, dim3(grid), dim3(kBlock), 0, s, mesh.uvs, mesh.indices, mesh.triangle_count,
-                                   m.width, m.height, row_begin, row_end, m.cover);
+                hipLaunchKernelGGL((k_cover<false, false>), dim3(grid), dim3(kBlock), 0, s, mesh.uvs, mesh.indices, mesh.triangle_count,
+                                   m.width, m.height, row_begin, row_end, m.cover, (const uint32_t*)nullptr);
         }
         hipLaunchKernelGGL(k_scan_count, dim3(nblocks), dim3(kBlock), 0, s, m.cover, cells, m.block_sums);
         hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(kBlock), 0, s, m.block_sums, nblocks);
@@ -452,18 +471,23 @@ int rasterize_material(AobBake* b, int32_t material, int32_t row_begin, int32_t 
         AOB_HIP(hipMemcpyAsync(b->pinned, m.block_sums + nblocks, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         AOB_HIP(hipStreamSynchronize(s));
         const uint64_t count = b->pinned[0];
+        if (peel && layer > 0 && count == 0) break;                    // the peel is through (the first layer stands for the section even when empty)
         AOB_TRY(ensure_surfel_capacity(b, m, m.surfel_count + count));
         if (count) {
             MeshXform xf;
             for (int k = 0; k < 16; k++) xf.m[k] = mesh.model[k];
-            if (b->opt.raster_mode == AOB_RASTER_CONSERVATIVE)
-                hipLaunchKernelGGL(k_emit_surfels<true>, dim3(nblocks), dim3(kBlock), 0, s, m.cover, cells, m.block_sums,
+            if (peel)
+                hipLaunchKernelGGL((k_emit_surfels<false, true>), dim3(nblocks), dim3(kBlock), 0, s, m.cover, cells, m.block_sums,
                                    mesh.positions, mesh.normals, mesh.uvs, mesh.indices, xf, m.width, m.height,
-                                   b->opt.normal_fp16, m.surfels + m.surfel_count, m.section_index + m.surfel_count);
+                                   b->opt.normal_fp16, m.surfels + m.surfel_count, m.section_index + m.surfel_count, m.prev_layer);
+            else if (conservative)
+                hipLaunchKernelGGL((k_emit_surfels<true, false>), dim3(nblocks), dim3(kBlock), 0, s, m.cover, cells, m.block_sums,
+                                   mesh.positions, mesh.normals, mesh.uvs, mesh.indices, xf, m.width, m.height,
+                                   b->opt.normal_fp16, m.surfels + m.surfel_count, m.section_index + m.surfel_count, (uint32_t*)nullptr);
             else
-                hipLaunchKernelGGL(k_emit_surfels<false>, dim3(nblocks), dim3(kBlock), 0, s, m.cover, cells, m.block_sums,
+                hipLaunchKernelGGL((k_emit_surfels<false, false>), dim3(nblocks), dim3(kBlock), 0, s, m.cover, cells, m.block_sums,
                                    mesh.positions, mesh.normals, mesh.uvs, mesh.indices, xf, m.width, m.height,
-                                   b->opt.normal_fp16, m.surfels + m.surfel_count, m.section_index + m.surfel_count);
+                                   b->opt.normal_fp16, m.surfels + m.surfel_count, m.section_index + m.surfel_count, (uint32_t*)nullptr);
             // trace order: 8x8 tiles (perm), then the per-surfel trace records in that order
             const uint32_t tiles_x = (uint32_t)(m.width + 7) / 8, tiles_y = (uint32_t)(m.height + 7) / 8;
             const uint64_t total_e = (uint64_t)tiles_x * tiles_y * 64u;
@@ -485,6 +509,7 @@ int rasterize_material(AobBake* b, int32_t material, int32_t row_begin, int32_t 
         m.surfel_count += count;
         m.section_offsets.push_back(m.surfel_count);
         m.section_mesh.push_back((uint32_t)mi);
+        }   // layers
     }
     AOB_HIP(hipGetLastError());
     m.rasterized = true;

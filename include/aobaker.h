@@ -64,6 +64,15 @@ enum { AOB_BLEED_REFERENCE = 0, AOB_BLEED_NEAREST = 1 };
  * covers the centre always wins over one that only touches the square, the last drawn winning within each class. */
 enum { AOB_RASTER_REFERENCE = 0, AOB_RASTER_CONSERVATIVE = 1 };
 
+/* Which fragments of a texel become surfels where UV triangles of ONE section overlap.  LAST is the reference: its
+ * stencil peel draws one layer per pass and keeps a texel only in the pass that reaches its last fragment
+ * (BakeEngine.cpp:130-140,531-588), so the earlier fragments never cast a ray.  ALL keeps every
+ * layer of the peel: layer j holds, per texel, the j-th triangle (in index order) that covers its centre, each layer
+ * is traced like a section of its own (its surfels numbered from 0, row-major) and all of them sum into the texel's
+ * cell — overlapping charts average instead of the last one winning.  At most 255 layers, the stencil's range.
+ * Centre sampling only: not combinable with AOB_RASTER_CONSERVATIVE. */
+enum { AOB_LAYERS_LAST = 0, AOB_LAYERS_ALL = 1 };
+
 typedef struct AobOptions {
     int32_t  sample_count;        /* rays per surfel (reference sampleCount)              */
     int32_t  sampler;             /* AOB_SAMPLER_*                                        */
@@ -94,7 +103,7 @@ typedef struct AobOptions {
                                      instead of x, y, z in turn (0: build_hlbvh.cl's order).  Flat scenes gain: 8 % fewer
                                      node visits per ray on the 1 M-triangle terrain                                  */
     int32_t  raster_mode;         /* AOB_RASTER_*; default REFERENCE                                  */
-    int32_t  reserved[1];
+    int32_t  raster_layers;       /* AOB_LAYERS_*; default LAST                                       */
 } AobOptions;
 
 /* ---- scene description ----------------------------------------------------

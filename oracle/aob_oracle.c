@@ -620,12 +620,19 @@ uint64_t orc_rasterize_ex(const AobSceneDesc* scene, int32_t material, const Aob
     const int32_t W = scene->materials[material].width, H = scene->materials[material].height;
     if (W <= 0 || H <= 0) return 0;
     uint32_t* cover = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)W * H);
+    /* AOB_LAYERS_ALL: every layer of the stencil peel (BakeEngine.cpp:531-532) is kept, each as a section of its own;
+     * prev holds, per texel, the triangle index + 1 of its fragment in the layer before */
+    const int peel = opt->raster_layers == AOB_LAYERS_ALL && opt->raster_mode != AOB_RASTER_CONSERVATIVE;
+    uint32_t* prev = peel ? (uint32_t*)calloc((size_t)W * H, sizeof(uint32_t)) : NULL;
     uint64_t total = 0;
     for (uint32_t mi = 0; mi < scene->mesh_count; mi++) {
         const AobMeshDesc* m = &scene->meshes[mi];
         if (m->material != material) continue;                       /* BakeEngine.cpp:523 */
+        if (peel) memset(prev, 0, sizeof(uint32_t) * (size_t)W * H);
+        for (int layer = 0; layer < (peel ? 255 : 1); layer++) {
         memset(cover, 0, sizeof(uint32_t) * (size_t)W * H);
         uint32_t ntri = m->index_count / 3;
+        uint64_t layer_count = 0;
         /* pass 1: the stencil layer peel keeps, per texel, the LAST fragment drawn
          * (BakeEngine.cpp:130-140,531-588): highest triangle index covering the centre */
         for (uint32_t t = 0; t < ntri; t++) {
@@ -671,10 +678,16 @@ uint64_t orc_rasterize_ex(const AobSceneDesc* scene, int32_t material, const Aob
                         if (centre) key |= 0x80000000u;
                     } else if (!centre) continue;
                     uint32_t* c = &cover[(size_t)py * W + px];
+                    if (peel) {
+                        /* the first triangle after the previous layer's */
+                        if (key > prev[(size_t)py * W + px] && (*c == 0 || key < *c)) { if (*c == 0) layer_count++; *c = key; }
+                        continue;
+                    }
                     if (key > *c) *c = key;
                 }
             }
         }
+        if (peel && layer > 0 && layer_count == 0) break;             /* the peel is through */
         /* pass 2: attributes of the winning fragment, row-major extraction */
         uint32_t local = 0;
         for (int32_t py = 0; py < H; py++) {
@@ -682,6 +695,7 @@ uint64_t orc_rasterize_ex(const AobSceneDesc* scene, int32_t material, const Aob
                 uint32_t c = cover[(size_t)py * W + px];
                 if (!c) continue;
                 uint32_t t = (c & 0x7fffffffu) - 1;
+                if (peel) { t = c - 1; prev[(size_t)py * W + px] = c; }
                 const int clamp = opt->raster_mode == AOB_RASTER_CONSERVATIVE && !(c & 0x80000000u);
                 RasterVertex rv[3];
                 int64_t X[3], Y[3];
@@ -742,8 +756,9 @@ uint64_t orc_rasterize_ex(const AobSceneDesc* scene, int32_t material, const Aob
                 total++; local++;
             }
         }
+        }   /* layers */
     }
-    free(cover);
+    free(cover); free(prev);
     return total;
 }
 

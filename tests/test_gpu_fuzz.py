@@ -1,7 +1,7 @@
 """Randomised GPU-vs-oracle parity: random scenes (triangle soups with random UVs, bumpy grids, degenerate and duplicate
 triangles, several objects / sections / materials with random transforms, visibility flags and ranges) baked with random
 options (every sampler, scoring, accumulation, structure, builder, Morton order, bleed mode, fp16 mode, odd sample counts,
-short rays, zero bias, both raster modes) must give the oracle's textures byte for byte.  Seeds are fixed: the cases are the same every run."""
+short rays, zero bias, both raster modes, all layers of overlapping charts) must give the oracle's textures byte for byte.  Seeds are fixed: the cases are the same every run."""
 import numpy as np
 import pytest
 
@@ -56,6 +56,9 @@ def random_options(rng):
     o.bvh_width, o.bvh_quantised = [(4, 1), (4, 1), (2, 1), (2, 0)][int(rng.integers(0, 4))]
     o.bvh_builder = int(rng.integers(0, 2)); o.morton_adaptive = int(rng.integers(0, 2))
     o.raster_mode = int(rng.integers(0, 2))       # drawn last: the cases keep the options they had before it existed
+    o.raster_layers = int(rng.integers(0, 2))
+    if o.raster_layers == capi.LAYERS_ALL:
+        o.raster_mode = capi.RASTER_REFERENCE     # the layers are centre-sampled
     return o
 
 

@@ -124,12 +124,12 @@ def test_surfels_bit_exact(engine, orc, name, fp16):
     assert bits(got).tobytes() == bits(ref).tobytes()
 
 
-def _soup_scene(seed=11, n=300, atlas=96):
+def _soup_scene(seed=11, n=300, atlas=96, spread=0.02, slivers=True):
     """Random small triangles with random UVs: slivers, overlaps, charts thinner than a texel."""
     from aobaker_amd.scene import BakeObject, MaterialObject, RenderMesh, Scene, Section, make_vertices
     rng = np.random.default_rng(seed)
     c = rng.uniform(0, 1, (n, 1, 3)); v = (c + rng.normal(scale=0.05, size=(n, 3, 3))).astype(np.float32).reshape(-1, 3)
-    uvc = rng.uniform(0, 1, (n, 1, 2)); uv = (uvc + rng.normal(scale=0.02, size=(n, 3, 2)) * rng.uniform(0.02, 1.0, (n, 1, 2))).astype(np.float32).reshape(-1, 2)
+    uvc = rng.uniform(0, 1, (n, 1, 2)); uv = (uvc + rng.normal(scale=spread, size=(n, 3, 2)) * (rng.uniform(0.02, 1.0, (n, 1, 2)) if slivers else 1.0)).astype(np.float32).reshape(-1, 2)
     nrm = rng.normal(size=(3 * n, 3)).astype(np.float32); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
     sc = Scene(); m = sc.AddMaterial(MaterialObject("A", atlas, atlas))
     o = sc.AddObject(BakeObject("O")); o.AddSection(Section("s", RenderMesh(make_vertices(v, nrm, uv), np.arange(3 * n, dtype=np.uint32)), m))
@@ -153,6 +153,42 @@ def test_conservative_surfels_bit_exact(engine, orc, name, fp16):
     assert bits(got).tobytes() == bits(ref).tobytes()
     if name == "soup":
         assert len(ref) > 1.2 * len(plain)                 # the slivers matter here
+
+
+@pytest.mark.parametrize("name", ["two_section", "sphere", "soup", "soup_large"])
+def test_all_layers_surfels_bit_exact(engine, orc, name):
+    """AOB_LAYERS_ALL: every layer of the stencil peel as a section of its own, surfel for surfel."""
+    make = {"soup": lambda: _soup_scene(seed=21, n=300, atlas=64, spread=0.08, slivers=False),
+            "soup_large": lambda: _soup_scene(seed=4, n=30000, atlas=256, spread=0.03, slivers=False)}.get(name) or SCENES[name]
+    flat = FlatScene(make())
+    opt = make_options(orc, raster_layers=capi.LAYERS_ALL)
+    ref, ref_idx = orc.rasterize(flat.desc, 0, opt)
+    plain, _ = orc.rasterize(flat.desc, 0, make_options(orc))
+    with Baker(flat, opt) as b:
+        b.rasterize(0)
+        got = b.surfels(0)
+        with pytest.raises(capi.AobError):
+            Baker(flat, make_options(orc, raster_layers=capi.LAYERS_ALL, raster_mode=capi.RASTER_CONSERVATIVE))
+    assert len(got) == len(ref) >= len(plain) > 0
+    assert bits(got).tobytes() == bits(ref).tobytes()
+    if name.startswith("soup"):
+        assert len(ref) > 1.5 * len(plain)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_all_layers_bake_equals_oracle(engine, orc, mode):
+    flat = FlatScene(_soup_scene(seed=9, n=300, atlas=64, spread=0.08, slivers=False))
+    opt = make_options(orc, sample_count=8, raster_layers=capi.LAYERS_ALL, **MODES[mode])
+    m = flat.material_array[0]
+    nodes, _ = orc.bvh_build(orc.scene_triangles(flat.desc))
+    surfels, sidx = orc.rasterize(flat.desc, 0, opt)
+    want, _ = orc.trace(nodes, surfels, sidx, opt, m.width, m.height, orc.compat_table(opt))
+    with Baker(flat, opt) as b:
+        b.build_bvh(); b.rasterize(0); b.trace(0)
+        got = b.results(0).copy()
+    assert np.array_equal(got["total_bits"], want["total_bits"]) and np.array_equal(got["weight_bits"], want["weight_bits"])
+    if MODES[mode]["sampler"] == capi.SAMPLER_COSINE and MODES[mode]["accumulate"] == capi.ACCUMULATE_FLOAT:
+        assert got["weight_bits"].view(np.float32).max() >= 3 * 8          # some texel has three layers or more
 
 
 @pytest.mark.parametrize("mode", [0, 2])

@@ -270,6 +270,55 @@ def test_conservative_raster_centre_coverage_wins(orc):
     assert len(got) == 6 and np.allclose(got["position"][:, 1], 5.0, atol=1e-5)
 
 
+def test_all_layers_keeps_every_fragment_of_the_peel(orc):
+    """AOB_LAYERS_ALL: layer j holds each texel's j-th covering triangle in index order; every layer is a section of its own
+    (surfels numbered from 0, row-major); LAST is the reference's last fragment."""
+    # three charts over each other in ONE section: [2,6]^2 at height 0, [2,6]^2 at height 5, [4,8]x[2,6] at height 9
+    flat = _quads_scene([(2, 2, 6, 6, 0.0), (2, 2, 6, 6, 5.0), (4, 2, 8, 6, 9.0)])
+    last, _ = orc.rasterize(flat.desc, 0, opts(orc, normal_fp16=capi.FP16_OFF))
+    assert len(last) == 24 and set(np.unique(last["position"][:, 1]).tolist()) == {5.0, 9.0}
+    got, sidx = orc.rasterize(flat.desc, 0, opts(orc, normal_fp16=capi.FP16_OFF, raster_layers=capi.LAYERS_ALL))
+    # layer 0: 16 texels at height 0 and the 8 texels only the third chart covers; layer 1: 16 at height 5; layer 2: the 8 shared by all
+    assert len(got) == 24 + 16 + 8
+    assert sidx.tolist() == list(range(24)) + list(range(16)) + list(range(8))
+    l0, l1, l2 = got[:24], got[24:40], got[40:]
+    h = lambda a: a["position"][:, 1]
+    assert ((h(l0) == 0.0) == (l0["texel_x"] < 6)).all() and ((h(l0) == 9.0) == (l0["texel_x"] >= 6)).all()
+    assert (h(l1) == 5.0).all() and (h(l2) == 9.0).all() and (l2["texel_x"] >= 4).all() and (l2["texel_x"] < 6).all()
+    for layer in (l0, l1, l2):
+        cells = layer["texel_y"].astype(np.int64) * 8 + layer["texel_x"]
+        assert np.all(np.diff(cells) > 0)
+    # the last layer of every texel is the reference's surfel
+    by_cell = {}
+    for s in got:
+        by_cell[(int(s["texel_x"]), int(s["texel_y"]))] = s.tobytes()
+    assert all(by_cell[(int(s["texel_x"]), int(s["texel_y"]))] == s.tobytes() for s in last)
+    # without overlaps the two modes agree
+    flat = _quads_scene([(2, 2, 6, 6, 0.0)])
+    a, _ = orc.rasterize(flat.desc, 0, opts(orc)); b, _ = orc.rasterize(flat.desc, 0, opts(orc, raster_layers=capi.LAYERS_ALL))
+    assert a.tobytes() == b.tobytes()
+
+
+def test_all_layers_average_in_the_bake(orc):
+    """Two coincident charts, the lower one under a lid: LAST bakes only the upper (open) one, ALL averages the two."""
+    from aobaker_amd.scene import BakeObject, MaterialObject, RenderMesh, Scene, Section, make_vertices
+    def scene():
+        # a floor chart at y = 0 under a big lid at y = 0.5, and the same chart again at y = 1 above the lid, drawn last
+        pos = np.float32([[0, 0, 0], [1, 0, 0], [1, 0, 1], [0, 0, 1], [0, 1, 0], [1, 1, 0], [1, 1, 1], [0, 1, 1],
+                          [-50, .5, -50], [50, .5, -50], [50, .5, 50], [-50, .5, 50]])
+        uv = np.float32([[0, 0], [1, 0], [1, 1], [0, 1]] * 2 + [[2, 2]] * 4)                  # the lid has no texels
+        idx = np.uint32([0, 1, 2, 0, 2, 3, 4, 5, 6, 4, 6, 7, 8, 9, 10, 8, 10, 11])
+        sc = Scene(); m = sc.AddMaterial(MaterialObject("A", 8, 8, 1, 4))
+        o = sc.AddObject(BakeObject("O")); o.AddSection(Section("s", RenderMesh(make_vertices(pos, np.tile(np.float32([0, 1, 0]), (12, 1)), uv), idx), m))
+        return sc
+    kw = dict(sampler=capi.SAMPLER_COSINE, accumulate=capi.ACCUMULATE_FLOAT, sample_count=16, bleed_distance=0)
+    a, b = scene(), scene()
+    orc.bake(FlatScene(a).desc, opts(orc, **kw))
+    orc.bake(FlatScene(b).desc, opts(orc, raster_layers=capi.LAYERS_ALL, **kw))
+    assert np.array_equal(a.GetMaterial(0).GetAOTexture().ao(), np.ones((8, 8), np.float32))     # only the open upper chart
+    assert np.array_equal(b.GetMaterial(0).GetAOTexture().ao(), np.full((8, 8), 0.5, np.float32))  # (0 + 1) / 2
+
+
 def test_conservative_coverage_equals_brute_force(orc):
     """Which texels get a surfel, against an exact restatement in Python integers: open texel square vs triangle by the
     separating-axis test, centre coverage by the top-left rule."""

@@ -92,6 +92,7 @@ int main(int argc, char** argv)
 		else if (a == "--bleed") opt.bleed_distance = std::atoi(next());
 		else if (a == "--bleed-mode") opt.bleed_mode = std::atoi(next());        // 0 reference, 1 nearest (AOB_BLEED_*)
 		else if (a == "--raster-mode") opt.raster_mode = std::atoi(next());      // 0 reference, 1 conservative (AOB_RASTER_*)
+		else if (a == "--raster-layers") opt.raster_layers = std::atoi(next());  // 0 last fragment, 1 all (AOB_LAYERS_*)
 		else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
 	}
 	if (!scene_path && !obj_path) { std::fprintf(stderr, "usage: aobake_cli (--scene file.aobs | --obj file.obj [--atlas W]) --out prefix [--png] [--exr] [--spp N] ...\n"); return 2; }
