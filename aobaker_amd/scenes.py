@@ -234,3 +234,23 @@ def instanced_scene(instances=100, rock_n=224, atlas=8192, seed=5, **kw):
                                     scale=tuple(rng.uniform(0.5, 1.5, 3))))
         o.AddSection(Section("Geometry", RenderMesh(make_vertices(p, n, chart(i + 1, uv)), idx), mat))
     return sc
+
+
+def soup_scene(seed=11, n=300, atlas=96, spread=0.02, slivers=True, **kw):
+    """A triangle soup in ONE section: `n` random small triangles with random UV charts around random centres —
+    overlapping charts (AOB_LAYERS_ALL), and with `slivers` charts thinner than a texel (AOB_RASTER_CONSERVATIVE).
+    Seeded; the reference has nothing like it — it exercises what real atlases have and clean synthetic ones lack."""
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(0, 1, (n, 1, 3))
+    v = (c + rng.normal(scale=0.05, size=(n, 3, 3))).astype(np.float32).reshape(-1, 3)
+    uvc = rng.uniform(0, 1, (n, 1, 2))
+    uv = (uvc + rng.normal(scale=spread, size=(n, 3, 2)) * (rng.uniform(0.02, 1.0, (n, 1, 2)) if slivers else 1.0)).astype(np.float32).reshape(-1, 2)
+    nrm = rng.normal(size=(3 * n, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    if isinstance(atlas, int):
+        atlas = (atlas, atlas)
+    sc = Scene()
+    m = sc.AddMaterial(MaterialObject("A", atlas[0], atlas[1], kw.get("channels", 1), kw.get("bpc", 1)))
+    o = sc.AddObject(BakeObject("Soup"))
+    o.AddSection(Section("s", RenderMesh(make_vertices(v, nrm, uv), np.arange(3 * n, dtype=np.uint32)), m))
+    return sc

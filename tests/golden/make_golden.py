@@ -9,7 +9,11 @@ and the same for a small 7 938-triangle terrain (128^2 atlas) whose AO is not tr
 They pin the oracle against regressions, and the GPU path against the oracle at a size the GPU box
 can check without running the oracle.
 
-    python tests/golden/make_golden.py      # rewrites tests/golden/{cube_cfg1,terrain_small}.npz
+    python tests/golden/make_golden.py      # rewrites tests/golden/{cube_cfg1,terrain_small,features_v2}.npz
+
+features_v2: a 250-triangle soup (slivers, overlapping charts) baked with the options the reference lacks —
+conservative rasterisation + nearest-texel dilation, all layers of the stencil peel, a section hidden from itself
+under a material range.
 """
 import hashlib
 import os
@@ -64,5 +68,48 @@ def main():
             print(name, k, v.shape if v.ndim else v)
 
 
+FEATURES = {
+    # options the reference does not have, on a triangle soup with slivers and overlapping charts,
+    # with the library's default traversal structure (PLOC, quantised 4-ary nodes, leaf pairs)
+    "conservative": (4, dict(sampler=capi.SAMPLER_COSINE, accumulate=capi.ACCUMULATE_FLOAT, normal_fp16=capi.FP16_OFF,
+                             raster_mode=capi.RASTER_CONSERVATIVE, bleed_mode=capi.BLEED_NEAREST, bleed_distance=2)),
+    "layers": (1, dict(raster_layers=capi.LAYERS_ALL, use_any_hit=0)),
+    "masks": (4, dict(sampler=capi.SAMPLER_COSINE, accumulate=capi.ACCUMULATE_FLOAT, material_ranges=1)),
+}
+
+
+def features_scene(bpc):
+    sc = scenes.soup_scene(seed=7, n=250, atlas=64, spread=0.06, bpc=bpc)
+    sc.GetMaterial(0).SetAOMaxRange(0.35)
+    return sc
+
+
+def features_options(name):
+    o = orc.default_options()
+    o.sample_count, o.seed = 16, 1
+    for k, v in FEATURES[name][1].items():
+        setattr(o, k, v)
+    return o
+
+
+def main_features():
+    out = {}
+    for name, (bpc, _) in FEATURES.items():
+        sc = features_scene(bpc)
+        if name == "masks":
+            sc.GetObject(0).GetSection(0).SetVisibleToSelf(False)
+        flat = FlatScene(sc)
+        o = features_options(name)
+        surfels, _ = orc.rasterize(flat.desc, 0, o)
+        st = orc.bake(flat.desc, o, threads=os.cpu_count() or 1)
+        out[f"{name}_image"] = sc.GetMaterial(0).GetAOTexture().GetData().copy()
+        out[f"{name}_surfels_sha256"] = np.array(digest(surfels))
+        out[f"{name}_counts"] = np.array([len(surfels), st.rays, st.hits], dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "features_v2.npz"), **out)
+    for k, v in out.items():
+        print("features_v2", k, v.shape if v.ndim else v)
+
+
 if __name__ == "__main__":
     main()
+    main_features()

@@ -104,3 +104,68 @@ def test_gpu_reproduces_golden(engine, mode, bpc, case, structure):
     if structure == "reference":
         assert st.bvh_depth == want[1]
     assert np.array_equal(sc.GetMaterial(0).GetAOTexture().GetData(), GOLD[f"{mode}_image"])
+
+
+# ---- features_v2.npz: the options the reference lacks, on a triangle soup (made by the same script) -------------------
+FEATURES_GOLD = np.load(os.path.join(GOLDEN, "features_v2.npz"))
+FEATURES = {
+    "conservative": (4, dict(sampler=capi.SAMPLER_COSINE, accumulate=capi.ACCUMULATE_FLOAT, normal_fp16=capi.FP16_OFF,
+                             raster_mode=capi.RASTER_CONSERVATIVE, bleed_mode=capi.BLEED_NEAREST, bleed_distance=2)),
+    "layers": (1, dict(raster_layers=capi.LAYERS_ALL, use_any_hit=0)),
+    "masks": (4, dict(sampler=capi.SAMPLER_COSINE, accumulate=capi.ACCUMULATE_FLOAT, material_ranges=1)),
+}
+
+
+def features_scene(name):
+    sc = scenes.soup_scene(seed=7, n=250, atlas=64, spread=0.06, bpc=FEATURES[name][0])
+    sc.GetMaterial(0).SetAOMaxRange(0.35)
+    if name == "masks":
+        sc.GetObject(0).GetSection(0).SetVisibleToSelf(False)
+    return sc
+
+
+def features_options(o, name):
+    o.sample_count, o.seed = 16, 1
+    for k, v in FEATURES[name][1].items():
+        setattr(o, k, v)
+    return o
+
+
+@pytest.mark.parametrize("name", sorted(FEATURES))
+def test_oracle_reproduces_feature_golden(orc, name):
+    sc = features_scene(name)
+    flat = FlatScene(sc)
+    o = features_options(orc.default_options(), name)
+    surfels, _ = orc.rasterize(flat.desc, 0, o)
+    assert digest(surfels) == str(FEATURES_GOLD[f"{name}_surfels_sha256"])
+    st = orc.bake(flat.desc, o, threads=os.cpu_count() or 1)
+    assert [len(surfels), st.rays, st.hits] == FEATURES_GOLD[f"{name}_counts"].tolist()
+    assert np.array_equal(sc.GetMaterial(0).GetAOTexture().GetData(), FEATURES_GOLD[f"{name}_image"])
+
+
+def test_feature_goldens_are_plausible():
+    """Implementation-independent relations between the vectors: the same soup gives more surfels when every overlapped
+    texel / every layer counts; a section hidden from itself under a short range sees (almost) only sky."""
+    n_cons, n_layers, n_masks = (int(FEATURES_GOLD[f"{k}_counts"][0]) for k in ("conservative", "layers", "masks"))
+    assert n_cons > 1.3 * n_masks and n_layers > 1.05 * n_masks and n_masks > 500
+    masks = FEATURES_GOLD["masks_image"].view(np.float32)
+    assert FEATURES_GOLD["masks_counts"][2] == 0 and set(np.unique(masks).tolist()) <= {0.0, 1.0}     # no hits: covered texels white
+    cons = FEATURES_GOLD["conservative_image"].view(np.float32)
+    assert (cons > 0).sum() >= n_cons and 0.0 < cons[cons > 0].min() < 0.9                # real occlusion; dilation only adds texels
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(FEATURES))
+def test_gpu_reproduces_feature_golden(engine, name):
+    """The HIP path against the committed vectors — no oracle involved."""
+    from aobaker_amd import Baker
+    sc = features_scene(name)
+    flat = FlatScene(sc)
+    o = features_options(capi.default_options(), name)
+    with Baker(flat, o) as b:
+        b.rasterize(0)
+        assert digest(b.surfels(0)) == str(FEATURES_GOLD[f"{name}_surfels_sha256"])
+    engine.Options = o
+    engine.Bake(sc)
+    assert np.array_equal(sc.GetMaterial(0).GetAOTexture().GetData(), FEATURES_GOLD[f"{name}_image"])
+    assert engine.LastStats.ray_count == int(FEATURES_GOLD[f"{name}_counts"][1])

@@ -124,16 +124,7 @@ def test_surfels_bit_exact(engine, orc, name, fp16):
     assert bits(got).tobytes() == bits(ref).tobytes()
 
 
-def _soup_scene(seed=11, n=300, atlas=96, spread=0.02, slivers=True):
-    """Random small triangles with random UVs: slivers, overlaps, charts thinner than a texel."""
-    from aobaker_amd.scene import BakeObject, MaterialObject, RenderMesh, Scene, Section, make_vertices
-    rng = np.random.default_rng(seed)
-    c = rng.uniform(0, 1, (n, 1, 3)); v = (c + rng.normal(scale=0.05, size=(n, 3, 3))).astype(np.float32).reshape(-1, 3)
-    uvc = rng.uniform(0, 1, (n, 1, 2)); uv = (uvc + rng.normal(scale=spread, size=(n, 3, 2)) * (rng.uniform(0.02, 1.0, (n, 1, 2)) if slivers else 1.0)).astype(np.float32).reshape(-1, 2)
-    nrm = rng.normal(size=(3 * n, 3)).astype(np.float32); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
-    sc = Scene(); m = sc.AddMaterial(MaterialObject("A", atlas, atlas))
-    o = sc.AddObject(BakeObject("O")); o.AddSection(Section("s", RenderMesh(make_vertices(v, nrm, uv), np.arange(3 * n, dtype=np.uint32)), m))
-    return sc
+_soup_scene = scenes.soup_scene
 
 
 @pytest.mark.parametrize("fp16", [capi.FP16_OFF, capi.FP16_RNE])
