@@ -41,6 +41,7 @@ namespace aob {
 static constexpr int kWave = 64;                  // threads per workgroup: one wavefront
 static constexpr int kLdsStack = 8;               // traversal stack entries per lane kept in LDS; deeper entries go to HBM
 static constexpr int kLdsStackCount = 11;         // ... when the sums are 4-byte miss counters (unit weights, any hit): the same 5 KB
+static constexpr int kLdsStackTotals = 10;        // ... when only the 8-byte totals are summed (unit weights, falloff scoring)
                                                   // (4-ary walk, 1 M-triangle terrain: 96 % of the pushes land in slots 1..7)
 static constexpr uint32_t kInvalid = 0xffffffffu;
 typedef float v2f __attribute__((ext_vector_type(2)));    // a register pair for v_pk_fma_f32
@@ -107,7 +108,9 @@ void k_trace(TraceParams p)
     // per surfel: total, weight as 64-bit sums — or, with unit weights and any-hit scoring, one 32-bit count of the
     // unoccluded samples (the weight sum is the sample count); the 768 B saved hold three more stack entries per lane
     constexpr bool COUNT32 = SAMPLER == AOB_SAMPLER_COSINE && ANYHIT;
-    __shared__ unsigned long long acc[COUNT32 ? 1 : kWave][2];
+    // (unit weights with falloff scoring: only the totals — the weight sum is the sample count — and two more stack entries)
+    constexpr bool TOTAL_ONLY = SAMPLER == AOB_SAMPLER_COSINE && !ANYHIT;
+    __shared__ unsigned long long acc[COUNT32 ? 1 : kWave][TOTAL_ONLY ? 1 : 2];
     __shared__ uint32_t miss_count[COUNT32 ? kWave : 1];
     __shared__ uint4 queue[kWave * 2];                  // ray queue: {dir.xyz, slot}, {1/dir.xyz, weight}
 
@@ -164,7 +167,7 @@ void k_trace(TraceParams p)
     const uint32_t nsurf = (uint32_t)min((uint64_t)kWave, p.end - wave_first);
 
     if (COUNT32) miss_count[lane] = 0u;
-    else { acc[lane][0] = 0ull; acc[lane][1] = 0ull; }
+    else { acc[lane][0] = 0ull; if (!TOTAL_ONLY) acc[lane][1] = 0ull; }
     lds_stack[lane] = kInvalid;      // entry 0: the INVALID sentinel (intersect_bvh2_lds.cl:103): a pop is one read
 
 
@@ -463,7 +466,7 @@ void k_trace(TraceParams p)
     if (valid) {
         const float4 d = p.frames[4ull * (wave_first + lane) + 3];
         const long long sT = COUNT32 ? (long long)miss_count[lane] * kUnit : (long long)acc[lane][0];
-        const long long sW = UNITW ? (long long)(gen_end - gen_begin) * kUnit : (long long)acc[lane][1];
+        const long long sW = UNITW ? (long long)(gen_end - gen_begin) * kUnit : (long long)acc[lane][TOTAL_ONLY ? 0 : 1];
         AobResult* cell = p.results + __float_as_uint(d.x);
         if (p.parts > 1u) {
             if (ACCUM == AOB_ACCUMULATE_QUANTISED) {
@@ -489,7 +492,7 @@ void k_trace(TraceParams p)
   }   // next unit
 }
 
-constexpr int lds_stack_entries(int sampler, int anyhit) { return sampler == AOB_SAMPLER_COSINE && anyhit ? kLdsStackCount : kLdsStack; }
+constexpr int lds_stack_entries(int sampler, int anyhit) { return sampler != AOB_SAMPLER_COSINE ? kLdsStack : (anyhit ? kLdsStackCount : kLdsStackTotals); }
 
 template <int SAMPLER, int ANYHIT, int ACCUM, int MASKED>
 static void launch_stack(int quant, dim3 grid, hipStream_t s, const TraceParams& p)
@@ -548,7 +551,7 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
         // a lane's stack holds the sentinel plus at most one deferred sibling per tree level
         // (the 4-ary walk defers up to three children per 4-ary level)
         const uint32_t need = (o.bvh_quantised && o.bvh_width == 4) ? 3u * ((b->bvh_depth + 2) / 2) + 2u : b->bvh_depth + 2;
-        // 8 or 11 stack entries per lane live in LDS (2 KB + 1 KB of sums, or 2.75 KB + 256 B of counters, + 2 KB of queued
+        // 8, 10 or 11 stack entries per lane live in LDS (2 KB + 1 KB of sums, 2.5 KB + 512 B of totals, or 2.75 KB + 256 B of counters, + 2 KB of queued
         // rays per wavefront = 32 wavefronts per CU); deeper entries — rare — go to an HBM array.
         const uint32_t in_lds = (uint32_t)lds_stack_entries(o.sampler, o.use_any_hit);
         const uint32_t overflow = need > in_lds ? need - in_lds : 0u;
