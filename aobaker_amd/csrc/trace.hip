@@ -32,6 +32,7 @@
 // neighbouring lanes and served from L1/L2/Infinity Cache); the per-surfel frame (64 B) is
 // re-read from L1 once per generated sample and the result cell (8 B) written once per surfel.
 #include "aob_internal.h"
+#include <type_traits>
 #include "aob_math.h"
 
 #include <cstdlib>
@@ -39,9 +40,6 @@
 namespace aob {
 
 static constexpr int kWave = 64;                  // threads per workgroup: one wavefront
-static constexpr int kLdsStack = 8;               // traversal stack entries per lane kept in LDS; deeper entries go to HBM
-static constexpr int kLdsStackCount = 11;         // ... when the sums are 4-byte miss counters (unit weights, any hit): the same 5 KB
-static constexpr int kLdsStackTotals = 10;        // ... when only the 8-byte totals are summed (unit weights, falloff scoring)
                                                   // (4-ary walk, 1 M-triangle terrain: 96 % of the pushes land in slots 1..7)
 static constexpr uint32_t kInvalid = 0xffffffffu;
 typedef float v2f __attribute__((ext_vector_type(2)));    // a register pair for v_pk_fma_f32
@@ -110,7 +108,9 @@ void k_trace(TraceParams p)
     constexpr bool COUNT32 = SAMPLER == AOB_SAMPLER_COSINE && ANYHIT;
     // (unit weights with falloff scoring: only the totals — the weight sum is the sample count — and two more stack entries)
     constexpr bool TOTAL_ONLY = SAMPLER == AOB_SAMPLER_COSINE && !ANYHIT;
-    __shared__ unsigned long long acc[COUNT32 ? 1 : kWave][TOTAL_ONLY ? 1 : 2];
+    // (QUANTISED sums are the reference's int32 cells: 4-byte sums are the same arithmetic, and free two or three entries more)
+    typedef typename std::conditional<ACCUM == AOB_ACCUMULATE_QUANTISED, unsigned int, unsigned long long>::type acc_t;
+    __shared__ acc_t acc[COUNT32 ? 1 : kWave][TOTAL_ONLY ? 1 : 2];
     __shared__ uint32_t miss_count[COUNT32 ? kWave : 1];
     __shared__ uint4 queue[kWave * 2];                  // ray queue: {dir.xyz, slot}, {1/dir.xyz, weight}
 
@@ -167,7 +167,7 @@ void k_trace(TraceParams p)
     const uint32_t nsurf = (uint32_t)min((uint64_t)kWave, p.end - wave_first);
 
     if (COUNT32) miss_count[lane] = 0u;
-    else { acc[lane][0] = 0ull; if (!TOTAL_ONLY) acc[lane][1] = 0ull; }
+    else { acc[lane][0] = 0; if (!TOTAL_ONLY) acc[lane][1] = 0; }
     lds_stack[lane] = kInvalid;      // entry 0: the INVALID sentinel (intersect_bvh2_lds.cl:103): a pop is one read
 
 
@@ -223,14 +223,14 @@ void k_trace(TraceParams p)
                 if (!hit) atomicAdd(&miss_count[slot], 1u);
             } else {
                 const long long cW = ACCUM == AOB_ACCUMULATE_QUANTISED ? (long long)ftoi(w * 255.0f) : f2fix(w);
-                atomicAdd(&acc[slot][1], (unsigned long long)cW);
-                if (!hit) atomicAdd(&acc[slot][0], (unsigned long long)cW);
+                atomicAdd(&acc[slot][1], (acc_t)cW);
+                if (!hit) atomicAdd(&acc[slot][0], (acc_t)cW);
             }
         } else {
             const float r = (hit && closest_t < p.falloff) ? closest_t / p.falloff : 1.0f;
             const float rw = UNITW ? r * 1.0f : r * w;
-            atomicAdd(&acc[slot][0], (unsigned long long)(ACCUM == AOB_ACCUMULATE_QUANTISED ? (long long)ftoi(rw * 255.0f) : f2fix(rw)));
-            if (!UNITW) atomicAdd(&acc[slot][1], (unsigned long long)(ACCUM == AOB_ACCUMULATE_QUANTISED ? (long long)ftoi(w * 255.0f) : f2fix(w)));
+            atomicAdd(&acc[slot][0], (acc_t)(ACCUM == AOB_ACCUMULATE_QUANTISED ? (long long)ftoi(rw * 255.0f) : f2fix(rw)));
+            if (!UNITW) atomicAdd(&acc[slot][1], (acc_t)(ACCUM == AOB_ACCUMULATE_QUANTISED ? (long long)ftoi(w * 255.0f) : f2fix(w)));
         }
         active = false;
     };
@@ -492,12 +492,18 @@ void k_trace(TraceParams p)
   }   // next unit
 }
 
-constexpr int lds_stack_entries(int sampler, int anyhit) { return sampler != AOB_SAMPLER_COSINE ? kLdsStack : (anyhit ? kLdsStackCount : kLdsStackTotals); }
+// 5 KB per wavefront = 2 KB of queued rays + the per-surfel sums + 256 B per stack entry
+constexpr int lds_stack_entries(int sampler, int anyhit, int accum)
+{
+    const int sums = sampler == AOB_SAMPLER_COSINE ? (anyhit ? 1 : (accum == AOB_ACCUMULATE_QUANTISED ? 1 : 2))      // 4-byte counts / totals
+                                                   : (accum == AOB_ACCUMULATE_QUANTISED ? 2 : 4);                   // total + weight
+    return (3072 - 256 * sums) / 256;       // 11, 10 or 8
+}
 
 template <int SAMPLER, int ANYHIT, int ACCUM, int MASKED>
 static void launch_stack(int quant, dim3 grid, hipStream_t s, const TraceParams& p)
 {
-    constexpr int N = lds_stack_entries(SAMPLER, ANYHIT);
+    constexpr int N = lds_stack_entries(SAMPLER, ANYHIT, ACCUM);
     if (quant == 2) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 2, MASKED>), grid, dim3(kWave), 0, s, p);
     else if (quant == 1) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 1, MASKED>), grid, dim3(kWave), 0, s, p);
     else hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 0, MASKED>), grid, dim3(kWave), 0, s, p);
@@ -553,7 +559,7 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
         const uint32_t need = (o.bvh_quantised && o.bvh_width == 4) ? 3u * ((b->bvh_depth + 2) / 2) + 2u : b->bvh_depth + 2;
         // 8, 10 or 11 stack entries per lane live in LDS (2 KB + 1 KB of sums, 2.5 KB + 512 B of totals, or 2.75 KB + 256 B of counters, + 2 KB of queued
         // rays per wavefront = 32 wavefronts per CU); deeper entries — rare — go to an HBM array.
-        const uint32_t in_lds = (uint32_t)lds_stack_entries(o.sampler, o.use_any_hit);
+        const uint32_t in_lds = (uint32_t)lds_stack_entries(o.sampler, o.use_any_hit, o.accumulate);
         const uint32_t overflow = need > in_lds ? need - in_lds : 0u;
         TraceParams p;
         p.nodes = (const float4*)b->nodes;
