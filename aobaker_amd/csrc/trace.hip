@@ -32,15 +32,14 @@
 // neighbouring lanes and served from L1/L2/Infinity Cache); the per-surfel frame (64 B) is
 // re-read from L1 once per generated sample and the result cell (8 B) written once per surfel.
 #include "aob_internal.h"
-#include <type_traits>
 #include "aob_math.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace aob {
 
 static constexpr int kWave = 64;                  // threads per workgroup: one wavefront
-                                                  // (4-ary walk, 1 M-triangle terrain: 96 % of the pushes land in slots 1..7)
 static constexpr uint32_t kInvalid = 0xffffffffu;
 typedef float v2f __attribute__((ext_vector_type(2)));    // a register pair for v_pk_fma_f32
 
@@ -492,7 +491,8 @@ void k_trace(TraceParams p)
   }   // next unit
 }
 
-// 5 KB per wavefront = 2 KB of queued rays + the per-surfel sums + 256 B per stack entry
+// Stack entries per lane kept in LDS (deeper ones go to an HBM array): 5 KB per wavefront = 2 KB of queued rays + the
+// per-surfel sums + 256 B per entry.  (4-ary walk, 1 M-triangle terrain: 96 % of the pushes land in slots 1..7.)
 constexpr int lds_stack_entries(int sampler, int anyhit, int accum)
 {
     const int sums = sampler == AOB_SAMPLER_COSINE ? (anyhit ? 1 : (accum == AOB_ACCUMULATE_QUANTISED ? 1 : 2))      // 4-byte counts / totals
