@@ -337,6 +337,32 @@ def test_empty_and_degenerate_inputs(engine, orc):
     assert np.array_equal(m.GetAOTexture().GetData(), mc.GetAOTexture().GetData())
 
 
+@pytest.mark.parametrize("size", [(1, 1), (3, 200), (37, 53), (100, 100), (257, 9), (64, 7)])
+@pytest.mark.parametrize("mode", [0, 2, 3])
+def test_ragged_atlas_sizes(engine, orc, size, mode):
+    """Atlases that are no multiple of the 8x8 trace tile, of the 64-surfel wavefront or of the 2048-texel scan tile
+    (the reference's BakeTexture takes any size, BakeTexture.cpp:52-67): whole bake == oracle, strips stitch."""
+    from aobaker_amd import dist as aod
+    mk = lambda: scenes.terrain_scene(grid=24, atlas=size, bpc=1 if MODES[mode]["accumulate"] == capi.ACCUMULATE_QUANTISED else 4)
+    opt = make_options(orc, sample_count=5, **MODES[mode])
+    gpu, cpu = mk(), mk()
+    engine.Options = opt
+    engine.Bake(gpu)
+    orc.bake(FlatScene(cpu).desc, opt, threads=4)
+    assert np.array_equal(gpu.GetMaterial(0).GetAOTexture().GetData(), cpu.GetMaterial(0).GetAOTexture().GetData())
+    if mode == 2 and size[1] > 8:
+        flat = FlatScene(mk())
+        with Baker(flat, opt) as b:
+            b.build_bvh(); b.rasterize(0); b.trace(0)
+            full = b.results(0).copy()
+            stitched = np.zeros_like(full)
+            for r in range(3):
+                y0, y1 = aod.row_window(size[1], r, 3)
+                b.rasterize(0, (y0, y1)); b.trace(0, 0, b.surfel_count(0))
+                stitched[y0 * size[0]:y1 * size[0]] = b.results(0)[y0 * size[0]:y1 * size[0]]
+        assert np.array_equal(stitched["total_bits"], full["total_bits"]) and np.array_equal(stitched["weight_bits"], full["weight_bits"])
+
+
 def test_invalid_arguments_are_reported(engine, orc):
     flat = FlatScene(scenes.plane_scene(8))
     opt = make_options(orc, sample_count=0)
