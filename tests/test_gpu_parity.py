@@ -363,6 +363,28 @@ def test_ragged_atlas_sizes(engine, orc, size, mode):
         assert np.array_equal(stitched["total_bits"], full["total_bits"]) and np.array_equal(stitched["weight_bits"], full["weight_bits"])
 
 
+@pytest.mark.parametrize("chunk,spp", [(4096, 8), (1000, 7), (64, 64), (0xFFFFFF, 300)])
+def test_chunk_local_sample_indexing(engine, orc, chunk, spp):
+    """The REFERENCE_COMPAT sampler reads Hemisphere[k * S + i] with k the surfel's index WITHIN its chunk of
+    min(rayChunkSize / S, 65535) texels (BakeEngine.cpp:359-364,598-628): small chunks wrap many times over a section."""
+    mk = lambda: scenes.terrain_scene(grid=24, atlas=(96, 80))
+    opt = make_options(orc, sample_count=spp, ray_chunk_size=chunk, **MODES[0])
+    gpu, cpu = mk(), mk()
+    engine.Options = opt
+    engine.Bake(gpu)
+    orc.bake(FlatScene(cpu).desc, opt, threads=4)
+    assert np.array_equal(gpu.GetMaterial(0).GetAOTexture().GetData(), cpu.GetMaterial(0).GetAOTexture().GetData())
+    flat = FlatScene(mk())
+    nodes, _ = orc.bvh_build(orc.scene_triangles(flat.desc))
+    surfels, sidx = orc.rasterize(flat.desc, 0, opt)
+    want, _ = orc.trace(nodes, surfels, sidx, opt, 96, 80, orc.compat_table(opt))
+    with Baker(flat, opt) as b:
+        b.build_bvh(); b.rasterize(0); b.trace(0)
+        got = b.results(0)
+    assert np.array_equal(got["total_bits"], want["total_bits"]) and np.array_equal(got["weight_bits"], want["weight_bits"])
+    assert len(surfels) > 4 * max(1, min(chunk // spp, 65535)) or chunk == 0xFFFFFF        # the index really wraps
+
+
 def test_invalid_arguments_are_reported(engine, orc):
     flat = FlatScene(scenes.plane_scene(8))
     opt = make_options(orc, sample_count=0)
