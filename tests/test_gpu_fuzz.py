@@ -1,5 +1,5 @@
 """Randomised GPU-vs-oracle parity: random scenes (triangle soups with random UVs, bumpy grids, degenerate and duplicate
-triangles, several objects / sections / materials with random transforms, visibility flags and ranges) baked with random
+triangles, several objects / sections / materials of ragged atlas sizes with random transforms, visibility flags and ranges) baked with random
 options (every sampler, scoring, accumulation, structure, builder, Morton order, bleed mode, fp16 mode, odd sample counts,
 short rays, zero bias, both raster modes, all layers of overlapping charts) must give the oracle's textures byte for byte.  Seeds are fixed: the cases are the same every run."""
 import numpy as np
@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def random_scene(rng, bpc):
     sc = Scene()
     nmat = int(rng.integers(1, 3))
-    mats = [sc.AddMaterial(MaterialObject(f"m{i}", int(rng.integers(2, 13)) * 8, int(rng.integers(2, 13)) * 8, 1, bpc)) for i in range(nmat)]
+    mats = [sc.AddMaterial(MaterialObject(f"m{i}", int(rng.integers(1, 100)), int(rng.integers(1, 100)), 1, bpc)) for i in range(nmat)]
     for m in mats:
         m.SetAOMaxRange(float(rng.uniform(0.1, 2.0)))
     for o in range(int(rng.integers(1, 4))):
@@ -57,6 +57,7 @@ def random_options(rng):
     o.bvh_builder = int(rng.integers(0, 2)); o.morton_adaptive = int(rng.integers(0, 2))
     o.raster_mode = int(rng.integers(0, 2))       # drawn last: the cases keep the options they had before it existed
     o.raster_layers = int(rng.integers(0, 2))
+    o.ray_chunk_size = int(rng.choice([0xFFFFFF, 4096, 640, 64]))      # the compat sampler's chunk-local table index wraps
     if o.raster_layers == capi.LAYERS_ALL:
         o.raster_mode = capi.RASTER_REFERENCE     # the layers are centre-sampled
     return o
