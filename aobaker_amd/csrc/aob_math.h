@@ -167,14 +167,14 @@ struct CosineGrid { int32_t sx, sy; float inv_sx, inv_sy; };
 // COSINE sampler: stratified (sx x sy grid over the unit square), jittered by a
 // counter-based hash of (seed, texel, sample), mapped to a cosine-weighted
 // direction in the local frame (x, z tangent; y normal).
-__device__ __forceinline__ f3 cosine_sample(uint32_t base, int32_t i, const CosineGrid& g)
+// (cx, cy) = (i % sx, i / sx): the caller that walks i upwards keeps them as counters instead of dividing
+__device__ __forceinline__ f3 cosine_sample_cell(uint32_t base, int32_t i, int32_t cx, int32_t cy, const CosineGrid& g)
 {
     const float one_minus = 0.99999994f;
     uint32_t a = pcg_hash(base + 2u * (uint32_t)i);
     uint32_t b = pcg_hash(base + 2u * (uint32_t)i + 1u);
     float j1 = (float)(a >> 8) * 5.9604644775390625e-8f;
     float j2 = (float)(b >> 8) * 5.9604644775390625e-8f;
-    int32_t cy = i / g.sx, cx = i - cy * g.sx;
     float u1 = fminf(((float)cx + j1) * g.inv_sx, one_minus);
     float u2 = fminf(((float)cy + j2) * g.inv_sy, one_minus);
     if (cy >= g.sy) { u1 = j1; u2 = j2; }      // samples beyond the sx*sy grid are plain random
@@ -183,6 +183,12 @@ __device__ __forceinline__ f3 cosine_sample(uint32_t base, int32_t i, const Cosi
     float s, c;
     sincos2pi(u2, s, c);
     return make_f3(r * c, y, r * s);
+}
+
+__device__ __forceinline__ f3 cosine_sample(uint32_t base, int32_t i, const CosineGrid& g)
+{
+    const int32_t cy = i / g.sx;
+    return cosine_sample_cell(base, i, i - cy * g.sx, cy, g);
 }
 
 // host side of the COSINE sampler: sx = floor(sqrt(spp)), sy = spp / sx; samples beyond sx*sy are unstratified

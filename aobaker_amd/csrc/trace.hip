@@ -187,6 +187,7 @@ void k_trace(TraceParams p)
     const int32_t gen_begin = (int32_t)((int64_t)p.spp * part / p.parts);
     const int32_t gen_end = n_valid ? (int32_t)((int64_t)p.spp * (part + 1u) / p.parts) : gen_begin;
     int32_t gen_next = gen_begin;    // wave-uniform: next sample index
+    int32_t gen_cy = gen_begin / p.grid.sx, gen_cx = gen_begin - gen_cy * p.grid.sx;     // ... and its cell of the COSINE sampler's grid
     uint32_t q_head = 0, q_count = 0;                   // wave-uniform: the queue is a ring of 64 rays
 
     // ---- the ray a lane is tracing ----
@@ -288,6 +289,8 @@ void k_trace(TraceParams p)
                 if (pass == 1 || q_count != 0u || gen_next >= gen_end) break;
                 // the queue is empty: sample gen_next of all 64 surfels, one per lane
                 const int32_t i = gen_next++;
+                const int32_t cell_x = gen_cx, cell_y = gen_cy;
+                if (++gen_cx == p.grid.sx) { gen_cx = 0; gen_cy++; }
                 if (valid) {
                     const float4* fr = p.frames + 4ull * (wave_first + lane);
                     const float4 a = fr[0], b = fr[1], c = fr[2];
@@ -297,7 +300,7 @@ void k_trace(TraceParams p)
                         const float* t = p.hemisphere + 3ull * gen_key + 3 * i;
                         h = make_f3(t[0], t[1], t[2]);
                     } else {
-                        h = cosine_sample(gen_key, i, p.grid);
+                        h = cosine_sample_cell(gen_key, i, cell_x, cell_y, p.grid);
                     }
                     const f3 d = make_f3(fmaf(h.z, Z.x, fmaf(h.y, N.x, h.x * X.x)),
                                          fmaf(h.z, Z.y, fmaf(h.y, N.y, h.x * X.y)),
