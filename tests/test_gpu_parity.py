@@ -393,6 +393,22 @@ def test_chunk_local_sample_indexing(engine, orc, chunk, spp):
     assert len(surfels) > 4 * max(1, min(chunk // spp, 65535)) or chunk == 0xFFFFFF        # the index really wraps
 
 
+@pytest.mark.parametrize("spp", [1, 2, 31, 33, 127, 1000, 4097])
+@pytest.mark.parametrize("mode", [0, 2, 3, 4])
+def test_odd_and_large_sample_counts(engine, orc, spp, mode):
+    """Sample counts that do not divide into the kernel's four parts per tile, below the 32 samples a part needs, and far
+    above the reference's 100: whole bake == oracle."""
+    mk = lambda: scenes.two_section_scene(16, bpc=1 if MODES[mode]["accumulate"] == capi.ACCUMULATE_QUANTISED else 4)
+    opt = make_options(orc, sample_count=spp, **MODES[mode])
+    gpu, cpu = mk(), mk()
+    engine.Options = opt
+    engine.Bake(gpu)
+    st = orc.bake(FlatScene(cpu).desc, opt, threads=8)
+    assert engine.LastStats.ray_count == st.rays and st.rays % spp == 0
+    for i in range(gpu.GetMaterialCount()):
+        assert np.array_equal(gpu.GetMaterial(i).GetAOTexture().GetData(), cpu.GetMaterial(i).GetAOTexture().GetData())
+
+
 def test_invalid_arguments_are_reported(engine, orc):
     flat = FlatScene(scenes.plane_scene(8))
     opt = make_options(orc, sample_count=0)
