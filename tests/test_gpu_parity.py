@@ -409,6 +409,41 @@ def test_odd_and_large_sample_counts(engine, orc, spp, mode):
         assert np.array_equal(gpu.GetMaterial(i).GetAOTexture().GetData(), cpu.GetMaterial(i).GetAOTexture().GetData())
 
 
+@pytest.mark.parametrize("structure", [(2, 0, 0), (4, 1, 1), (2, 1, 1), (4, 0, 0)])
+@pytest.mark.parametrize("bad", ["nan", "inf", "huge", "tiny", "far"])
+def test_hostile_coordinates(engine, orc, bad, structure):
+    """A NaN or infinite vertex, coordinates of 1e30 / 1e-30, a mesh 1e8 away from the origin: builders, quantisation and
+    the walk end, and agree with the oracle (such triangles are never hit, `common.cl:193-216`)."""
+    from aobaker_amd.scene import BakeObject, MaterialObject, RenderMesh, Scene, Section, make_vertices
+
+    def mk():
+        p, n, uv, idx = scenes.terrain_mesh(grid=36, seed=1)            # 2 592 triangles: more than one PLOC tile
+        p = p.copy()
+        if bad == "nan":
+            p[10] = np.nan; p[700, 2] = np.nan
+        elif bad == "inf":
+            p[10, 1] = np.inf; p[900, 0] = -np.inf
+        elif bad == "huge":
+            p *= np.float32(1e30)
+        elif bad == "tiny":
+            p *= np.float32(1e-30)
+        else:
+            p += np.float32(1e8)
+        sc = Scene(); m = sc.AddMaterial(MaterialObject("A", 48, 48))
+        o = sc.AddObject(BakeObject("O")); o.AddSection(Section("s", RenderMesh(make_vertices(p, n, uv), idx), m))
+        return sc
+    opt = make_options(orc, sample_count=6, **MODES[0])
+    opt.bvh_width, opt.bvh_quantised, opt.bvh_builder = structure
+    gpu, cpu = mk(), mk()
+    engine.Options = opt
+    engine.Bake(gpu)
+    st = orc.bake(FlatScene(cpu).desc, opt, threads=8)
+    # AobStats::ray_count is covered surfels x spp (SURVEY §8(d)); the oracle counts the rays it cast, and casts none from a
+    # surfel whose position or normal is not finite
+    assert engine.LastStats.ray_count >= st.rays and (bad in ("nan", "inf") or engine.LastStats.ray_count == st.rays)
+    assert np.array_equal(gpu.GetMaterial(0).GetAOTexture().GetData(), cpu.GetMaterial(0).GetAOTexture().GetData())
+
+
 def test_invalid_arguments_are_reported(engine, orc):
     flat = FlatScene(scenes.plane_scene(8))
     opt = make_options(orc, sample_count=0)
