@@ -86,6 +86,7 @@ struct AobBake {
     aob::Box* node_bounds = nullptr;
     uint32_t* refit_flags = nullptr;
     uint32_t* depth_dev = nullptr;
+    uint32_t* node_height = nullptr;      // PLOC: height of every inner node (the root's is the tree depth)
     uint2*    ploc_sums = nullptr;      // PLOC builder: scan partials (alive, merged)
     uint32_t* ploc_totals = nullptr;
     AobBvhNode* nodes = nullptr;

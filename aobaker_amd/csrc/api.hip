@@ -95,7 +95,7 @@ static void free_bake(AobBake* b)
     hipFree(b->tri_verts); hipFree(b->prim_bounds); hipFree(b->scene_bounds_enc);
     hipFree(b->codes[0]); hipFree(b->codes[1]); hipFree(b->prim_idx[0]); hipFree(b->prim_idx[1]);
     hipFree(b->sort_temp); hipFree(b->child_left); hipFree(b->child_right); hipFree(b->parent);
-    hipFree(b->node_bounds); hipFree(b->refit_flags); hipFree(b->depth_dev); hipFree(b->ploc_sums); hipFree(b->ploc_totals); hipFree(b->nodes); hipFree(b->nodes4); hipFree(b->leaf_tris); hipFree(b->nodes2q); hipFree(b->nodes4q); hipFree(b->packed_index); hipFree(b->node4q_count_dev); hipFree(b->quant_frame);
+    hipFree(b->node_bounds); hipFree(b->refit_flags); hipFree(b->depth_dev); hipFree(b->node_height); hipFree(b->ploc_sums); hipFree(b->ploc_totals); hipFree(b->nodes); hipFree(b->nodes4); hipFree(b->leaf_tris); hipFree(b->nodes2q); hipFree(b->nodes4q); hipFree(b->packed_index); hipFree(b->node4q_count_dev); hipFree(b->quant_frame);
     hipFree(b->hemisphere); hipFree(b->gstack); hipFree(b->trace_unit_next); hipFree(b->hidden_from_others);
     if (b->pinned) hipHostFree(b->pinned);
     for (auto& e : b->ev) if (e) hipEventDestroy(e);
@@ -283,6 +283,7 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
     AOB_C(dev_alloc(&b->node_bounds, 2 * n));
     AOB_C(dev_alloc(&b->refit_flags, n));
     AOB_C(dev_alloc(&b->depth_dev, 1));
+    AOB_C(dev_alloc(&b->node_height, n));
     AOB_C(dev_alloc(&b->ploc_sums, n / 1024 + 4));
     AOB_C(dev_alloc(&b->ploc_totals, 4));
     AOB_C(dev_alloc(&b->nodes, 2 * n));

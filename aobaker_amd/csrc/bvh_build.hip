@@ -582,7 +582,7 @@ void k_ploc_scan(uint2* sums, uint32_t nblocks, uint32_t* __restrict__ totals_ho
 // one tile of the compaction: survivors keep their order, the lower half of a mutual pair becomes the merged node
 __device__ __forceinline__ void ploc_emit_tile(const uint32_t* cl, const uint32_t* nn, uint32_t m, uint32_t base, uint2 off,
                                                uint32_t created, uint32_t n, uint32_t* nxt, uint32_t* child_left,
-                                               uint32_t* child_right, uint32_t* parent, Box* bounds, uint2* total_out)
+                                               uint32_t* child_right, uint32_t* parent, Box* bounds, uint32_t* height, uint2* total_out)
 {
     uint32_t al[kPlocItems], mg[kPlocItems];
     uint2 c = make_uint2(0, 0);
@@ -606,6 +606,8 @@ __device__ __forceinline__ void ploc_emit_tile(const uint32_t* cl, const uint32_
             bounds[id] = u;
             child_left[id] = a; child_right[id] = b2;
             parent[a] = id; parent[b2] = id;
+            // leaves (ids from n - 1) have height 0; the root's height is the depth of the deepest leaf
+            height[id] = 1u + max(a < n - 1u ? height[a] : 0u, b2 < n - 1u ? height[b2] : 0u);
         }
         nxt[pos++] = id;
     }
@@ -614,11 +616,11 @@ __device__ __forceinline__ void ploc_emit_tile(const uint32_t* cl, const uint32_
 __global__ __launch_bounds__(kBlock)
 void k_ploc_emit(const uint32_t* __restrict__ cl, const uint32_t* __restrict__ nn, uint32_t m, const uint2* __restrict__ offsets,
                  uint32_t created, uint32_t n, uint32_t* __restrict__ nxt, uint32_t* __restrict__ child_left,
-                 uint32_t* __restrict__ child_right, uint32_t* __restrict__ parent, Box* __restrict__ bounds)
+                 uint32_t* __restrict__ child_right, uint32_t* __restrict__ parent, Box* __restrict__ bounds, uint32_t* height)
 {
     uint2 total;
     ploc_emit_tile(cl, nn, m, blockIdx.x * kPlocTile + threadIdx.x * kPlocItems, offsets[blockIdx.x], created, n, nxt,
-                   child_left, child_right, parent, bounds, &total);
+                   child_left, child_right, parent, bounds, height, &total);
 }
 
 // The last rounds — once the list fits one tile — in ONE launch: the same three steps per round, separated by
@@ -627,12 +629,16 @@ void k_ploc_emit(const uint32_t* __restrict__ cl, const uint32_t* __restrict__ n
 __global__ __launch_bounds__(kBlock)
 void k_ploc_tail(const uint32_t* __restrict__ cl_in, uint32_t m, uint32_t created, uint32_t n, int iter, int radius,
                  uint32_t* __restrict__ child_left, uint32_t* __restrict__ child_right, uint32_t* __restrict__ parent,
-                 Box* __restrict__ bounds)
+                 Box* __restrict__ bounds, const uint32_t* __restrict__ height, uint32_t* __restrict__ depth_out)
 {
     __shared__ Box s_box[2][kPlocTile];
     __shared__ uint32_t s_cl[2][kPlocTile];
+    __shared__ uint16_t s_h[2][kPlocTile];              // cluster heights (a tree deeper than 65535 levels is refused long before)
     __shared__ uint32_t s_nn[kPlocTile];
-    for (uint32_t i = threadIdx.x; i < m; i += kBlock) { const uint32_t id = cl_in[i]; s_cl[0][i] = id; s_box[0][i] = bounds[id]; }
+    for (uint32_t i = threadIdx.x; i < m; i += kBlock) {
+        const uint32_t id = cl_in[i];
+        s_cl[0][i] = id; s_box[0][i] = bounds[id]; s_h[0][i] = (uint16_t)(id < n - 1u ? height[id] : 0u);
+    }
     __syncthreads();
     int cur = 0;
     while (m > 1) {
@@ -670,6 +676,7 @@ void k_ploc_tail(const uint32_t* __restrict__ cl_in, uint32_t m, uint32_t create
             if (!al[k]) continue;
             uint32_t id = s_cl[cur][i];
             Box u = s_box[cur][i];
+            uint16_t h = s_h[cur][i];
             if (mg[k]) {
                 const uint32_t j = s_nn[i], a = id, b2 = s_cl[cur][j];
                 id = n - 2u - (created + mk);                          // as ploc_emit_tile
@@ -680,25 +687,16 @@ void k_ploc_tail(const uint32_t* __restrict__ cl_in, uint32_t m, uint32_t create
                 bounds[id] = u;
                 child_left[id] = a; child_right[id] = b2;
                 parent[a] = id; parent[b2] = id;
+                h = (uint16_t)(1u + max((uint32_t)h, (uint32_t)s_h[cur][j]));
             }
-            s_cl[cur ^ 1][pos] = id; s_box[cur ^ 1][pos] = u;
+            s_cl[cur ^ 1][pos] = id; s_box[cur ^ 1][pos] = u; s_h[cur ^ 1][pos] = h;
             pos++;
         }
         __syncthreads();
         if (total.x >= m || total.y == 0) iter = 256;                  // no progress (never observed): pair up next round
         else { m = total.x; created += total.y; cur ^= 1; iter++; }
     }
-}
-
-__global__ __launch_bounds__(kBlock)
-void k_leaf_depth(uint32_t n, const uint32_t* __restrict__ parent, uint32_t* __restrict__ depth_max)
-{
-    uint32_t p = blockIdx.x * kBlock + threadIdx.x;
-    uint32_t depth = 0;
-    if (p < n) for (uint32_t a = n - 1 + p; parent[a] != 0xffffffffu; a = parent[a]) depth++;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) depth = max(depth, (uint32_t)__shfl_xor((int)depth, off));
-    if ((threadIdx.x & 63) == 0 && depth) atomicMax(depth_max, depth);
+    if (threadIdx.x == 0) *depth_out = s_h[cur][0];                    // the root
 }
 
 __global__ void k_set_root_parent(uint32_t* parent) { if (threadIdx.x == 0) parent[0] = 0xffffffffu; }
@@ -718,7 +716,7 @@ static int build_ploc(AobBake* b, uint32_t n)
         hipLaunchKernelGGL(k_ploc_count, dim3(tiles), dim3(kBlock), 0, s, nn, m, b->ploc_sums);
         hipLaunchKernelGGL(k_ploc_scan, dim3(1), dim3(kBlock), 0, s, b->ploc_sums, tiles, b->ploc_totals);
         hipLaunchKernelGGL(k_ploc_emit, dim3(tiles), dim3(kBlock), 0, s, cl[cur], nn, m, b->ploc_sums, created, n, cl[cur ^ 1],
-                           b->child_left, b->child_right, b->parent, b->node_bounds);
+                           b->child_left, b->child_right, b->parent, b->node_bounds, b->node_height);
         AOB_HIP(hipMemcpyAsync(&b->pinned[2], b->ploc_totals, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         AOB_HIP(hipStreamSynchronize(s));                               // the list length drives the next launch
         const uint32_t alive = b->pinned[2], merged = b->pinned[3];
@@ -726,9 +724,8 @@ static int build_ploc(AobBake* b, uint32_t n)
         m = alive; created += merged; cur ^= 1; iter++;
     }
     if (m > 1) hipLaunchKernelGGL(k_ploc_tail, dim3(1), dim3(kBlock), 0, s, cl[cur], m, created, n, iter, kPlocRadius,
-                                  b->child_left, b->child_right, b->parent, b->node_bounds);
+                                  b->child_left, b->child_right, b->parent, b->node_bounds, b->node_height, b->depth_dev);
     hipLaunchKernelGGL(k_set_root_parent, dim3(1), dim3(64), 0, s, b->parent);
-    hipLaunchKernelGGL(k_leaf_depth, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, b->parent, b->depth_dev);
     return AOB_OK;
 }
 
