@@ -596,9 +596,10 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
             p.begin = sb; p.end = se;
             p.ntiles = (uint32_t)((se - sb + kWave - 1) / kWave);
             // Sample parts: a wavefront lives ~11 ms on the headline workload and the launch ends with a tail of idle
-            // CUs about that long; four parts per tile shorten both fourfold.  Only where adding the parts is exact.
+            // CUs about that long; four parts per tile shorten both fourfold (a part is at least 16 samples: fewer cost more in
+            // prologues and result atomics than they balance).  Only where adding the parts is exact.
             const bool split_exact = o.accumulate == AOB_ACCUMULATE_QUANTISED || (o.sampler == AOB_SAMPLER_COSINE && o.use_any_hit);
-            p.parts = split_exact ? (uint32_t)max(1, min(env_int("AOB_TRACE_PARTS", 4), o.sample_count / 32)) : 1u;
+            p.parts = split_exact ? (uint32_t)max(1, min(env_int("AOB_TRACE_PARTS", 4), o.sample_count / max(1, env_int("AOB_TRACE_PART_MIN", 16)))) : 1u;
             // chunks: bands of 8 tile rows when every texel of the rasterised rows has exactly one surfel (then the trace
             // order is the plain tile grid), else 2048 tiles
             p.band_row = 0;
