@@ -559,26 +559,6 @@ void k_ploc_count(const uint32_t* __restrict__ nn, uint32_t m, uint2* __restrict
     if (threadIdx.x == 0) sums[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(kBlock)
-void k_ploc_scan(uint2* sums, uint32_t nblocks, uint32_t* __restrict__ totals_host_visible)
-{
-    __shared__ uint2 carry_s;
-    if (threadIdx.x == 0) carry_s = make_uint2(0, 0);
-    __syncthreads();
-    for (uint32_t base = 0; base < nblocks; base += kBlock) {
-        const uint32_t i = base + threadIdx.x;
-        const uint2 v = i < nblocks ? sums[i] : make_uint2(0, 0);
-        uint2 total;
-        const uint2 ex = block_exclusive_scan2(v, &total);
-        const uint2 carry = carry_s;
-        if (i < nblocks) sums[i] = make_uint2(carry.x + ex.x, carry.y + ex.y);
-        __syncthreads();
-        if (threadIdx.x == 0) carry_s = make_uint2(carry.x + total.x, carry.y + total.y);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { sums[nblocks] = carry_s; totals_host_visible[0] = carry_s.x; totals_host_visible[1] = carry_s.y; }
-}
-
 // one tile of the compaction: survivors keep their order, the lower half of a mutual pair becomes the merged node
 __device__ __forceinline__ void ploc_emit_tile(const uint32_t* cl, const uint32_t* nn, uint32_t m, uint32_t base, uint2 off,
                                                uint32_t created, uint32_t n, uint32_t* nxt, uint32_t* child_left,
@@ -613,13 +593,27 @@ __device__ __forceinline__ void ploc_emit_tile(const uint32_t* cl, const uint32_
     }
 }
 
+// `sums` holds every tile's (alive, merged) counts (k_ploc_count): a tile's offsets are the sums of the tiles before it — at
+// most a thousand values, added up by the tile itself rather than by a scan launch of its own; tile 0 also leaves the totals
+// for the host.
 __global__ __launch_bounds__(kBlock)
-void k_ploc_emit(const uint32_t* __restrict__ cl, const uint32_t* __restrict__ nn, uint32_t m, const uint2* __restrict__ offsets,
+void k_ploc_emit(const uint32_t* __restrict__ cl, const uint32_t* __restrict__ nn, uint32_t m, const uint2* __restrict__ sums,
+                 uint32_t tiles, uint32_t* __restrict__ totals_host_visible,
                  uint32_t created, uint32_t n, uint32_t* __restrict__ nxt, uint32_t* __restrict__ child_left,
                  uint32_t* __restrict__ child_right, uint32_t* __restrict__ parent, Box* __restrict__ bounds, uint32_t* height)
 {
+    uint2 before = make_uint2(0, 0), all = make_uint2(0, 0);
+    for (uint32_t i = threadIdx.x; i < tiles; i += kBlock) {
+        const uint2 v = sums[i];
+        all.x += v.x; all.y += v.y;
+        if (i < blockIdx.x) { before.x += v.x; before.y += v.y; }
+    }
+    uint2 off, grand;
+    block_exclusive_scan2(before, &off);
+    block_exclusive_scan2(all, &grand);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { totals_host_visible[0] = grand.x; totals_host_visible[1] = grand.y; }
     uint2 total;
-    ploc_emit_tile(cl, nn, m, blockIdx.x * kPlocTile + threadIdx.x * kPlocItems, offsets[blockIdx.x], created, n, nxt,
+    ploc_emit_tile(cl, nn, m, blockIdx.x * kPlocTile + threadIdx.x * kPlocItems, off, created, n, nxt,
                    child_left, child_right, parent, bounds, height, &total);
 }
 
@@ -714,9 +708,8 @@ static int build_ploc(AobBake* b, uint32_t n)
         const uint32_t tiles = (m + kPlocTile - 1) / kPlocTile;
         hipLaunchKernelGGL(k_ploc_nn, dim3(blocks_for(m)), dim3(kBlock), 0, s, cl[cur], m, b->node_bounds, kPlocRadius, forced, nn);
         hipLaunchKernelGGL(k_ploc_count, dim3(tiles), dim3(kBlock), 0, s, nn, m, b->ploc_sums);
-        hipLaunchKernelGGL(k_ploc_scan, dim3(1), dim3(kBlock), 0, s, b->ploc_sums, tiles, b->ploc_totals);
-        hipLaunchKernelGGL(k_ploc_emit, dim3(tiles), dim3(kBlock), 0, s, cl[cur], nn, m, b->ploc_sums, created, n, cl[cur ^ 1],
-                           b->child_left, b->child_right, b->parent, b->node_bounds, b->node_height);
+        hipLaunchKernelGGL(k_ploc_emit, dim3(tiles), dim3(kBlock), 0, s, cl[cur], nn, m, b->ploc_sums, tiles, b->ploc_totals, created, n,
+                           cl[cur ^ 1], b->child_left, b->child_right, b->parent, b->node_bounds, b->node_height);
         AOB_HIP(hipMemcpyAsync(&b->pinned[2], b->ploc_totals, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         AOB_HIP(hipStreamSynchronize(s));                               // the list length drives the next launch
         const uint32_t alive = b->pinned[2], merged = b->pinned[3];
