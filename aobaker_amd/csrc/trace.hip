@@ -69,7 +69,10 @@ struct TraceParams {
     uint32_t full_tiles;           // tiles in those groups; the rest is split into 8 runs of rest_per_xcd
     uint32_t rest_per_xcd;
     uint32_t band_row;             // fully covered atlas: tiles per tile row (chunk = a band of 8 tile rows), else 0
-    uint32_t units_per_xcd;        // (xcd_chunk_tiles + rest_per_xcd) * parts
+    uint32_t units_per_xcd;        // coarse_units + fine tiles * parts_fine
+    uint32_t coarse_units;         // the first units of a queue: coarse_tiles tiles x parts
+    uint32_t coarse_tiles;
+    uint32_t parts_fine;           // the last tiles of every queue are cut into this many parts: a shorter tail of idle CUs at the end
     uint32_t* unit_next;           // [8] next unit of each XCD's queue (zeroed before the launch)
     // MASKED: section visibility (AOB_MESH_*)
     const uint32_t* hidden_from_others;    // bit s: the triangles of shape s are ignored by rays of other shapes
@@ -148,7 +151,10 @@ void k_trace(TraceParams p)
         if (rank < p.units_per_xcd) break;
         if (++tried == 8u) return;
     }
-    const uint32_t part = rank % p.parts, kt = rank / p.parts;
+    const bool fine = rank >= p.coarse_units;
+    const uint32_t nparts = fine ? p.parts_fine : p.parts;
+    const uint32_t part = fine ? (rank - p.coarse_units) % p.parts_fine : rank % p.parts;
+    const uint32_t kt = fine ? p.coarse_tiles + (rank - p.coarse_units) / p.parts_fine : rank / p.parts;
     uint32_t tile;
     if (kt < p.xcd_chunk_tiles) {
         const uint32_t c = kt / p.chunk, within = kt - c * p.chunk;
@@ -184,8 +190,8 @@ void k_trace(TraceParams p)
     const uint64_t valid_m = __ballot(valid);
     const uint32_t n_valid = (uint32_t)__popcll(valid_m);
     // this workgroup's part of the samples
-    const int32_t gen_begin = (int32_t)((int64_t)p.spp * part / p.parts);
-    const int32_t gen_end = n_valid ? (int32_t)((int64_t)p.spp * (part + 1u) / p.parts) : gen_begin;
+    const int32_t gen_begin = (int32_t)((int64_t)p.spp * part / nparts);
+    const int32_t gen_end = n_valid ? (int32_t)((int64_t)p.spp * (part + 1u) / nparts) : gen_begin;
     int32_t gen_next = gen_begin;    // wave-uniform: next sample index
     int32_t gen_cy = gen_begin / p.grid.sx, gen_cx = gen_begin - gen_cy * p.grid.sx;     // ... and its cell of the COSINE sampler's grid
     uint32_t q_head = 0, q_count = 0;                   // wave-uniform: the queue is a ring of 64 rays
@@ -611,7 +617,14 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
             p.xcd_chunk_tiles = groups * p.chunk;
             p.full_tiles = groups * p.chunk * 8u;
             p.rest_per_xcd = (p.ntiles - p.full_tiles + 7u) / 8u;
-            p.units_per_xcd = (p.xcd_chunk_tiles + p.rest_per_xcd) * p.parts;
+            // the last eighth of every queue in parts half as long (where a part keeps at least 16 samples): the launch ends
+            // when the slowest wavefront finishes its last unit
+            const uint32_t queue_tiles = p.xcd_chunk_tiles + p.rest_per_xcd;
+            p.parts_fine = p.parts * 2u;
+            const uint32_t fine_tiles = (p.parts > 1u && (uint32_t)o.sample_count / p.parts_fine >= 16u) ? queue_tiles / (uint32_t)max(1, env_int("AOB_TRACE_FINE_DIV", 8)) : 0u;
+            p.coarse_tiles = queue_tiles - fine_tiles;
+            p.coarse_units = p.coarse_tiles * p.parts;
+            p.units_per_xcd = p.coarse_units + fine_tiles * p.parts_fine;
             // as many wavefronts as the chip holds (5 KB of LDS and <= 64 VGPRs each: 32 per CU), fewer for small jobs
             const uint32_t resident = 32u * (uint32_t)b->cu_count;
             dim3 grid(min(resident, (p.units_per_xcd * 8u + 7u) / 8u * 8u));

@@ -444,6 +444,23 @@ def test_hostile_coordinates(engine, orc, bad, structure):
     assert np.array_equal(gpu.GetMaterial(0).GetAOTexture().GetData(), cpu.GetMaterial(0).GetAOTexture().GetData())
 
 
+@pytest.mark.parametrize("spp", [128, 200])
+@pytest.mark.parametrize("mode", [0, 2, 4])
+def test_fine_units_at_the_end_of_the_queues(engine, orc, mode, spp):
+    """Enough tiles per XCD queue (>= 8) and enough samples (>= 128) for the last eighth of every queue to be cut into twice as
+    many sample parts: the cells are the oracle's whatever the cut."""
+    flat = FlatScene(scenes.terrain_scene(grid=40, atlas=(96, 72)))              # 6 912 surfels: 108 tiles, 14 per queue
+    opt = make_options(orc, sample_count=spp, **MODES[mode])
+    m = flat.material_array[0]
+    nodes, _ = orc.bvh_build(orc.scene_triangles(flat.desc))
+    surfels, sidx = orc.rasterize(flat.desc, 0, opt)
+    want, _ = orc.trace(nodes, surfels, sidx, opt, m.width, m.height, orc.compat_table(opt), threads=8)
+    with Baker(flat, opt) as b:
+        b.build_bvh(); b.rasterize(0); b.trace(0)
+        got = b.results(0)
+    assert np.array_equal(got["total_bits"], want["total_bits"]) and np.array_equal(got["weight_bits"], want["weight_bits"])
+
+
 def test_invalid_arguments_are_reported(engine, orc):
     flat = FlatScene(scenes.plane_scene(8))
     opt = make_options(orc, sample_count=0)
