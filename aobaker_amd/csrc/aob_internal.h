@@ -102,6 +102,7 @@ struct AobBake {
     uint64_t node_count = 0;
     uint32_t bvh_depth = 0;
     bool bvh_built = false, depth_known = false, bvh_timed = false;
+    bool nodes_emitted = false, nodes2q_emitted = false;   // `nodes` / `nodes2q` are written when something first wants them (bvh_build.hip)
     uint32_t* pinned = nullptr;         // 64 B of pinned host memory for small read-backs
 
     uint32_t* gstack = nullptr;         // traversal stacks in HBM, only for trees deeper than 62 levels
@@ -123,6 +124,8 @@ struct AobBake {
 namespace aob {
 // stage launchers (each enqueues on bake->stream; only the ones that say so synchronise)
 int build_bvh(AobBake* b);                                   // bvh_build.hip
+int ensure_nodes(AobBake* b);                                // the fp32 BVH2 node array (`nodes`), from the tree that is built
+int ensure_nodes2q(AobBake* b);                              // the quantised BVH2 node array (`nodes2q`)
 int rasterize_material(AobBake* b, int32_t material, int32_t row_begin, int32_t row_end);   // raster.hip (syncs once per section)
 int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end);   // trace.hip
 int resolve_material(AobBake* b, int32_t material);          // resolve.hip

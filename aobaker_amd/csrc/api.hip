@@ -491,6 +491,7 @@ int aob_bake_copy_nodes(AobBake* b, AobBvhNode* dst, uint64_t capacity)
 {
     AOB_TRY(check_bake(b, 0, false));
     if (capacity < b->node_count || (!dst && b->node_count)) { set_error("node buffer too small"); return AOB_ERR_INVALID_ARGUMENT; }
+    AOB_TRY(ensure_nodes(b));
     if (b->node_count) AOB_HIP(hipMemcpyAsync(dst, b->nodes, sizeof(AobBvhNode) * b->node_count, hipMemcpyDeviceToHost, b->stream));
     AOB_HIP(hipStreamSynchronize(b->stream));
     return AOB_OK;
@@ -528,6 +529,7 @@ int aob_bake_copy_nodes2q(AobBake* b, AobBvh2QNode* dst, uint64_t capacity)
     AOB_TRY(check_bake(b, 0, false));
     const uint64_t n = b->bvh_built && b->triangle_count ? b->triangle_count - 1 : 0;
     if (capacity < n || (!dst && n)) { set_error("quantised node buffer too small"); return AOB_ERR_INVALID_ARGUMENT; }
+    AOB_TRY(ensure_nodes2q(b));
     if (n) AOB_HIP(hipMemcpyAsync(dst, b->nodes2q, sizeof(AobBvh2QNode) * n, hipMemcpyDeviceToHost, b->stream));
     AOB_HIP(hipStreamSynchronize(b->stream));
     return AOB_OK;

@@ -769,8 +769,9 @@ int build_bvh(AobBake* b)
                            b->child_right, b->node_bounds, b->refit_flags, b->depth_dev);
     }
     b->node_count = n == 1 ? 1 : 2 * n - 1;
-    hipLaunchKernelGGL(k_emit_nodes, dim3(blocks_for(b->node_count)), dim3(kBlock), 0, s, (uint32_t)n, b->child_left,
-                       b->child_right, b->node_bounds, b->prim_idx[1], b->tri_verts, (float4*)b->nodes);
+    // the node arrays of the other traversal structures are written when something asks for them (a parity test, a
+    // trace with those options): the default walk reads nodes4q and leaf_tris only
+    b->nodes_emitted = false; b->nodes2q_emitted = false;
     // the 4-ary structure the quad-per-ray traversal walks (bvh_width 4)
     b->node4_count = n == 1 ? 1 : n - 1;
     AOB_HIP(hipMemsetAsync(b->nodes4, 0, sizeof(float4) * 8 * b->node4_count, s));
@@ -781,8 +782,6 @@ int build_bvh(AobBake* b)
     else hipLaunchKernelGGL(k_collapse4<0>, dim3(blocks_for(n - 1)), dim3(kBlock), 0, s, (uint32_t)n, b->parent, b->child_left,
                             b->child_right, b->node_bounds, b->nodes4);
     hipLaunchKernelGGL(k_quant_frame, dim3(1), dim3(64), 0, s, b->scene_bounds_enc, b->quant_frame);
-    if (n > 1) hipLaunchKernelGGL(k_emit_nodes_q, dim3(blocks_for(n - 1)), dim3(kBlock), 0, s, (uint32_t)n, b->child_left,
-                                  b->child_right, b->node_bounds, b->quant_frame, b->nodes2q);
     {
         uint32_t* live = b->refit_flags;                     // free once the tree is built
         uint32_t* packed = b->packed_index;
@@ -797,6 +796,28 @@ int build_bvh(AobBake* b)
                        b->leaf_tris);
     AOB_HIP(hipGetLastError());
     b->bvh_built = true;
+    if (b->opt.bvh_width != 4 && !b->opt.bvh_quantised) AOB_TRY(ensure_nodes(b));
+    if (b->opt.bvh_width != 4 && b->opt.bvh_quantised) AOB_TRY(ensure_nodes2q(b));
+    return AOB_OK;
+}
+
+int ensure_nodes(AobBake* b)
+{
+    if (b->nodes_emitted || !b->bvh_built || b->triangle_count == 0) return AOB_OK;
+    hipLaunchKernelGGL(k_emit_nodes, dim3(blocks_for(b->node_count)), dim3(kBlock), 0, b->stream, (uint32_t)b->triangle_count, b->child_left,
+                       b->child_right, b->node_bounds, b->prim_idx[1], b->tri_verts, (float4*)b->nodes);
+    AOB_HIP(hipGetLastError());
+    b->nodes_emitted = true;
+    return AOB_OK;
+}
+
+int ensure_nodes2q(AobBake* b)
+{
+    if (b->nodes2q_emitted || !b->bvh_built || b->triangle_count < 2) return AOB_OK;
+    hipLaunchKernelGGL(k_emit_nodes_q, dim3(blocks_for(b->triangle_count - 1)), dim3(kBlock), 0, b->stream, (uint32_t)b->triangle_count,
+                       b->child_left, b->child_right, b->node_bounds, b->quant_frame, b->nodes2q);
+    AOB_HIP(hipGetLastError());
+    b->nodes2q_emitted = true;
     return AOB_OK;
 }
 

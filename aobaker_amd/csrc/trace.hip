@@ -571,6 +571,8 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
         const uint32_t in_lds = (uint32_t)lds_stack_entries(o.sampler, o.use_any_hit, o.accumulate);
         const uint32_t overflow = need > in_lds ? need - in_lds : 0u;
         TraceParams p;
+        if (!o.bvh_quantised) AOB_TRY(ensure_nodes(b));
+        else if (o.bvh_width != 4) AOB_TRY(ensure_nodes2q(b));
         p.nodes = (const float4*)b->nodes;
         p.nodesq = b->nodes2q; p.nodes4q = b->nodes4q; p.leaf_tris = b->leaf_tris; p.quant_frame = b->quant_frame;
         const int quant = o.bvh_quantised ? (o.bvh_width == 4 ? 2 : 1) : 0;
