@@ -117,6 +117,7 @@ struct AobBake {
 
     hipEvent_t ev[8] = {};
     hipEvent_t ev_trace[2] = {};
+    hipEvent_t ev_ploc[2] = {};         // PLOC rounds: the list length of round r is read back while round r + 1 runs
     bool trace_timed = false;
     AobStats stats = {};
 };

@@ -100,6 +100,7 @@ static void free_bake(AobBake* b)
     if (b->pinned) hipHostFree(b->pinned);
     for (auto& e : b->ev) if (e) hipEventDestroy(e);
     for (auto& e : b->ev_trace) if (e) hipEventDestroy(e);
+    for (auto& e : b->ev_ploc) if (e) hipEventDestroy(e);
     if (b->stream) hipStreamDestroy(b->stream);
     delete b;
 }
@@ -220,6 +221,7 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
     AOB_CH(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     for (auto& e : b->ev) AOB_CH(hipEventCreate(&e));
     for (auto& e : b->ev_trace) AOB_CH(hipEventCreate(&e));
+    for (auto& e : b->ev_ploc) AOB_CH(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     AOB_CH(hipHostMalloc((void**)&b->pinned, 64));
     AOB_CH(hipMalloc((void**)&b->trace_unit_next, 8 * sizeof(uint32_t)));
     AOB_CH(hipDeviceGetAttribute(&b->cu_count, hipDeviceAttributeMultiprocessorCount, g_device));
@@ -285,7 +287,7 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
     AOB_C(dev_alloc(&b->depth_dev, 1));
     AOB_C(dev_alloc(&b->node_height, n));
     AOB_C(dev_alloc(&b->ploc_sums, n / 1024 + 4));
-    AOB_C(dev_alloc(&b->ploc_totals, 4));
+    AOB_C(dev_alloc(&b->ploc_totals, 8));
     AOB_C(dev_alloc(&b->nodes, 2 * n));
     AOB_C(dev_alloc(&b->nodes4, 8 * n));
     AOB_C(dev_alloc(&b->leaf_tris, 3 * n));

@@ -483,10 +483,11 @@ __device__ __forceinline__ float merged_area(const Box& a, const Box& b)
 }
 
 __global__ __launch_bounds__(kBlock)
-void k_ploc_init(uint32_t n, uint32_t* __restrict__ cl)
+void k_ploc_init(uint32_t n, uint32_t* __restrict__ cl, uint32_t* __restrict__ state)
 {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i < n) cl[i] = n - 1 + i;
+    if (i == 0) { state[0] = n; state[1] = 0; state[2] = 0; state[3] = 0; }     // list length, inner nodes made, no-progress flag
 }
 
 // the position of cluster i's nearest neighbour within `radius` places (merged surface area; ties: the lower position)
@@ -505,10 +506,14 @@ __device__ __forceinline__ uint32_t ploc_nearest(const uint32_t* cl, uint32_t m,
     return bj;
 }
 
+// The round kernels take the list length (state[0]) and the number of inner nodes made so far (state[1]) from device
+// memory: the host launches a round with the length of two rounds ago as the grid's upper bound and reads the new length
+// back while the next round runs, instead of draining the stream after every round.
 __global__ __launch_bounds__(kBlock)
-void k_ploc_nn(const uint32_t* __restrict__ cl, uint32_t m, const Box* __restrict__ bounds, int radius, int forced,
+void k_ploc_nn(const uint32_t* __restrict__ cl, const uint32_t* __restrict__ state, const Box* __restrict__ bounds, int radius, int forced,
                uint32_t* __restrict__ nn)
 {
+    const uint32_t m = state[0];
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i < m) nn[i] = ploc_nearest(cl, m, bounds, radius, forced, i);
 }
@@ -548,8 +553,9 @@ __device__ __forceinline__ uint2 block_exclusive_scan2(uint2 v, uint2* total_out
 }
 
 __global__ __launch_bounds__(kBlock)
-void k_ploc_count(const uint32_t* __restrict__ nn, uint32_t m, uint2* __restrict__ sums)
+void k_ploc_count(const uint32_t* __restrict__ nn, const uint32_t* __restrict__ state, uint2* __restrict__ sums)
 {
+    const uint32_t m = state[0];                 // tiles beyond the list count nothing
     const uint32_t base = blockIdx.x * kPlocTile + threadIdx.x * kPlocItems;
     uint2 c = make_uint2(0, 0);
 #pragma unroll
@@ -597,11 +603,12 @@ __device__ __forceinline__ void ploc_emit_tile(const uint32_t* cl, const uint32_
 // most a thousand values, added up by the tile itself rather than by a scan launch of its own; tile 0 also leaves the totals
 // for the host.
 __global__ __launch_bounds__(kBlock)
-void k_ploc_emit(const uint32_t* __restrict__ cl, const uint32_t* __restrict__ nn, uint32_t m, const uint2* __restrict__ sums,
-                 uint32_t tiles, uint32_t* __restrict__ totals_host_visible,
-                 uint32_t created, uint32_t n, uint32_t* __restrict__ nxt, uint32_t* __restrict__ child_left,
+void k_ploc_emit(const uint32_t* __restrict__ cl, const uint32_t* __restrict__ nn, const uint32_t* __restrict__ state, const uint2* __restrict__ sums,
+                 uint32_t tiles, uint32_t* __restrict__ state_out,
+                 uint32_t n, uint32_t* __restrict__ nxt, uint32_t* __restrict__ child_left,
                  uint32_t* __restrict__ child_right, uint32_t* __restrict__ parent, Box* __restrict__ bounds, uint32_t* height)
 {
+    const uint32_t m = state[0], created = state[1];
     uint2 before = make_uint2(0, 0), all = make_uint2(0, 0);
     for (uint32_t i = threadIdx.x; i < tiles; i += kBlock) {
         const uint2 v = sums[i];
@@ -611,7 +618,10 @@ void k_ploc_emit(const uint32_t* __restrict__ cl, const uint32_t* __restrict__ n
     uint2 off, grand;
     block_exclusive_scan2(before, &off);
     block_exclusive_scan2(all, &grand);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { totals_host_visible[0] = grand.x; totals_host_visible[1] = grand.y; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        state_out[0] = grand.x; state_out[1] = created + grand.y;
+        state_out[2] = state[2] | ((grand.x >= m || grand.y == 0) ? 1u : 0u);      // a round without progress (never observed)
+    }
     uint2 total;
     ploc_emit_tile(cl, nn, m, blockIdx.x * kPlocTile + threadIdx.x * kPlocItems, off, created, n, nxt,
                    child_left, child_right, parent, bounds, height, &total);
@@ -621,7 +631,7 @@ void k_ploc_emit(const uint32_t* __restrict__ cl, const uint32_t* __restrict__ n
 // workgroup barriers instead of launches and a host read-back, with the cluster list, its boxes and the neighbour
 // indices in LDS (on the 1 M-triangle terrain two thirds of the rounds work on fewer than 1024 clusters).
 __global__ __launch_bounds__(kBlock)
-void k_ploc_tail(const uint32_t* __restrict__ cl_in, uint32_t m, uint32_t created, uint32_t n, int iter, int radius,
+void k_ploc_tail(const uint32_t* __restrict__ cl_in, const uint32_t* __restrict__ state, uint32_t n, int iter, int radius,
                  uint32_t* __restrict__ child_left, uint32_t* __restrict__ child_right, uint32_t* __restrict__ parent,
                  Box* __restrict__ bounds, const uint32_t* __restrict__ height, uint32_t* __restrict__ depth_out)
 {
@@ -629,6 +639,7 @@ void k_ploc_tail(const uint32_t* __restrict__ cl_in, uint32_t m, uint32_t create
     __shared__ uint32_t s_cl[2][kPlocTile];
     __shared__ uint16_t s_h[2][kPlocTile];              // cluster heights (a tree deeper than 65535 levels is refused long before)
     __shared__ uint32_t s_nn[kPlocTile];
+    uint32_t m = state[0], created = state[1];
     for (uint32_t i = threadIdx.x; i < m; i += kBlock) {
         const uint32_t id = cl_in[i];
         s_cl[0][i] = id; s_box[0][i] = bounds[id]; s_h[0][i] = (uint16_t)(id < n - 1u ? height[id] : 0u);
@@ -700,24 +711,38 @@ static int build_ploc(AobBake* b, uint32_t n)
     hipStream_t s = b->stream;
     uint32_t* cl[2] = { b->prim_idx[0], (uint32_t*)b->codes[0] };      // both free once the sort is done
     uint32_t* nn = b->refit_flags;
-    hipLaunchKernelGGL(k_ploc_init, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, cl[0]);
-    uint32_t m = n, created = 0;
+    hipLaunchKernelGGL(k_ploc_init, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, cl[0], b->ploc_totals);
+    // state[k] = { list length, inner nodes made, no-progress flag, - }: round r reads state[r & 1] and writes the other
+    uint32_t* state[2] = { b->ploc_totals, b->ploc_totals + 4 };
+    uint32_t* host[2] = { b->pinned + 4, b->pinned + 8 };
+    // a round is launched with the length read back after the round before last as its upper bound
+    uint32_t known = n;                                                // the latest length the host has seen
     int cur = 0, iter = 0;
-    while (m > (uint32_t)kPlocTile) {
+    while (known > (uint32_t)kPlocTile) {
         const int forced = iter >= 256;                                 // never observed; guarantees termination
-        const uint32_t tiles = (m + kPlocTile - 1) / kPlocTile;
-        hipLaunchKernelGGL(k_ploc_nn, dim3(blocks_for(m)), dim3(kBlock), 0, s, cl[cur], m, b->node_bounds, kPlocRadius, forced, nn);
-        hipLaunchKernelGGL(k_ploc_count, dim3(tiles), dim3(kBlock), 0, s, nn, m, b->ploc_sums);
-        hipLaunchKernelGGL(k_ploc_emit, dim3(tiles), dim3(kBlock), 0, s, cl[cur], nn, m, b->ploc_sums, tiles, b->ploc_totals, created, n,
+        const uint32_t tiles = (known + kPlocTile - 1) / kPlocTile;
+        const uint32_t* st = state[iter & 1]; uint32_t* st_out = state[(iter & 1) ^ 1];
+        hipLaunchKernelGGL(k_ploc_nn, dim3(blocks_for(known)), dim3(kBlock), 0, s, cl[cur], st, b->node_bounds, kPlocRadius, forced, nn);
+        hipLaunchKernelGGL(k_ploc_count, dim3(tiles), dim3(kBlock), 0, s, nn, st, b->ploc_sums);
+        hipLaunchKernelGGL(k_ploc_emit, dim3(tiles), dim3(kBlock), 0, s, cl[cur], nn, st, b->ploc_sums, tiles, st_out, n,
                            cl[cur ^ 1], b->child_left, b->child_right, b->parent, b->node_bounds, b->node_height);
-        AOB_HIP(hipMemcpyAsync(&b->pinned[2], b->ploc_totals, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        AOB_HIP(hipStreamSynchronize(s));                               // the list length drives the next launch
-        const uint32_t alive = b->pinned[2], merged = b->pinned[3];
-        if (alive >= m || merged == 0) { set_error("PLOC made no progress (m=%u)", m); return AOB_ERR_DEVICE; }
-        m = alive; created += merged; cur ^= 1; iter++;
+        AOB_HIP(hipMemcpyAsync(host[iter & 1], st_out, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        AOB_HIP(hipEventRecord(b->ev_ploc[iter & 1], s));
+        if (iter >= 1) {
+            // the length after the round BEFORE this one: its copy finished before this round's kernels began
+            AOB_HIP(hipEventSynchronize(b->ev_ploc[(iter - 1) & 1]));
+            known = host[(iter - 1) & 1][0];
+        }
+        cur ^= 1; iter++;
+        if (iter > 4096) { set_error("PLOC does not converge"); return AOB_ERR_DEVICE; }
     }
-    if (m > 1) hipLaunchKernelGGL(k_ploc_tail, dim3(1), dim3(kBlock), 0, s, cl[cur], m, created, n, iter, kPlocRadius,
-                                  b->child_left, b->child_right, b->parent, b->node_bounds, b->node_height, b->depth_dev);
+    if (iter >= 1) {
+        AOB_HIP(hipEventSynchronize(b->ev_ploc[(iter - 1) & 1]));
+        if (host[(iter - 1) & 1][2]) { set_error("PLOC made no progress"); return AOB_ERR_DEVICE; }
+    }
+    // the list now holds at most one tile (the last round launched may have run on less): the rest in one launch
+    hipLaunchKernelGGL(k_ploc_tail, dim3(1), dim3(kBlock), 0, s, cl[cur], state[iter & 1], n, iter, kPlocRadius,
+                       b->child_left, b->child_right, b->parent, b->node_bounds, b->node_height, b->depth_dev);
     hipLaunchKernelGGL(k_set_root_parent, dim3(1), dim3(64), 0, s, b->parent);
     return AOB_OK;
 }
