@@ -461,6 +461,26 @@ def test_fine_units_at_the_end_of_the_queues(engine, orc, mode, spp):
     assert np.array_equal(got["total_bits"], want["total_bits"]) and np.array_equal(got["weight_bits"], want["weight_bits"])
 
 
+@pytest.mark.parametrize("mode", [0, 2, 4])
+def test_tuning_hooks_change_the_schedule_not_the_result(engine, orc, mode, monkeypatch):
+    """AOB_TRACE_* environment variables move work between wavefronts; the result cells stay bit-identical."""
+    flat = FlatScene(scenes.terrain_scene(grid=40, atlas=(128, 72)))
+    opt = make_options(orc, sample_count=160, **MODES[mode])
+    with Baker(flat, opt) as b:
+        b.build_bvh(); b.rasterize(0); b.trace(0)
+        want = b.results(0).copy()
+        for env in ({"AOB_TRACE_PARTS": "1"}, {"AOB_TRACE_PARTS": "8", "AOB_TRACE_PART_MIN": "4"}, {"AOB_TRACE_FINE_DIV": "2"},
+                    {"AOB_TRACE_FINE_DIV": "1000000"}, {"AOB_TRACE_REFILL_IDLE": "1", "AOB_TRACE_LEAF_WAIT": "1"},
+                    {"AOB_TRACE_REFILL_IDLE": "64", "AOB_TRACE_LEAF_WAIT": "64"}, {"AOB_TRACE_BANDS": "0"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            b.clear_results(0); b.trace(0)
+            got = b.results(0)
+            assert np.array_equal(got["total_bits"], want["total_bits"]) and np.array_equal(got["weight_bits"], want["weight_bits"]), env
+            for k in env:
+                monkeypatch.delenv(k)
+
+
 def test_invalid_arguments_are_reported(engine, orc):
     flat = FlatScene(scenes.plane_scene(8))
     opt = make_options(orc, sample_count=0)
