@@ -46,6 +46,7 @@ struct DeviceMaterial {
     int32_t width = 0, height = 0, channels = 0, bytes_per_channel = 0;
     float ao_max_range = 0.0f;            // AobMaterialDesc::ao_max_range
     int32_t window_rows = 0;              // texel rows the last rasterisation covered (height, or a strip of it)
+    int32_t window_row0 = 0;              // ... and the first of them
     uint8_t* host_data = nullptr;
     uint32_t* cover = nullptr;            // W*H: winning triangle index + 1, per section pass
     uint32_t* prev_layer = nullptr;       // W*H, AOB_LAYERS_ALL only: triangle index + 1 of the texel's fragment in the layer before

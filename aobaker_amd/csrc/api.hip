@@ -617,7 +617,9 @@ int aob_bake_shard_bounds(AobBake* b, int32_t material, uint32_t parts, uint64_t
     const uint64_t n = m.surfel_count, cells = (uint64_t)m.width * m.height;
     const bool single = m.section_offsets.size() == 2;
     if (overlapping) *overlapping = single ? 0 : 1;
-    const uint32_t tiles_y = (uint32_t)(m.height + 7) / 8;
+    // tile rows of the strip the last rasterisation covered (the whole atlas by default)
+    const uint32_t tiles_y = (uint32_t)(m.window_rows + 7) / 8;
+    const uint64_t row0 = (uint64_t)m.window_row0, row_end = (uint64_t)m.window_row0 + (uint64_t)m.window_rows;
     std::vector<uint32_t> row_of(parts + 1, 0);
     bounds[0] = 0; bounds[parts] = n; row_of[parts] = tiles_y;
     for (uint32_t r = 1; r < parts; r++) {
@@ -636,7 +638,7 @@ int aob_bake_shard_bounds(AobBake* b, int32_t material, uint32_t parts, uint64_t
     for (uint32_t r = 0; r < parts; r++) {
         uint64_t c0 = 1, c1 = 0;                      // empty: first > last
         if (bounds[r + 1] > bounds[r]) {
-            if (single) { c0 = (uint64_t)row_of[r] * 8u * m.width; c1 = std::min<uint64_t>((uint64_t)row_of[r + 1] * 8u, (uint64_t)m.height) * m.width - 1; }
+            if (single) { c0 = (row0 + (uint64_t)row_of[r] * 8u) * m.width; c1 = std::min<uint64_t>(row0 + (uint64_t)row_of[r + 1] * 8u, row_end) * m.width - 1; }
             else { c0 = 0; c1 = cells - 1; }
         }
         if (first_cell) first_cell[r] = c0;

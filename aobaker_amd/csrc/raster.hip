@@ -246,7 +246,7 @@ __global__ __launch_bounds__(kBlock)
 void k_emit_surfels(uint32_t* __restrict__ cover, uint64_t cells, const uint32_t* __restrict__ block_offsets,
                     const float* __restrict__ positions, const float* __restrict__ normals,
                     const float* __restrict__ uvs, const uint32_t* __restrict__ indices,
-                    MeshXform xf, int32_t W, int32_t H, int fp16_mode,
+                    MeshXform xf, int32_t W, int32_t H, int32_t row0, int fp16_mode,
                     AobSurfel* __restrict__ surfels, uint32_t* __restrict__ section_index, uint32_t* __restrict__ prev)
 {
     // the block's 2048 texels in eight stripes of 256: consecutive lanes take consecutive texels, so the 40-byte records of a
@@ -261,7 +261,7 @@ void k_emit_surfels(uint32_t* __restrict__ cover, uint64_t cells, const uint32_t
         offset += total;
         if (!cv) continue;
         const uint32_t t = PEEL ? 0xffffffffu - cv : (cv & ~kCentreBit) - 1;
-        const int32_t py = (int32_t)(cell / (uint64_t)W), px = (int32_t)(cell % (uint64_t)W);
+        const int32_t py = row0 + (int32_t)(cell / (uint64_t)W), px = (int32_t)(cell % (uint64_t)W);    // `cover` starts at texel row row0
         RasterVertex rv[3];
         int64_t X[3], Y[3];
 #pragma unroll
@@ -432,25 +432,31 @@ static int ensure_surfel_capacity(AobBake* b, DeviceMaterial& m, uint64_t need)
 int rasterize_material(AobBake* b, int32_t material, int32_t row_begin, int32_t row_end)
 {
     DeviceMaterial& m = b->materials[material];
-    m.window_rows = row_end - row_begin;
+    m.window_rows = row_end - row_begin; m.window_row0 = row_begin;
     hipStream_t s = b->stream;
     const uint64_t cells = (uint64_t)m.width * m.height;
     m.surfel_count = 0;
     m.section_offsets.clear(); m.section_mesh.clear();
     m.section_offsets.push_back(0);
     AOB_HIP(hipMemsetAsync(m.results, 0, sizeof(AobResult) * cells, s));
-    const uint32_t nblocks = m.scan_blocks;
+    // Everything after the coverage pass works on the strip of texel rows alone: the strip starts on a tile row, so it is an
+    // atlas of its own — W x window_rows texels at cover + row_begin * W — and a rank of the N-GPU run does not walk the
+    // other ranks' rows.
+    const int32_t hw = row_end - row_begin;
+    const uint64_t cell0 = (uint64_t)row_begin * m.width, cells_w = (uint64_t)hw * m.width;
+    uint32_t* const cover_w = m.cover + cell0;
+    const uint32_t nblocks = max(1u, (uint32_t)((cells_w + kScanTile - 1) / kScanTile));     // (an empty strip still runs the scans, on nothing)
     const bool conservative = b->opt.raster_mode == AOB_RASTER_CONSERVATIVE;
     const bool peel = b->opt.raster_layers == AOB_LAYERS_ALL;
     if (peel && !m.prev_layer) AOB_HIP(hipMalloc((void**)&m.prev_layer, sizeof(uint32_t) * cells));
     for (size_t mi = 0; mi < b->meshes.size(); mi++) {
         const DeviceMesh& mesh = b->meshes[mi];
         if (mesh.material != material) continue;                       // BakeEngine.cpp:523
-        if (peel) AOB_HIP(hipMemsetAsync(m.prev_layer, 0, sizeof(uint32_t) * cells, s));
+        if (peel) AOB_HIP(hipMemsetAsync(m.prev_layer + cell0, 0, sizeof(uint32_t) * cells_w, s));
         // one pass per section — or, AOB_LAYERS_ALL, one per layer of the section's stencil peel (BakeEngine.cpp:531-532),
         // each layer a section of its own from here on
         for (int layer = 0; layer < (peel ? 255 : 1); layer++) {
-        AOB_HIP(hipMemsetAsync(m.cover, 0, sizeof(uint32_t) * cells, s));
+        AOB_HIP(hipMemsetAsync(cover_w, 0, sizeof(uint32_t) * cells_w, s));
         if (mesh.triangle_count) {
             uint32_t grid = (mesh.triangle_count + kBlock - 1) / kBlock;
             if (peel)
@@ -463,7 +469,7 @@ int rasterize_material(AobBake* b, int32_t material, int32_t row_begin, int32_t 
                 hipLaunchKernelGGL((k_cover<false, false>), dim3(grid), dim3(kBlock), 0, s, mesh.uvs, mesh.indices, mesh.triangle_count,
                                    m.width, m.height, row_begin, row_end, m.cover, (const uint32_t*)nullptr);
         }
-        hipLaunchKernelGGL(k_scan_count, dim3(nblocks), dim3(kBlock), 0, s, m.cover, cells, m.block_sums);
+        hipLaunchKernelGGL(k_scan_count, dim3(nblocks), dim3(kBlock), 0, s, cover_w, cells_w, m.block_sums);
         hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(kBlock), 0, s, m.block_sums, nblocks);
         // the section's surfel count decides the launch geometry of everything downstream
         AOB_HIP(hipMemcpyAsync(b->pinned, m.block_sums + nblocks, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -475,27 +481,27 @@ int rasterize_material(AobBake* b, int32_t material, int32_t row_begin, int32_t 
             MeshXform xf;
             for (int k = 0; k < 16; k++) xf.m[k] = mesh.model[k];
             if (peel)
-                hipLaunchKernelGGL((k_emit_surfels<false, true>), dim3(nblocks), dim3(kBlock), 0, s, m.cover, cells, m.block_sums,
-                                   mesh.positions, mesh.normals, mesh.uvs, mesh.indices, xf, m.width, m.height,
-                                   b->opt.normal_fp16, m.surfels + m.surfel_count, m.section_index + m.surfel_count, m.prev_layer);
+                hipLaunchKernelGGL((k_emit_surfels<false, true>), dim3(nblocks), dim3(kBlock), 0, s, cover_w, cells_w, m.block_sums,
+                                   mesh.positions, mesh.normals, mesh.uvs, mesh.indices, xf, m.width, m.height, row_begin,
+                                   b->opt.normal_fp16, m.surfels + m.surfel_count, m.section_index + m.surfel_count, m.prev_layer + cell0);
             else if (conservative)
-                hipLaunchKernelGGL((k_emit_surfels<true, false>), dim3(nblocks), dim3(kBlock), 0, s, m.cover, cells, m.block_sums,
-                                   mesh.positions, mesh.normals, mesh.uvs, mesh.indices, xf, m.width, m.height,
+                hipLaunchKernelGGL((k_emit_surfels<true, false>), dim3(nblocks), dim3(kBlock), 0, s, cover_w, cells_w, m.block_sums,
+                                   mesh.positions, mesh.normals, mesh.uvs, mesh.indices, xf, m.width, m.height, row_begin,
                                    b->opt.normal_fp16, m.surfels + m.surfel_count, m.section_index + m.surfel_count, (uint32_t*)nullptr);
             else
-                hipLaunchKernelGGL((k_emit_surfels<false, false>), dim3(nblocks), dim3(kBlock), 0, s, m.cover, cells, m.block_sums,
-                                   mesh.positions, mesh.normals, mesh.uvs, mesh.indices, xf, m.width, m.height,
+                hipLaunchKernelGGL((k_emit_surfels<false, false>), dim3(nblocks), dim3(kBlock), 0, s, cover_w, cells_w, m.block_sums,
+                                   mesh.positions, mesh.normals, mesh.uvs, mesh.indices, xf, m.width, m.height, row_begin,
                                    b->opt.normal_fp16, m.surfels + m.surfel_count, m.section_index + m.surfel_count, (uint32_t*)nullptr);
             // trace order: 8x8 tiles (perm), then the per-surfel trace records in that order
-            const uint32_t tiles_x = (uint32_t)(m.width + 7) / 8, tiles_y = (uint32_t)(m.height + 7) / 8;
+            const uint32_t tiles_x = (uint32_t)(m.width + 7) / 8, tiles_y = (uint32_t)(hw + 7) / 8;      // of the strip
             const uint64_t total_e = (uint64_t)tiles_x * tiles_y * 64u;
             const uint32_t tblocks = (uint32_t)((total_e + kScanTile - 1) / kScanTile);
-            hipLaunchKernelGGL(k_tile_count, dim3(tblocks), dim3(kBlock), 0, s, m.cover, m.width, m.height, tiles_x, total_e, m.tile_sums);
+            hipLaunchKernelGGL(k_tile_count, dim3(tblocks), dim3(kBlock), 0, s, cover_w, m.width, hw, tiles_x, total_e, m.tile_sums);
             hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(kBlock), 0, s, m.tile_sums, tblocks);
-            hipLaunchKernelGGL(k_tile_emit, dim3(tblocks), dim3(kBlock), 0, s, m.cover, m.width, m.height, tiles_x, total_e, m.tile_sums,
+            hipLaunchKernelGGL(k_tile_emit, dim3(tblocks), dim3(kBlock), 0, s, cover_w, m.width, hw, tiles_x, total_e, m.tile_sums,
                                m.perm + m.surfel_count);
             if (m.section_offsets.size() == 1) {
-                hipLaunchKernelGGL(k_tile_row_prefix, dim3((tiles_y + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, m.cover, m.width, m.height,
+                hipLaunchKernelGGL(k_tile_row_prefix, dim3((tiles_y + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, cover_w, m.width, hw,
                                    tiles_x, tiles_y, m.tile_sums, (uint32_t)count, m.tile_row_prefix);
                 AOB_HIP(hipMemcpyAsync(m.tile_row_prefix_host, m.tile_row_prefix, sizeof(uint32_t) * (tiles_y + 1), hipMemcpyDeviceToHost, s));
             }

@@ -317,7 +317,8 @@ int aob_bake_copy_results(AobBake* bake, int32_t material, AobResult* dst, uint6
  * 8x8 texel tiles, tile rows top to bottom, so with a single section the boundaries are placed on
  * tile rows and part r owns the disjoint strip of result cells [first_cell[r], last_cell[r]] — the
  * "texel tiles" rank 0 gathers (first > last: empty part).  With several sections the strips of
- * different parts may overlap: *overlapping is set and the caller must sum-reduce instead. */
+ * different parts may overlap: *overlapping is set and the caller must sum-reduce instead.
+ * After aob_bake_rasterize_rows the list, the tile rows and the cells are those of that strip. */
 int aob_bake_shard_bounds(AobBake* bake, int32_t material, uint32_t parts, uint64_t* bounds,
                           uint64_t* first_cell, uint64_t* last_cell, int32_t* overlapping);
 /* Device address of the material's W*H AobResult buffer (for an RCCL
