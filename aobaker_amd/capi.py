@@ -12,7 +12,7 @@ import importlib.util
 import os
 import sys
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # ---- enums (include/aobaker.h) ------------------------------------------------
 AOB_OK = 0
@@ -57,6 +57,12 @@ class AobOptions(C.Structure):
         ("morton_adaptive", C.c_int32),
         ("raster_mode", C.c_int32),
         ("raster_layers", C.c_int32),
+        ("trace_refill_idle", C.c_int32),
+        ("trace_leaf_wait", C.c_int32),
+        ("trace_parts", C.c_int32),
+        ("trace_part_min", C.c_int32),
+        ("trace_fine_div", C.c_int32),
+        ("trace_bands", C.c_int32),
     ]
 
 

@@ -59,6 +59,7 @@ struct DeviceMaterial {
     uint32_t* tile_sums = nullptr;        // scan partials of the tile-order pass
     uint32_t* tile_row_prefix = nullptr;  // covered texels before each 8-texel tile row (first section)
     uint32_t* tile_row_prefix_host = nullptr;   // pinned copy
+    bool      tile_prefix_valid = false;        // ... filled by the last rasterisation (it is not when the first section is empty)
     uint64_t  surfel_capacity = 0, surfel_count = 0;
     std::vector<uint64_t> section_offsets; // prefix offsets per contributing mesh (+ total)
     std::vector<uint32_t> section_mesh;

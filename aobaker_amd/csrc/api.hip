@@ -15,8 +15,9 @@
 namespace aob {
 
 static thread_local char g_error[512] = "";
-static bool g_initialised = false;
-static int g_device = 0;
+// per host thread, like HIP's current device: a multi-GPU host runs one thread per device (aobaker_amd/host/MultiGpu.cpp)
+static thread_local bool g_initialised = false;
+static thread_local int g_device = 0;
 
 void set_error(const char* fmt, ...)
 {
@@ -62,6 +63,9 @@ static int validate_options(const AobOptions* o)
     if (o->material_ranges != 0 && o->material_ranges != 1) { set_error("material_ranges %d: must be 0 or 1", o->material_ranges); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->bvh_builder != 0 && o->bvh_builder != 1) { set_error("bvh_builder %d: must be 0 (LBVH) or 1 (PLOC)", o->bvh_builder); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->bvh_width != 0 && o->bvh_width != 2 && o->bvh_width != 4) { set_error("bvh_width %d: must be 0, 2 or 4", o->bvh_width); return AOB_ERR_INVALID_ARGUMENT; }
+    if (o->trace_refill_idle < 0 || o->trace_refill_idle > 64 || o->trace_leaf_wait < 0 || o->trace_leaf_wait > 64) { set_error("trace_refill_idle %d / trace_leaf_wait %d: must be 0 (default) or 1..64", o->trace_refill_idle, o->trace_leaf_wait); return AOB_ERR_INVALID_ARGUMENT; }
+    if (o->trace_parts < 0 || o->trace_parts > 64 || o->trace_part_min < 0 || o->trace_fine_div < 0) { set_error("trace_parts %d (0..64), trace_part_min %d, trace_fine_div %d: must not be negative", o->trace_parts, o->trace_part_min, o->trace_fine_div); return AOB_ERR_INVALID_ARGUMENT; }
+    if (o->trace_bands < 0 || o->trace_bands > 2) { set_error("trace_bands %d: must be 0 (default), 1 or 2", o->trace_bands); return AOB_ERR_INVALID_ARGUMENT; }
     if (!(o->falloff_distance > 0.0f)) { set_error("falloff_distance must be positive"); return AOB_ERR_INVALID_ARGUMENT; }
     return AOB_OK;
 }
@@ -159,6 +163,13 @@ void aob_default_options(AobOptions* o)
     o->morton_adaptive = 1;
     o->raster_mode = AOB_RASTER_REFERENCE;
     o->raster_layers = AOB_LAYERS_LAST;
+    // schedule of k_trace: the measured optima on BASELINE configs[2]
+    o->trace_refill_idle = 24;
+    o->trace_leaf_wait = 16;
+    o->trace_parts = 4;
+    o->trace_part_min = 16;
+    o->trace_fine_div = 8;
+    o->trace_bands = 1;
 }
 
 int aob_init(const AobDeviceConfig* config)
@@ -181,6 +192,7 @@ int aob_init(const AobDeviceConfig* config)
     return AOB_OK;
 }
 
+// aob_init acquires nothing (every stream, event and buffer belongs to an AobBake handle), so there is nothing to release
 void aob_shutdown(void) { g_initialised = false; }
 
 int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBake** out)
@@ -615,8 +627,14 @@ int aob_bake_shard_bounds(AobBake* b, int32_t material, uint32_t parts, uint64_t
     if (!m.rasterized) { set_error("material %d has not been rasterised", material); return AOB_ERR_INVALID_ARGUMENT; }
     AOB_HIP(hipStreamSynchronize(b->stream));
     const uint64_t n = m.surfel_count, cells = (uint64_t)m.width * m.height;
-    const bool single = m.section_offsets.size() == 2;
-    if (overlapping) *overlapping = single ? 0 : 1;
+    const bool single = m.section_offsets.size() == 2 && m.tile_prefix_valid;
+    if (overlapping) *overlapping = (single || n == 0) ? 0 : 1;
+    if (n == 0) {
+        // an empty strip (or a material nothing maps to): every part is empty, no cell range
+        for (uint32_t r = 0; r <= parts; r++) bounds[r] = 0;
+        for (uint32_t r = 0; r < parts; r++) { if (first_cell) first_cell[r] = 1; if (last_cell) last_cell[r] = 0; }
+        return AOB_OK;
+    }
     // tile rows of the strip the last rasterisation covered (the whole atlas by default)
     const uint32_t tiles_y = (uint32_t)(m.window_rows + 7) / 8;
     const uint64_t row0 = (uint64_t)m.window_row0, row_end = (uint64_t)m.window_row0 + (uint64_t)m.window_rows;

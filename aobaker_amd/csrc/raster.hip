@@ -411,10 +411,18 @@ static int ensure_surfel_capacity(AobBake* b, DeviceMaterial& m, uint64_t need)
     uint64_t cap = m.surfel_capacity ? m.surfel_capacity : (uint64_t)m.width * m.height;
     while (cap < need) cap *= 2;
     AobSurfel* ns = nullptr; uint32_t* ni = nullptr; float4* nf = nullptr; uint32_t* np = nullptr;
-    AOB_HIP(hipMalloc((void**)&ns, sizeof(AobSurfel) * cap));
-    AOB_HIP(hipMalloc((void**)&ni, sizeof(uint32_t) * cap));
-    AOB_HIP(hipMalloc((void**)&nf, sizeof(float4) * 4 * cap));
-    AOB_HIP(hipMalloc((void**)&np, sizeof(uint32_t) * cap));
+    {
+        // all four or none: a failed allocation must not leak the ones before it
+        hipError_t e = hipMalloc((void**)&ns, sizeof(AobSurfel) * cap);
+        if (e == hipSuccess) e = hipMalloc((void**)&ni, sizeof(uint32_t) * cap);
+        if (e == hipSuccess) e = hipMalloc((void**)&nf, sizeof(float4) * 4 * cap);
+        if (e == hipSuccess) e = hipMalloc((void**)&np, sizeof(uint32_t) * cap);
+        if (e != hipSuccess) {
+            hipFree(ns); hipFree(ni); hipFree(nf); hipFree(np);
+            set_error("growing the surfel buffers to %llu entries failed: %s", (unsigned long long)cap, hipGetErrorString(e));
+            return e == hipErrorOutOfMemory ? AOB_ERR_OUT_OF_MEMORY : AOB_ERR_DEVICE;
+        }
+    }
     if (m.surfel_count) {
         AOB_HIP(hipMemcpyAsync(ns, m.surfels, sizeof(AobSurfel) * m.surfel_count, hipMemcpyDeviceToDevice, b->stream));
         AOB_HIP(hipMemcpyAsync(ni, m.section_index, sizeof(uint32_t) * m.surfel_count, hipMemcpyDeviceToDevice, b->stream));
@@ -438,6 +446,7 @@ int rasterize_material(AobBake* b, int32_t material, int32_t row_begin, int32_t 
     m.surfel_count = 0;
     m.section_offsets.clear(); m.section_mesh.clear();
     m.section_offsets.push_back(0);
+    m.tile_prefix_valid = false;          // tile_row_prefix_host is written by the first section that has surfels
     AOB_HIP(hipMemsetAsync(m.results, 0, sizeof(AobResult) * cells, s));
     // Everything after the coverage pass works on the strip of texel rows alone: the strip starts on a tile row, so it is an
     // atlas of its own — W x window_rows texels at cover + row_begin * W — and a rank of the N-GPU run does not walk the
@@ -504,6 +513,7 @@ int rasterize_material(AobBake* b, int32_t material, int32_t row_begin, int32_t 
                 hipLaunchKernelGGL(k_tile_row_prefix, dim3((tiles_y + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, cover_w, m.width, hw,
                                    tiles_x, tiles_y, m.tile_sums, (uint32_t)count, m.tile_row_prefix);
                 AOB_HIP(hipMemcpyAsync(m.tile_row_prefix_host, m.tile_row_prefix, sizeof(uint32_t) * (tiles_y + 1), hipMemcpyDeviceToHost, s));
+                m.tile_prefix_valid = true;
             }
             hipLaunchKernelGGL(k_surfel_frames, dim3((uint32_t)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
                                m.surfels + m.surfel_count, m.section_index + m.surfel_count, m.perm + m.surfel_count, count, m.width, m.height,

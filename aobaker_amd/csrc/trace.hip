@@ -34,7 +34,6 @@
 #include "aob_internal.h"
 #include "aob_math.h"
 
-#include <cstdlib>
 #include <type_traits>
 
 namespace aob {
@@ -546,11 +545,8 @@ uint64_t chunk_texel_max(const AobOptions& opt)
     return c;
 }
 
-static int env_int(const char* name, int fallback)
-{
-    const char* v = getenv(name);
-    return v && *v ? atoi(v) : fallback;
-}
+// a schedule field of AobOptions: 0 means the default aob_default_options writes
+static int knob(int32_t value, int fallback) { return value > 0 ? value : fallback; }
 
 int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
 {
@@ -592,8 +588,8 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
         p.inv_tmax = 1.0f / p.tmax;
         p.bias = o.ray_bias;
         p.hidden_from_others = b->hidden_from_others;
-        p.refill_idle = max(1, env_int("AOB_TRACE_REFILL_IDLE", 24));
-        p.leaf_wait = max(1, env_int("AOB_TRACE_LEAF_WAIT", 16));
+        p.refill_idle = knob(o.trace_refill_idle, 24);
+        p.leaf_wait = knob(o.trace_leaf_wait, 16);
         cosine_grid(o.sample_count, p.grid);
         // one launch per section: two sections of a material may cover the same texel, and
         // their contributions are added in section order (BakeEngine.cpp:473,659)
@@ -607,12 +603,12 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
             // CUs about that long; four parts per tile shorten both fourfold (a part is at least 16 samples: fewer cost more in
             // prologues and result atomics than they balance).  Only where adding the parts is exact.
             const bool split_exact = o.accumulate == AOB_ACCUMULATE_QUANTISED || (o.sampler == AOB_SAMPLER_COSINE && o.use_any_hit);
-            p.parts = split_exact ? (uint32_t)max(1, min(env_int("AOB_TRACE_PARTS", 4), o.sample_count / max(1, env_int("AOB_TRACE_PART_MIN", 16)))) : 1u;
+            p.parts = split_exact ? (uint32_t)max(1, min(knob(o.trace_parts, 4), o.sample_count / knob(o.trace_part_min, 16))) : 1u;
             // chunks: bands of 8 tile rows when every texel of the rasterised rows has exactly one surfel (then the trace
             // order is the plain tile grid), else 2048 tiles
             p.band_row = 0;
             if (m.section_offsets.size() == 2 && m.surfel_count == (uint64_t)m.width * m.window_rows && m.width % 64 == 0 &&
-                sb % ((uint64_t)m.width * 8u) == 0 && env_int("AOB_TRACE_BANDS", 1))
+                sb % ((uint64_t)m.width * 8u) == 0 && o.trace_bands != 2)
                 p.band_row = (uint32_t)m.width / 8u;
             p.chunk = p.band_row ? p.band_row * 8u : 2048u;
             const uint32_t groups = p.ntiles / (p.chunk * 8u);
@@ -623,7 +619,7 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
             // when the slowest wavefront finishes its last unit
             const uint32_t queue_tiles = p.xcd_chunk_tiles + p.rest_per_xcd;
             p.parts_fine = p.parts * 2u;
-            const uint32_t fine_tiles = (p.parts > 1u && (uint32_t)o.sample_count / p.parts_fine >= 16u) ? queue_tiles / (uint32_t)max(1, env_int("AOB_TRACE_FINE_DIV", 8)) : 0u;
+            const uint32_t fine_tiles = (p.parts > 1u && (uint32_t)o.sample_count / p.parts_fine >= 16u) ? queue_tiles / (uint32_t)knob(o.trace_fine_div, 8) : 0u;
             p.coarse_tiles = queue_tiles - fine_tiles;
             p.coarse_units = p.coarse_tiles * p.parts;
             p.units_per_xcd = p.coarse_units + fine_tiles * p.parts_fine;

@@ -6,7 +6,10 @@
 // is called on it (:734).  Everything in between runs in the HIP library.
 #include "../../include/BakeEngine.h"
 #include "../../include/aobaker.h"
+#include "../../include/aobaker_multi.h"
 #include "../../include/aobaker_scene.h"
+
+#include <hip/hip_runtime_api.h>
 
 #include <cstdio>
 #include <cstring>
@@ -17,6 +20,7 @@ AobOptions g_options;
 bool g_have_options = false;
 AobStats g_stats;
 int g_status = AOB_OK;
+int g_device_count = 1;
 
 void flatten(Scene* scene, std::vector<AobMeshDesc>& meshes, std::vector<AobMaterialDesc>& materials)
 {
@@ -64,6 +68,11 @@ void flatten(Scene* scene, std::vector<AobMeshDesc>& meshes, std::vector<AobMate
 }
 }
 
+void BakeEngine::Flatten(Scene* scene, std::vector<AobMeshDesc>& meshes, std::vector<AobMaterialDesc>& materials)
+{
+	flatten(scene, meshes, materials);
+}
+
 AobOptions& BakeEngine::Options()
 {
 	if (!g_have_options) { aob_default_options(&g_options); g_have_options = true; }
@@ -85,12 +94,47 @@ void BakeEngine::Dispose()
 	aob_shutdown();
 }
 
+void BakeEngine::SetDeviceCount(int count)
+{
+	if (count <= 0)
+	{
+		count = 1;
+		if (hipGetDeviceCount(&count) != hipSuccess || count < 1) count = 1;
+	}
+	g_device_count = count;
+}
+
+int BakeEngine::DeviceCount() { return g_device_count; }
+
+// Bake(Scene*) over g_device_count GPUs: upload to every device, one step, device 0 downloads (aobaker_multi.h)
+static int bake_multi(const AobSceneDesc& desc)
+{
+	std::vector<int> devices;
+	for (int i = 0; i < g_device_count; i++) devices.push_back(i);
+	AobMultiGpuBake* multi = AobMultiGpuBake::Create(&desc, &BakeEngine::Options(), devices, false);
+	if (!multi) { std::fprintf(stderr, "BakeEngine::Bake: %s\n", AobMultiGpuBake::LastError()); return AOB_ERR_DEVICE; }
+	int status = multi->Step(nullptr);
+	if (status == AOB_OK) status = multi->Download();
+	if (status == AOB_OK) status = multi->GetStats(&g_stats);
+	if (status != AOB_OK) std::fprintf(stderr, "BakeEngine::Bake: %s\n", AobMultiGpuBake::LastError());
+	delete multi;
+	return status;
+}
+
 void BakeEngine::Bake(Scene* scene)
 {
 	std::vector<AobMeshDesc> meshes;
 	std::vector<AobMaterialDesc> materials;
 	flatten(scene, meshes, materials);
 	AobSceneDesc desc = { meshes.data(), (uint32_t)meshes.size(), materials.data(), (uint32_t)materials.size() };
+	if (g_device_count > 1)
+	{
+		g_status = bake_multi(desc);
+		if (g_status != AOB_OK) return;
+		for (int i = 0; i < scene->GetMaterialCount(); i++)
+			scene->GetMaterial(i)->GetAOTexture()->RefreshPreview();
+		return;
+	}
 	g_status = aob_bake(&desc, &Options(), &g_stats);
 	if (g_status != AOB_OK) { std::fprintf(stderr, "BakeEngine::Bake: %s\n", aob_last_error()); return; }
 	for (int i = 0; i < scene->GetMaterialCount(); i++)

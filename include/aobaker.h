@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AOB_ABI_VERSION 2
+#define AOB_ABI_VERSION 3
 
 typedef enum AobStatus {
     AOB_OK = 0,
@@ -104,6 +104,16 @@ typedef struct AobOptions {
                                      node visits per ray on the 1 M-triangle terrain                                  */
     int32_t  raster_mode;         /* AOB_RASTER_*; default REFERENCE                                  */
     int32_t  raster_layers;       /* AOB_LAYERS_*; default LAST                                       */
+    /* Schedule of the fused trace kernel (trace.hip).  These six move work between wavefronts and never change a result
+     * cell (tests/test_gpu_parity.py::test_trace_schedule_knobs_do_not_change_results).  aob_default_options writes the
+     * values measured fastest on MI355X for BASELINE configs[2]; 0 in any of them also means "that default". */
+    int32_t  trace_refill_idle;   /* lanes of a wavefront without a ray that trigger the refill section: 1..64, default 24 */
+    int32_t  trace_leaf_wait;     /* lanes parked at a leaf that trigger the leaf section: 1..64, default 16               */
+    int32_t  trace_parts;         /* sample parts a tile's rays are cut into (units of one work queue), default 4          */
+    int32_t  trace_part_min;      /* a part holds at least this many samples, default 16                                   */
+    int32_t  trace_fine_div;      /* the last 1/trace_fine_div of every queue is cut into half-length units, default 8     */
+    int32_t  trace_bands;         /* 1 (default): on a fully covered atlas, 8x8-tile blocks inside bands of 8 tile rows;
+                                     2: plain chunks of 2048 tiles                                                          */
 } AobOptions;
 
 /* ---- scene description ----------------------------------------------------
@@ -238,10 +248,13 @@ typedef struct AobResult { uint32_t total_bits, weight_bits; } AobResult;
 
 /* ---- one-shot API --------------------------------------------------------- */
 
-/* Replaces BakeEngine::Init (BakeEngine.cpp:118-213): selects the device and
- * creates the stream + persistent workspaces. */
+/* Replaces BakeEngine::Init (BakeEngine.cpp:118-213): checks that the device is a gfx950 and makes it the device every
+ * later aob_bake_create of the calling THREAD allocates on (one host thread per GPU: each thread calls aob_init with
+ * its own device).  It acquires nothing: streams, events and buffers belong to the AobBake handles (the reference's
+ * Init allocates ~3 GB of fixed buffers here, BakeEngine.cpp:163-212; this library sizes them per scene). */
 int aob_init(const AobDeviceConfig* config);
-/* Replaces BakeEngine::Dispose (BakeEngine.cpp:215-279). */
+/* Replaces BakeEngine::Dispose (BakeEngine.cpp:215-279).  Since aob_init acquires nothing there is nothing to release
+ * beyond the calling thread's device selection; handles still alive stay valid until aob_bake_destroy. */
 void aob_shutdown(void);
 /* Fills `out` with the reference's constants (BakeEngine.cpp:13-18). */
 void aob_default_options(AobOptions* out);

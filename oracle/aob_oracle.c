@@ -1195,9 +1195,10 @@ typedef struct {
 
 /* intersect_bvh2_lds.cl:65-226 (closest) / :228-363 (any hit): near child first,
  * deferred child on a stack, leaf = inlined triangle. Returns hit flag, *t_out. */
-static inline int traverse(const AobBvhNode* nodes, uint64_t node_count, f3 o, f3 d, float t_max,
-                           int any_hit, float* t_out, OrcTraceStats* st, int* error, const OrcMask* mask)
+static inline int traverse_addr(const AobBvhNode* nodes, uint64_t node_count, f3 o, f3 d, float t_max,
+                                int any_hit, float* t_out, OrcTraceStats* st, int* error, const OrcMask* mask, uint32_t* addr_out)
 {
+    if (addr_out) *addr_out = AOB_INVALID_ADDR;
     if (node_count == 0) { *t_out = t_max; return 0; }
     f3 invdir = safe_invdir(d);
     f3 oxinvdir = f3_make(-o.x * invdir.x, -o.y * invdir.y, -o.z * invdir.z);
@@ -1236,6 +1237,7 @@ static inline int traverse(const AobBvhNode* nodes, uint64_t node_count, f3 o, f
             if (mask && mask_skips(mask, n->shape_id)) t = closest_t;
             if (t < closest_t) {
                 closest_t = t; hit = 1;
+                if (addr_out) *addr_out = addr;          /* closest_addr, intersect_bvh2_lds.cl:176 */
                 if (any_hit) break;
             }
         }
@@ -1243,6 +1245,12 @@ static inline int traverse(const AobBvhNode* nodes, uint64_t node_count, f3 o, f
     }
     *t_out = closest_t;
     return hit;
+}
+
+static inline int traverse(const AobBvhNode* nodes, uint64_t node_count, f3 o, f3 d, float t_max,
+                           int any_hit, float* t_out, OrcTraceStats* st, int* error, const OrcMask* mask)
+{
+    return traverse_addr(nodes, node_count, o, d, t_max, any_hit, t_out, st, error, mask, NULL);
 }
 
 /* FLOAT accumulation is order independent by construction: every sample's r*w and w are
@@ -1438,6 +1446,218 @@ int orc_trace_ex(const AobBvhNode* nodes, uint64_t node_count,
         stats->leaf_visits += job.stats.leaf_visits; stats->hits += job.stats.hits;
     }
     return job.error;
+}
+
+/* ------------------------------------------------------------------------ */
+/* the reference's own records: rays in, intersections out                   */
+
+/* The tangent frame of a surfel (GenerateRaysComputeShader.hlsl:34-41); 0 when the frame is not finite. */
+static inline int surfel_frame(const AobSurfel* s, f3* P, f3* N, f3* X, f3* Z)
+{
+    *P = f3_make(s->position[0], s->position[1], s->position[2]);
+    *N = f3_make(s->normal[0], s->normal[1], s->normal[2]);
+    *X = f3_make(1.0f, 0.0f, 0.0f); *Z = f3_make(0.0f, 0.0f, 1.0f);
+    if (N->y < 0.9999f && N->y > -0.9999f) {
+        *X = f3_normalize(f3_make(-N->z, 0.0f, N->x));
+        *Z = f3_normalize(f3_cross(*X, *N));
+    }
+    return f3_finite(*P) && f3_finite(*N) && f3_finite(*X) && f3_finite(*Z);
+}
+
+/* GenerateRaysComputeShader.hlsl:43-54: the 48-byte RadeonRays ray records of surfels [begin, end), sample_count
+ * records per surfel, exactly the rays orc_trace casts.  `mask` goes to extra.x (the reference writes 0, :51).  A
+ * surfel without a finite frame gets inactive records (extra.y = 0): the kernels skip them. */
+uint64_t orc_generate_rays(const AobSurfel* surfels, const uint32_t* section_index, uint64_t begin, uint64_t end,
+                           const AobOptions* opt, const float* hemisphere, int32_t width, float t_max, int32_t mask,
+                           OrcRay* out)
+{
+    const int32_t spp = opt->sample_count;
+    const int compat = opt->sampler == AOB_SAMPLER_REFERENCE_COMPAT;
+    if (compat && !hemisphere && end > begin) return 0;
+    CosineGrid grid;
+    cosine_grid(spp, &grid.sx, &grid.sy);
+    grid.inv_sx = 1.0f / (float)grid.sx; grid.inv_sy = 1.0f / (float)grid.sy;
+    const uint64_t chunk_max = chunk_texel_max(opt);
+    uint64_t n = 0;
+    for (uint64_t k = begin; k < end; k++) {
+        const AobSurfel* s = &surfels[k];
+        f3 P, N, X, Z;
+        const int ok = surfel_frame(s, &P, &N, &X, &Z);
+        const uint32_t texel = (uint32_t)s->texel_y * (uint32_t)width + (uint32_t)s->texel_x;
+        const uint32_t base = pcg_hash(texel + pcg_hash(opt->seed));
+        const uint64_t local = section_index ? section_index[k] : k;
+        const float* table = compat ? hemisphere + 3 * ((local % chunk_max) * (uint64_t)spp) : NULL;
+        for (int32_t i = 0; i < spp; i++, n++) {
+            OrcRay* r = &out[n];
+            memset(r, 0, sizeof *r);
+            if (!ok) continue;
+            f3 h = compat ? f3_make(table[3 * i], table[3 * i + 1], table[3 * i + 2]) : cosine_sample(base, i, &grid);
+            f3 dir = f3_make(fmaf(h.z, Z.x, fmaf(h.y, N.x, h.x * X.x)),
+                             fmaf(h.z, Z.y, fmaf(h.y, N.y, h.x * X.y)),
+                             fmaf(h.z, Z.z, fmaf(h.y, N.z, h.x * X.z)));                                   /* :46 */
+            r->o[0] = fmaf(dir.x, opt->ray_bias, P.x); r->o[1] = fmaf(dir.y, opt->ray_bias, P.y);
+            r->o[2] = fmaf(dir.z, opt->ray_bias, P.z); r->o[3] = t_max;                                    /* :47,49 */
+            r->d[0] = dir.x; r->d[1] = dir.y; r->d[2] = dir.z; r->d[3] = 0.0f;                             /* :50 */
+            r->extra[0] = mask; r->extra[1] = (int32_t)0xCDCDCDCDu;                                        /* :51 */
+        }
+    }
+    return n;
+}
+
+/* common.cl:249-277, USE_SAFE_MATH branch */
+static inline void triangle_barycentrics(f3 p, f3 v1, f3 v2, f3 v3, float* b1, float* b2)
+{
+    f3 e1 = f3_sub(v2, v1), e2 = f3_sub(v3, v1), e = f3_sub(p, v1);
+    float d00 = f3_dot(e1, e1), d01 = f3_dot(e1, e2), d11 = f3_dot(e2, e2), d20 = f3_dot(e, e1), d21 = f3_dot(e, e2);
+    float denom = fmaf(d00, d11, -(d01 * d01));
+    if (denom == 0.0f) { *b1 = 0.0f; *b2 = 0.0f; return; }
+    float invdenom = 1.0f / denom;
+    *b1 = fmaf(d11, d20, -(d01 * d21)) * invdenom;
+    *b2 = fmaf(d00, d21, -(d01 * d20)) * invdenom;
+}
+
+/* intersect_main (intersect_bvh2_lds.cl:65-226) over ray records: the 32-byte Intersection of every active ray
+ * (:201-223); inactive rays leave their record untouched.  use_mask: the RR_RAY_MASK build (:163-166) — a ray skips
+ * the triangles of the mesh whose id equals extra.x. */
+void orc_intersect_rays(const AobBvhNode* nodes, uint64_t node_count, const OrcRay* rays, uint64_t n, int32_t use_mask,
+                        OrcIntersection* hits)
+{
+    OrcTraceStats st; memset(&st, 0, sizeof st);
+    for (uint64_t i = 0; i < n; i++) {
+        const OrcRay* r = &rays[i];
+        if (r->extra[1] == 0) continue;                                  /* ray_is_active, :88 */
+        f3 o = f3_make(r->o[0], r->o[1], r->o[2]), d = f3_make(r->d[0], r->d[1], r->d[2]);
+        uint32_t flags_self = AOB_MESH_HIDDEN_FROM_SELF;
+        OrcMask m = { &flags_self, 1u, 1u };
+        float t; uint32_t addr; int error = 0;
+        int hit;
+        if (use_mask && r->extra[0] > 0) {
+            /* one hidden shape: present it to mask_skips as "shape extra.x hidden from itself" */
+            const uint32_t shape = (uint32_t)r->extra[0];
+            uint32_t* flags = (uint32_t*)calloc(shape, sizeof(uint32_t));
+            flags[shape - 1] = AOB_MESH_HIDDEN_FROM_SELF;
+            m.mesh_flags = flags; m.mesh_count = shape; m.self_shape = shape;
+            hit = traverse_addr(nodes, node_count, o, d, r->o[3], 0, &t, &st, &error, &m, &addr);
+            free(flags);
+        } else {
+            hit = traverse_addr(nodes, node_count, o, d, r->o[3], 0, &t, &st, &error, NULL, &addr);
+        }
+        OrcIntersection* h = &hits[i];
+        if (hit) {
+            const AobBvhNode* nd = &nodes[addr];
+            f3 p = f3_make(fmaf(t, d.x, o.x), fmaf(t, d.y, o.y), fmaf(t, d.z, o.z));        /* :207 o + t*d */
+            float b1, b2;
+            triangle_barycentrics(p, f3_make(nd->lmin_or_v0[0], nd->lmin_or_v0[1], nd->lmin_or_v0[2]),
+                                  f3_make(nd->lmax_or_v1[0], nd->lmax_or_v1[1], nd->lmax_or_v1[2]),
+                                  f3_make(nd->rmin_or_v2[0], nd->rmin_or_v2[1], nd->rmin_or_v2[2]), &b1, &b2);
+            h->prim_id = (int32_t)nd->prim_id; h->shape_id = (int32_t)nd->shape_id;
+            h->uvwt[0] = b1; h->uvwt[1] = b2; h->uvwt[2] = 0.0f; h->uvwt[3] = t;
+        } else {
+            h->prim_id = -1; h->shape_id = -1;                            /* MISS_MARKER, :221-222 */
+        }
+    }
+}
+
+/* occluded_main (intersect_bvh2_lds.cl:228-363): 1 (HIT_MARKER) or -1 (MISS_MARKER) per active ray. */
+void orc_occluded_rays(const AobBvhNode* nodes, uint64_t node_count, const OrcRay* rays, uint64_t n, int32_t* hits)
+{
+    OrcTraceStats st; memset(&st, 0, sizeof st);
+    for (uint64_t i = 0; i < n; i++) {
+        const OrcRay* r = &rays[i];
+        if (r->extra[1] == 0) continue;
+        float t; int error = 0;
+        int hit = traverse(nodes, node_count, f3_make(r->o[0], r->o[1], r->o[2]), f3_make(r->d[0], r->d[1], r->d[2]),
+                           r->o[3], 1, &t, &st, &error, NULL);
+        hits[i] = hit ? 1 : -1;
+    }
+}
+
+/* ProcessIntersectionsComputeShader.hlsl:52-92 over the reference's own records: scores the rays of surfels
+ * [begin, end) from their Intersection records (shape_id == -1: miss; t in uvwt.w) and accumulates into `results`
+ * exactly as orc_trace does — so cells made from the REFERENCE kernel's hits can be compared with the library's. */
+void orc_process_intersections(const AobSurfel* surfels, uint64_t begin, uint64_t end, const OrcRay* rays,
+                               const OrcIntersection* hits, const AobOptions* opt, float falloff,
+                               int32_t width, int32_t height, AobResult* results)
+{
+    const int32_t spp = opt->sample_count;
+    const int compat = opt->sampler == AOB_SAMPLER_REFERENCE_COMPAT;
+    const int any_hit = opt->use_any_hit != 0;
+    for (uint64_t k = begin; k < end; k++) {
+        const AobSurfel* s = &surfels[k];
+        if (s->texel_x < 0 || s->texel_y < 0 || s->texel_x >= width || s->texel_y >= height) continue;
+        AobResult* cell = &results[(size_t)s->texel_y * width + s->texel_x];
+        f3 N = f3_make(s->normal[0], s->normal[1], s->normal[2]);
+        int32_t qT = 0, qW = 0; int64_t xT = 0, xW = 0;
+        int any = 0;
+        for (int32_t i = 0; i < spp; i++) {
+            const uint64_t ri = (k - begin) * (uint64_t)spp + (uint64_t)i;
+            const OrcRay* r = &rays[ri];
+            if (r->extra[1] == 0) continue;
+            any = 1;
+            const int hit = hits[ri].shape_id != -1;
+            const float t = hits[ri].uvwt[3];
+            float w = compat ? f3_dot(N, f3_make(r->d[0], r->d[1], r->d[2])) : 1.0f;
+            float rr;
+            if (any_hit) rr = hit ? 0.0f : 1.0f;
+            else rr = (hit && t < falloff) ? t / falloff : 1.0f;
+            if (opt->accumulate == AOB_ACCUMULATE_QUANTISED) { qT += orc_ftoi(rr * w * 255.0f); qW += orc_ftoi(w * 255.0f); }
+            else { xT += f2fix(rr * w); xW += f2fix(w); }
+        }
+        if (!any) continue;
+        if (opt->accumulate == AOB_ACCUMULATE_QUANTISED) {
+            cell->total_bits = (uint32_t)((int32_t)cell->total_bits + qT);
+            cell->weight_bits = (uint32_t)((int32_t)cell->weight_bits + qW);
+        } else {
+            float a, b;
+            memcpy(&a, &cell->total_bits, 4); memcpy(&b, &cell->weight_bits, 4);
+            a += (float)xT * 2.3283064365386962890625e-10f; b += (float)xW * 2.3283064365386962890625e-10f;
+            memcpy(&cell->total_bits, &a, 4); memcpy(&cell->weight_bits, &b, 4);
+        }
+    }
+}
+
+/* The 63-bit Morton codes orc_bvh_build_ex sorts by (primitive order, before the sort) and the primitive and scene
+ * boxes they are made from — build_hlbvh.cl:101-125 makes the top 30 bits of the non-adaptive code. */
+void orc_morton_codes(const OrcTriangle* tris, uint64_t n, int adaptive, uint64_t* codes, float* prim_boxes8, float* scene_box8)
+{
+    Box scene;
+    for (int k = 0; k < 3; k++) { scene.pmin[k] = INFINITY; scene.pmax[k] = -INFINITY; }
+    Box* pb = (Box*)malloc(sizeof(Box) * (n ? n : 1));
+    for (uint64_t i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++) {
+            pb[i].pmin[k] = fminf(fminf(tris[i].v[0][k], tris[i].v[1][k]), tris[i].v[2][k]);
+            pb[i].pmax[k] = fmaxf(fmaxf(tris[i].v[0][k], tris[i].v[1][k]), tris[i].v[2][k]);
+            scene.pmin[k] = fminf(scene.pmin[k], pb[i].pmin[k]);
+            scene.pmax[k] = fmaxf(scene.pmax[k], pb[i].pmax[k]);
+        }
+    float ext[3];
+    for (int k = 0; k < 3; k++) ext[k] = scene.pmax[k] - scene.pmin[k];
+    for (uint64_t i = 0; i < n; i++) {
+        uint32_t q[3];
+        for (int k = 0; k < 3; k++) q[k] = morton_axis((pb[i].pmax[k] + pb[i].pmin[k]) * 0.5f, scene.pmin[k], ext[k]);
+        if (adaptive) {
+            float e[3] = { ext[0], ext[1], ext[2] };
+            int used[3] = { 0, 0, 0 };
+            uint64_t code = 0;
+            for (int bit = 0; bit < 63; bit++) {
+                int ax = -1; float best = -1.0f;
+                for (int k = 0; k < 3; k++) if (used[k] < 21 && e[k] > best) { best = e[k]; ax = k; }
+                code = code << 1 | ((q[ax] >> (20 - used[ax])) & 1u);
+                used[ax]++; e[ax] *= 0.5f;
+            }
+            codes[i] = code;
+        } else codes[i] = (expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]);
+        if (prim_boxes8) {       /* the reference's bbox record: float4 pmin, float4 pmax (common.cl:46-50) */
+            float* b = prim_boxes8 + 8 * i;
+            b[0] = pb[i].pmin[0]; b[1] = pb[i].pmin[1]; b[2] = pb[i].pmin[2]; b[3] = 0.0f;
+            b[4] = pb[i].pmax[0]; b[5] = pb[i].pmax[1]; b[6] = pb[i].pmax[2]; b[7] = 0.0f;
+        }
+    }
+    if (scene_box8) {
+        scene_box8[0] = scene.pmin[0]; scene_box8[1] = scene.pmin[1]; scene_box8[2] = scene.pmin[2]; scene_box8[3] = 0.0f;
+        scene_box8[4] = scene.pmax[0]; scene_box8[5] = scene.pmax[1]; scene_box8[6] = scene.pmax[2]; scene_box8[7] = 0.0f;
+    }
+    free(pb);
 }
 
 /* ------------------------------------------------------------------------ */

@@ -140,6 +140,31 @@ void orc_resolve(const AobResult* results, int32_t width, int32_t height, const 
  * scene->materials[i].data. */
 int orc_bake(const AobSceneDesc* scene, const AobOptions* opt, int32_t threads, OrcTraceStats* stats);
 
+/* ---- the reference's own records (for the tests that run the reference's OpenCL kernels, oracle/ref_kernels.mk) ---- */
+
+/* 48 B: RadeonRays/math/ray.h:103-107, kernels/CL/common.cl:53-60 */
+typedef struct OrcRay { float o[4]; float d[4]; int32_t extra[2]; int32_t backface_cull; int32_t padding; } OrcRay;
+/* 32 B: RadeonRays/radeon_rays.h:140-154, kernels/CL/common.cl:63-70 */
+typedef struct OrcIntersection { int32_t shape_id, prim_id, pad[2]; float uvwt[4]; } OrcIntersection;
+
+/* GenerateRaysComputeShader.hlsl:43-54: sample_count ray records per surfel of [begin, end) — the rays orc_trace casts.
+ * t_max goes to o.w, `mask` to extra.x (the reference writes 0); surfels without a finite tangent frame get inactive
+ * records (extra.y = 0).  Returns the record count. */
+uint64_t orc_generate_rays(const AobSurfel* surfels, const uint32_t* section_index, uint64_t begin, uint64_t end,
+                           const AobOptions* opt, const float* hemisphere, int32_t width, float t_max, int32_t mask,
+                           OrcRay* out);
+/* intersect_main (intersect_bvh2_lds.cl:65-226) / occluded_main (:228-363) over ray records, as the kernels write them. */
+void orc_intersect_rays(const AobBvhNode* nodes, uint64_t node_count, const OrcRay* rays, uint64_t n, int32_t use_mask,
+                        OrcIntersection* hits);
+void orc_occluded_rays(const AobBvhNode* nodes, uint64_t node_count, const OrcRay* rays, uint64_t n, int32_t* hits);
+/* ProcessIntersectionsComputeShader.hlsl:52-92 from Intersection records (accumulates into results like orc_trace). */
+void orc_process_intersections(const AobSurfel* surfels, uint64_t begin, uint64_t end, const OrcRay* rays,
+                               const OrcIntersection* hits, const AobOptions* opt, float falloff,
+                               int32_t width, int32_t height, AobResult* results);
+/* The Morton codes orc_bvh_build_ex sorts by, per primitive (unsorted), with the primitive boxes and the scene box in
+ * the reference's bbox record form (8 floats each; NULL: not wanted). */
+void orc_morton_codes(const OrcTriangle* tris, uint64_t n, int adaptive, uint64_t* codes, float* prim_boxes8, float* scene_box8);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,6 +68,11 @@ def load():
                                    P(OrcTraceStats)]),
         "orc_resolve": (None, [vp, i32, i32, P(capi.AobOptions), i32, i32, vp]),
         "orc_bake": (C.c_int, [P(capi.AobSceneDesc), P(capi.AobOptions), i32, P(OrcTraceStats)]),
+        "orc_generate_rays": (u64, [vp, vp, u64, u64, P(capi.AobOptions), vp, i32, f32, i32, vp]),
+        "orc_intersect_rays": (None, [vp, u64, vp, u64, i32, vp]),
+        "orc_occluded_rays": (None, [vp, u64, vp, u64, vp]),
+        "orc_process_intersections": (None, [vp, u64, u64, vp, vp, P(capi.AobOptions), f32, i32, i32, vp]),
+        "orc_morton_codes": (None, [vp, u64, C.c_int, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -285,6 +290,66 @@ def bake(desc, opt, threads=1):
     return stats
 
 
+# ---- the reference's own records (tests/refkernels.py runs the reference's OpenCL kernels on them) ----------------
+RAY = np.dtype([("o", "<f4", 4), ("d", "<f4", 4), ("extra", "<i4", 2), ("backface_cull", "<i4"), ("padding", "<i4")])   # 48 B
+INTERSECTION = np.dtype([("shape_id", "<i4"), ("prim_id", "<i4"), ("pad", "<i4", 2), ("uvwt", "<f4", 4)])               # 32 B
+
+
+def generate_rays(surfels, section_index, opt, width, hemisphere=None, t_max=None, mask=0, begin=0, end=None):
+    """GenerateRaysComputeShader.hlsl:43-54: sample_count 48-byte ray records per surfel, the rays orc_trace casts."""
+    if end is None:
+        end = len(surfels)
+    surfels = np.ascontiguousarray(surfels)
+    sidx = None if section_index is None else np.ascontiguousarray(section_index, dtype=np.uint32)
+    hemi = None if hemisphere is None else np.ascontiguousarray(hemisphere, dtype=np.float32)
+    out = np.zeros(max(1, (end - begin) * opt.sample_count), dtype=RAY)
+    n = load().orc_generate_rays(surfels.ctypes.data if len(surfels) else None,
+                                 None if sidx is None or not len(sidx) else sidx.ctypes.data, begin, end, C.byref(opt),
+                                 None if hemi is None else hemi.ctypes.data, width,
+                                 float(opt.ray_tmax if t_max is None else t_max), int(mask), out.ctypes.data)
+    return out[:n]
+
+
+def intersect_rays(nodes, rays, use_mask=False, fill=None):
+    """intersect_main (intersect_bvh2_lds.cl:65-226) on the CPU.  fill: initial content of the records (inactive rays
+    leave theirs untouched)."""
+    nodes, rays = np.ascontiguousarray(nodes), np.ascontiguousarray(rays)
+    hits = np.zeros(max(1, len(rays)), dtype=INTERSECTION) if fill is None else fill.copy()
+    load().orc_intersect_rays(nodes.ctypes.data if len(nodes) else None, len(nodes), rays.ctypes.data, len(rays),
+                              int(bool(use_mask)), hits.ctypes.data)
+    return hits[:len(rays)]
+
+
+def occluded_rays(nodes, rays, fill=None):
+    """occluded_main (intersect_bvh2_lds.cl:228-363) on the CPU: 1 / -1 per active ray."""
+    nodes, rays = np.ascontiguousarray(nodes), np.ascontiguousarray(rays)
+    hits = np.zeros(max(1, len(rays)), dtype=np.int32) if fill is None else fill.copy()
+    load().orc_occluded_rays(nodes.ctypes.data if len(nodes) else None, len(nodes), rays.ctypes.data, len(rays), hits.ctypes.data)
+    return hits[:len(rays)]
+
+
+def process_intersections(surfels, rays, hits, opt, width, height, falloff=None, results=None):
+    """ProcessIntersectionsComputeShader.hlsl:52-92 from Intersection records of all surfels' rays."""
+    surfels, rays, hits = np.ascontiguousarray(surfels), np.ascontiguousarray(rays), np.ascontiguousarray(hits)
+    if results is None:
+        results = np.zeros(width * height, dtype=capi.result_dtype())
+    load().orc_process_intersections(surfels.ctypes.data, 0, len(surfels), rays.ctypes.data, hits.ctypes.data, C.byref(opt),
+                                     float(opt.falloff_distance if falloff is None else falloff), width, height,
+                                     results.ctypes.data)
+    return results
+
+
+def morton_codes(tris, adaptive=0):
+    """(codes uint64 [n] in primitive order, primitive boxes [n, 8], scene box [8]) — boxes as the reference's bbox records."""
+    tris = np.ascontiguousarray(tris)
+    n = len(tris)
+    codes = np.zeros(max(1, n), dtype=np.uint64)
+    boxes = np.zeros((max(1, n), 8), dtype=np.float32)
+    scene = np.zeros(8, dtype=np.float32)
+    load().orc_morton_codes(tris.ctypes.data, n, int(adaptive), codes.ctypes.data, boxes.ctypes.data, scene.ctypes.data)
+    return codes[:n], boxes[:n], scene
+
+
 def default_options():
     """The reference's constants (BakeEngine.cpp:13-18), stated independently of the library."""
     o = capi.AobOptions()
@@ -304,4 +369,6 @@ def default_options():
     o.bvh_quantised = 1
     o.bvh_builder = 1
     o.morton_adaptive = 1
+    # the schedule of the library's trace kernel (no meaning for the oracle; stated so that the two defaults compare equal)
+    o.trace_refill_idle, o.trace_leaf_wait, o.trace_parts, o.trace_part_min, o.trace_fine_div, o.trace_bands = 24, 16, 4, 16, 8, 1
     return o

@@ -462,23 +462,23 @@ def test_fine_units_at_the_end_of_the_queues(engine, orc, mode, spp):
 
 
 @pytest.mark.parametrize("mode", [0, 2, 4])
-def test_tuning_hooks_change_the_schedule_not_the_result(engine, orc, mode, monkeypatch):
-    """AOB_TRACE_* environment variables move work between wavefronts; the result cells stay bit-identical."""
+def test_trace_schedule_knobs_do_not_change_results(engine, orc, mode):
+    """AobOptions::trace_* (DESIGN.md §3.1) move work between wavefronts; the result cells stay bit-identical."""
     flat = FlatScene(scenes.terrain_scene(grid=40, atlas=(128, 72)))
-    opt = make_options(orc, sample_count=160, **MODES[mode])
-    with Baker(flat, opt) as b:
-        b.build_bvh(); b.rasterize(0); b.trace(0)
-        want = b.results(0).copy()
-        for env in ({"AOB_TRACE_PARTS": "1"}, {"AOB_TRACE_PARTS": "8", "AOB_TRACE_PART_MIN": "4"}, {"AOB_TRACE_FINE_DIV": "2"},
-                    {"AOB_TRACE_FINE_DIV": "1000000"}, {"AOB_TRACE_REFILL_IDLE": "1", "AOB_TRACE_LEAF_WAIT": "1"},
-                    {"AOB_TRACE_REFILL_IDLE": "64", "AOB_TRACE_LEAF_WAIT": "64"}, {"AOB_TRACE_BANDS": "0"}):
-            for k, v in env.items():
-                monkeypatch.setenv(k, v)
-            b.clear_results(0); b.trace(0)
-            got = b.results(0)
-            assert np.array_equal(got["total_bits"], want["total_bits"]) and np.array_equal(got["weight_bits"], want["weight_bits"]), env
-            for k in env:
-                monkeypatch.delenv(k)
+
+    def cells(**knobs):
+        with Baker(flat, make_options(orc, sample_count=160, **MODES[mode], **knobs)) as b:
+            b.build_bvh(); b.rasterize(0); b.trace(0)
+            return b.results(0).copy()
+
+    want = cells()
+    for knobs in (dict(trace_parts=1), dict(trace_parts=8, trace_part_min=4), dict(trace_fine_div=2), dict(trace_fine_div=1000000),
+                  dict(trace_refill_idle=1, trace_leaf_wait=1), dict(trace_refill_idle=64, trace_leaf_wait=64), dict(trace_bands=2),
+                  dict(trace_refill_idle=0, trace_leaf_wait=0, trace_parts=0, trace_part_min=0, trace_fine_div=0, trace_bands=0)):
+        got = cells(**knobs)
+        assert np.array_equal(got["total_bits"], want["total_bits"]) and np.array_equal(got["weight_bits"], want["weight_bits"]), knobs
+    with pytest.raises(capi.AobError):
+        cells(trace_refill_idle=65)
 
 
 def test_invalid_arguments_are_reported(engine, orc):
@@ -577,7 +577,10 @@ def test_ploc_builder_end_to_end(engine, orc, name, mode):
         ref4, _ = orc.bvh4_build(nodes)
         assert bits(b.nodes4()).tobytes() == bits(ref4).tobytes()
     assert np.array_equal(got["total_bits"], ref["total_bits"]) and np.array_equal(got["weight_bits"], ref["weight_bits"])
-    # same image as the LBVH, fewer node visits
+    # same image as the LBVH.  Node visits: on these SMALL scenes (18 050 / 4 608 triangles) the two builders are level once
+    # both sort by the adaptive Morton order — PLOC 3 015 317 vs LBVH 3 002 547 inner visits on this terrain, +0.4 % —
+    # so the bound is "not worse by more than 2 %"; PLOC's 5 % advantage is a property of the 1 M-triangle
+    # tree and is asserted there (tests/test_gpu_fullsize.py::test_config3_ploc_visits_fewer_nodes_than_lbvh)
     opt0 = make_options(orc, sample_count=16, bvh_builder=0, **MODES[mode])
     nodes0, _ = orc.bvh_build(orc.scene_triangles(flat.desc), 0)
     ref0, st0 = orc.trace(nodes0, surfels, sidx, opt0, m.width, m.height, hemi, threads=8)
@@ -585,7 +588,7 @@ def test_ploc_builder_end_to_end(engine, orc, name, mode):
     if opt.use_any_hit:
         assert np.array_equal(ref0["total_bits"], ref["total_bits"])
     if name != "cube_inward":
-        assert st1.inner_visits < 1.02 * st0.inner_visits      # with the adaptive Morton order the two builders are level on flat scenes
+        assert st1.inner_visits < 1.02 * st0.inner_visits
         # ... and that order is what helps a flat scene: the strict x, y, z interleave visits more nodes
         if name == "terrain":
             nodes_xyz, _ = orc.bvh_build(orc.scene_triangles(flat.desc), 1, 0)

@@ -26,44 +26,7 @@
 #include <string>
 #include <vector>
 
-static bool read_exact(FILE* f, void* dst, size_t n) { return std::fread(dst, 1, n, f) == n; }
-
-static Scene* load_scene(const char* path)
-{
-	FILE* f = std::fopen(path, "rb");
-	if (!f) { std::perror(path); return nullptr; }
-	char magic[4]; uint32_t version, nmat, nobj;
-	if (!read_exact(f, magic, 4) || std::memcmp(magic, "AOBS", 4) || !read_exact(f, &version, 4) || version != 1 ||
-	    !read_exact(f, &nmat, 4) || !read_exact(f, &nobj, 4)) { std::fprintf(stderr, "%s: bad header\n", path); std::fclose(f); return nullptr; }
-	Scene* scene = new Scene();
-	for (uint32_t i = 0; i < nmat; i++)
-	{
-		int32_t d[4];
-		if (!read_exact(f, d, sizeof d)) { std::fclose(f); delete scene; return nullptr; }
-		scene->AddMaterial(new MaterialObject(L"Material", d[0], d[1], d[2], d[3]));
-	}
-	for (uint32_t i = 0; i < nobj; i++)
-	{
-		float trs[9]; uint32_t nsec;
-		if (!read_exact(f, trs, sizeof trs) || !read_exact(f, &nsec, 4)) { std::fclose(f); delete scene; return nullptr; }
-		BakeObject* object = new BakeObject(L"Object");
-		object->SetPosition({ trs[0], trs[1], trs[2] });
-		object->SetRotation({ trs[3], trs[4], trs[5] });
-		object->SetScale({ trs[6], trs[7], trs[8] });
-		for (uint32_t s = 0; s < nsec; s++)
-		{
-			int32_t material; uint32_t nv, ni;
-			if (!read_exact(f, &material, 4) || !read_exact(f, &nv, 4) || !read_exact(f, &ni, 4)) { std::fclose(f); delete scene; return nullptr; }
-			std::vector<RenderVertex> v(nv); std::vector<unsigned int> idx(ni);
-			if (!read_exact(f, v.data(), sizeof(RenderVertex) * nv) || !read_exact(f, idx.data(), 4ull * ni)) { std::fclose(f); delete scene; return nullptr; }
-			MaterialObject* mat = material >= 0 && material < scene->GetMaterialCount() ? scene->GetMaterial(material) : nullptr;
-			object->AddSection(new BakeObject::Section(L"Geometry", new RenderMesh(v.data(), (int)nv, idx.data(), (int)ni), mat));
-		}
-		scene->AddObject(object);
-	}
-	std::fclose(f);
-	return scene;
-}
+#include "scene_file.h"
 
 int main(int argc, char** argv)
 {
