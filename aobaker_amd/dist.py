@@ -34,6 +34,42 @@ def weak_scaling_atlas(base: int, world: int) -> tuple[int, int]:
     return base * a, base * b
 
 
+def equal_rows(height: int, parts: int, align: int = 8) -> list[int]:
+    """Cuts of `height` texel rows into `parts` strips of (nearly) equal numbers of 8-texel tile rows: parts + 1 row
+    numbers, [0, ..., height].  (aob_equal_rows of include/aobaker_multi.h computes the same.)"""
+    tile_rows = (height + align - 1) // align
+    b = [min(tile_rows * r // parts * align, height) for r in range(parts + 1)]
+    b[parts] = height
+    return b
+
+
+def rebalance_rows(bounds: list[int], old_ms: list[float], height: int, align: int = 8) -> list[int]:
+    """New tile-row aligned cuts such that every strip costs the same, with the cost per row of old strip r taken as
+    old_ms[r] / rows(r) (piecewise linear cumulative cost).  The border strips of the terrain cost less per row than the
+    middle ones; two or three warm-up steps of measure -> re-cut level the ranks.  The result cells do not depend on
+    where the cuts are.  Twin of aob_rebalance_rows (aobaker_amd/host/MultiGpu.cpp): same arithmetic, same cuts."""
+    parts = len(old_ms)
+    if len(bounds) != parts + 1 or parts == 0:
+        return list(bounds)
+    cost = [max(0.0, float(t)) for t in old_ms]
+    total = sum(cost)
+    if not total > 0.0:
+        return list(bounds)
+    out = [0] * (parts + 1)
+    out[parts] = height
+    seg, before = 0, 0.0
+    for r in range(1, parts):
+        want = total * r / parts
+        while seg + 1 < parts and before + cost[seg] < want:
+            before += cost[seg]
+            seg += 1
+        span = float(bounds[seg + 1] - bounds[seg])
+        row = bounds[seg] + span * (want - before) / cost[seg] if cost[seg] > 0.0 else float(bounds[seg + 1])
+        cut = int(row / align + 0.5) * align
+        out[r] = min(max(cut, out[r - 1]), height)
+    return out
+
+
 def row_window(height: int, rank: int, world: int, align: int = 8) -> tuple[int, int]:
     """Rank `rank`'s strip of texel rows [begin, end): the atlas's tile rows (8 texels) dealt out evenly.  With
     `Baker.rasterize(rows=...)` a rank rasterises and traces its own strip only; its result cells are the contiguous

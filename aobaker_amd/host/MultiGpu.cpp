@@ -196,6 +196,7 @@ AobMultiGpuBake* AobMultiGpuBake::Create(const AobSceneDesc* scene, const AobOpt
 	for (uint32_t i = 0; i < scene->material_count; i++) d.rows.push_back(aob_equal_rows(scene->materials[i].height, d.n));
 	const bool distinct = std::set<int>(devices.begin(), devices.end()).size() == devices.size();
 	d.use_rccl = distinct && d.n > 1;
+	if (!distinct) d.balance = false;      // ranks that share a device time each other's work: nothing to balance by
 	if (d.use_rccl)
 	{
 		d.comms.assign((size_t)d.n, nullptr);
@@ -417,5 +418,22 @@ int AobMultiGpuBake::GetStats(AobStats* stats)
 		stats->ray_count = stats->surfel_count * (uint64_t)d.opt.sample_count;
 	}
 	for (const AobStats& s : all) stats->ms_trace = std::max(stats->ms_trace, s.ms_trace);
+	return AOB_OK;
+}
+
+// C entry points of the two pure functions above, for the twin test against aobaker_amd/dist.py (tests/test_host_logic.py)
+extern "C" int aobhost_rebalance_rows(const int32_t* bounds, const double* old_ms, int32_t parts, int32_t height, int32_t align, int32_t* out)
+{
+	if (!bounds || !old_ms || !out || parts < 1) return AOB_ERR_INVALID_ARGUMENT;
+	const std::vector<int32_t> r = aob_rebalance_rows(std::vector<int32_t>(bounds, bounds + parts + 1), std::vector<double>(old_ms, old_ms + parts), height, align);
+	std::copy(r.begin(), r.end(), out);
+	return AOB_OK;
+}
+
+extern "C" int aobhost_equal_rows(int32_t height, int32_t parts, int32_t align, int32_t* out)
+{
+	if (!out || parts < 1) return AOB_ERR_INVALID_ARGUMENT;
+	const std::vector<int32_t> r = aob_equal_rows(height, parts, align);
+	std::copy(r.begin(), r.end(), out);
 	return AOB_OK;
 }

@@ -5,24 +5,39 @@ A step is one full device-side bake of the workload with the scene already resid
 BVH build -> UV rasterise + compact -> fused trace -> (N>1: gather of texel strips to rank 0)
 -> resolve + bleed.  value = rays all ranks cast / max-over-ranks step time.
 
-N=1 workload = BASELINE configs[2]: synthetic 999 698-triangle terrain, 2048^2 atlas, 256 spp,
-COSINE sampler, any-hit scoring, float accumulation.  N>1 is weak scaling: the atlas grows to
-N x 2048^2 texels (N=4 is configs[3]'s 4096^2); each rank rasterises and traces an equal strip of texel rows.
+Workloads (all: COSINE sampler, any-hit scoring, float accumulation, 256 spp, seed 3):
+  N = 1   BASELINE configs[2]: synthetic 999 698-triangle terrain, 2048^2 atlas.
+  N > 1   BASELINE configs[3]: the same terrain, ONE fixed 4096^2 atlas cut into N strips of texel rows, one per rank
+          (strong scaling: total work is fixed).  The strips start equal and are re-cut during the warm-up steps in
+          proportion to the ranks' measured times (the border strips of the terrain are cheaper per row).
+          `--scaling weak` keeps round 1's N x 2048^2 atlas instead.
+
+Launch: `python bench.py --gpus N` starts its own N rank processes (fresh children, created before this process
+touches the GPU); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the launcher's ranks are
+used.  One process per GPU, RCCL (`nccl`) for the gather, one JSON line from rank 0.
 
 The JSON line also carries
-  roofline     the trace kernel against HBM peak, ALGORITHMIC bytes:
-               B_ray = node_packet*n_inner + 48*n_leaf + 64 + 8/spp, node visits counted by the CPU oracle on
-               a texel subsample of the same rays; kernel time from HIP events on the library's
-               own stream.  frac can exceed 1: every node visit is counted as memory traffic
-               although most are served by L1/L2/Infinity Cache — `traffic` is what reaches HBM.
-  cpu_baseline the CPU oracle (a port, oracle/) timed on this box's host cores on a bounded
-               texel subsample of the same workload (rank 0, N=1 only).
+  roofline      the trace kernel: ALGORITHMIC bytes per SURVEY.md §8(d) — B_ray = 64 (n_inner + n_leaf) + 40 / spp, node
+                fetches counted by the CPU oracle on a texel subsample of the same rays — over the kernel's time from HIP
+                events on the library's own stream, against HBM peak.  `frac` can exceed 1: the model counts every node
+                fetch as memory traffic although L1 / L2 / Infinity Cache serve most of them; a fraction above 1 means
+                "cache-served", not "faster than HBM".  `traffic` / `hbm_counter_frac` (what the memory-side counters
+                saw) and `valu_issue_frac` (the roof that actually binds: VALU issue) come from the committed rocprofv3
+                PMC passes of THIS kernel source and THIS configuration (profiles/k_trace_counters.json) and are null
+                when either differs.
+  cpu_baseline  the CPU oracle (a port, oracle/) timed on this box's host cores on a bounded texel subsample (N = 1 only).
+  bake_wallclock_ms  the PCIe-inclusive `aob_bake` (allocation + upload + device step + download), first call of the
+                process (cold) and second (warm), beside the device step (N = 1 only) — SURVEY.md §8(d)(ii).
+  cpp_host      the same workload through the C++ multi-GPU host (one process, one thread + one RCCL rank per device,
+                aobaker_amd/host/MultiGpu.cpp), run by rank 0 as a child process after the timed region.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,28 +45,87 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+KERNEL_SOURCES = ("aobaker_amd/csrc/trace.hip", "aobaker_amd/csrc/aob_math.h", "aobaker_amd/csrc/aob_internal.h")
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--atlas", type=int, default=2048)
+    ap.add_argument("--atlas", type=int, default=0, help="0 = the BASELINE config of --gpus (2048 at N=1, 4096 at N>1)")
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--grid", type=int, default=708, help="terrain grid (708 -> 999 698 triangles)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--bvh-width", type=int, default=0, help="0 = library default (4), 2 = BVH2 nodes, 4 = 4-ary nodes")
     ap.add_argument("--bvh-quantised", type=int, default=-1, help="-1 = library default (1); 1 = 15-bit quantised boxes, lane per ray; 0 = fp32 boxes")
     ap.add_argument("--bvh-builder", type=int, default=-1, help="-1 = library default; 0 = LBVH, 1 = PLOC")
+    ap.add_argument("--no-balance", action="store_true", help="N>1: keep the equal strips (no re-cut during warm-up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpp-host", action="store_true")
+    ap.add_argument("--no-wallclock", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+# ---------------------------------------------------------------------------------------------------------------
+# parent of a self-launched N-rank run: never imports torch, never touches the GPU
+
+def visible_devices():
+    """GPUs a fresh process sees (counted in a child: counting must not initialise the GPU in THIS process)."""
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                             capture_output=True, text=True, timeout=600)
+        return int(out.stdout.strip().splitlines()[-1])
+    except Exception:
+        return 0
+
+
+def launch_ranks(args):
+    import socket
+    have = visible_devices()
+    if have < args.gpus:
+        msg = f"bench.py --gpus {args.gpus} needs {args.gpus} devices, {have} visible on this box: nothing was run"
+        print(msg, file=sys.stderr)
+        print(json.dumps({"metric": "AO rays/sec", "value": None, "unit": "rays/s", "n_gpus": args.gpus, "skipped": msg}), flush=True)
+        return 0
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    line = None
+    for l in (out0 or "").splitlines():
+        if l.startswith("{"):
+            line = l
+        else:
+            print(l, file=sys.stderr)
+    if line:
+        print(line, flush=True)
+    if any(codes) or not line:
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        return 1
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import torch                       # first: one HIP runtime for torch and the library
     import torch.distributed as dist
@@ -61,11 +135,20 @@ def main():
     from aobaker_amd.scene import FlatScene
 
     torch.cuda.set_device(local_rank)
+    host_group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        host_group = dist.new_group(backend="gloo")         # host-side waits that keep the GPUs idle (cpp_host leg)
 
-    W, H = aod.weak_scaling_atlas(args.atlas, world)
+    strong = args.scaling == "strong"
+    if world == 1:
+        W = H = args.atlas or 2048
+    elif strong:
+        W = H = args.atlas or 4096
+    else:
+        W, H = aod.weak_scaling_atlas(args.atlas or 2048, world)
     scene = scenes.terrain_scene(grid=args.grid, atlas=(W, H), seed=3, bpc=4)
     flat = FlatScene(scene)
     BakeEngine.Init(local_rank)
@@ -83,29 +166,48 @@ def main():
     if args.bvh_builder >= 0:
         opts.bvh_builder = args.bvh_builder
 
+    wallclock = None
+    if world == 1 and not args.no_wallclock:
+        # what corresponds to the reference's Bake() — allocation, upload (28 MB), device step, download
+        # (W*H*4 B) — through the one-shot entry point; first call of the process (code objects load, first launches) and again
+        times = []
+        for _ in range(2):
+            t = time.perf_counter()
+            BakeEngine.Options = opts
+            BakeEngine.Bake(scene)
+            times.append((time.perf_counter() - t) * 1e3)
+        st = BakeEngine.LastStats
+        wallclock = {"aob_bake_cold_ms": round(times[0], 2), "aob_bake_warm_ms": round(times[1], 2),
+                     "of_which_ms": {"upload": round(st.ms_upload, 3), "bvh_build": round(st.ms_bvh_build, 3), "rasterize": round(st.ms_rasterize, 3),
+                                     "trace": round(st.ms_trace, 3), "resolve": round(st.ms_resolve, 3), "download": round(st.ms_download, 3)},
+                     "note": "PCIe-inclusive one-shot aob_bake (create + upload + device step + download + destroy); never `value`"}
+
     baker = Baker(flat, opts)           # uploads the scene: inputs resident in HBM from here on
     cells = aod.alias_results(baker, 0, as_float=True) if world > 1 else None
-    trace_ms = []
+    trace_ms, step_ms = [], []
     counts = {}
-
-    # every rank rasterises and traces its own strip of texel rows (the whole atlas at N = 1); the BVH is built by all
-    rows = aod.row_window(H, rank, world)
-    my_cells = (rows[0] * W, rows[1] * W - 1)
-    all_cells = [(b * W, e * W - 1) for b, e in (aod.row_window(H, r, world) for r in range(world))]
+    bounds = aod.equal_rows(H, world)   # every rank rasterises and traces its own strip of texel rows; the BVH is built by all
 
     def step():
+        t = time.perf_counter()
+        rows = (bounds[rank], bounds[rank + 1])
         baker.build_bvh()
         baker.rasterize(0, rows if world > 1 else None)
         n = baker.surfel_count(0)
         baker.trace(0, 0, n)
         if world > 1:
             baker.sync()
-            aod.gather_strips(cells, my_cells, rank, world, 0, False, all_cells)
+            mine = (time.perf_counter() - t) * 1e3
+            all_cells = [(bounds[r] * W, bounds[r + 1] * W - 1) for r in range(world)]
+            aod.gather_strips(cells, all_cells[rank], rank, world, 0, False, all_cells)
             torch.cuda.synchronize()
         if rank == 0:
             baker.resolve(0)
         baker.sync()
+        if world == 1:
+            mine = (time.perf_counter() - t) * 1e3
         trace_ms.append(baker.last_trace_ms())
+        step_ms.append(mine)
         counts["mine"] = n
 
     def fence():
@@ -114,9 +216,19 @@ def main():
         torch.cuda.synchronize()
         baker.sync()
 
+    history = []
     for _ in range(args.warmup):
         step()
+        if world > 1 and not args.no_balance:
+            # re-cut the strips in proportion to what every rank's strip just cost (host clock: build + raster + trace)
+            t = torch.tensor([step_ms[-1]], dtype=torch.float64, device="cuda")
+            every = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+            dist.all_gather(every, t)
+            ms = [float(v.item()) for v in every]
+            history.append({"rows": list(bounds), "rank_ms": [round(v, 3) for v in ms]})
+            bounds = aod.rebalance_rows(bounds, ms, H)
     trace_ms.clear()
+    step_ms.clear()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -130,64 +242,163 @@ def main():
 
     stats = baker.stats()
     my_rays = counts["mine"] * args.spp
+    rank_ms = [sum(step_ms) / len(step_ms)]
     if world > 1:
         t = torch.tensor([counts["mine"]], dtype=torch.int64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         counts["surfels"] = int(t.item())
+        t = torch.tensor(rank_ms, dtype=torch.float64, device="cuda")
+        every = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+        dist.all_gather(every, t)
+        rank_ms = [float(v.item()) for v in every]
     else:
         counts["surfels"] = counts["mine"]
     total_rays = counts["surfels"] * args.spp                  # all ranks together
     ms_per_step = elapsed / args.steps * 1e3
     value = total_rays / (elapsed / args.steps)
     kernel_ms = sum(trace_ms) / len(trace_ms)
+    baker.close()
+    BakeEngine.Dispose()
 
-    cpu = None
-    roofline = None
+    # the same workload through the C++ multi-GPU host (rank 0 starts it as a child once every rank has let go of its GPU work)
+    cpp = None
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    if rank == 0 and not args.no_cpp_host:
+        cpp = cpp_host_leg(scene, world, args)
+    if world > 1:
+        dist.barrier(group=host_group)      # gloo: the peers wait on the host, their GPUs stay idle meanwhile
+
     if rank == 0:
+        cpu = None
         visits = None
         if world == 1 and not args.no_cpu_baseline:
             cpu, visits = cpu_baseline(flat, opts, W, H, args.cpu_seconds)
         if visits is None:
             visits = visits_per_ray(flat, opts, W, H)
-        n_inner, n_leaf = visits
-        n_visits = n_inner + n_leaf
-        # bytes one ray asks of the memory system (with this build's packet sizes):
-        # inner-node packet (64 B fp32 BVH2 / 32 B quantised BVH2 / 128 B fp32 4-ary / 64 B quantised 4-ary), 48 B per leaf
-        # triangle, plus per ray 64 B of its surfel's frame (48 B when the sample is generated, 16 B when it is
-        # taken off the wavefront's queue) and per surfel the 8 B result cell
-        inner_bytes = ((64.0 if opts.bvh_quantised else 128.0) if opts.bvh_width == 4
-                       else (32.0 if opts.bvh_quantised else 64.0))
-        b_ray = inner_bytes * n_inner + 48.0 * n_leaf + 64.0 + 8.0 / args.spp
-        achieved = my_rays * b_ray / (kernel_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(),
-                    "kernel": "k_trace", "kernel_ms": round(kernel_ms, 3),
-                    "bytes_per_ray": round(b_ray, 1), "node_visits_per_ray": round(n_visits, 3),
-                    "inner_visits_per_ray": round(n_inner, 3), "leaf_visits_per_ray": round(n_leaf, 3),
-                    "inner_packet_bytes": inner_bytes,
-                    "rays_per_launch": my_rays}
+        roofline = roofline_record(opts, args, W, H, world, visits, my_rays, kernel_ms)
         line = {
             "metric": "AO rays/sec", "value": value, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"terrain {flat.triangle_count()} tris, {W}x{H} atlas, {args.spp} spp, "
                                    f"cosine sampler, any-hit, float accumulate, {'PLOC' if opts.bvh_builder else 'LBVH'} bvh_width {opts.bvh_width or 2}"
-                                   f"{' quantised' if opts.bvh_quantised else ''} (BASELINE configs[2]"
-                                   f"{' scaled: N x 2048^2 texels' if world > 1 else ''})",
+                                   f"{' quantised' if opts.bvh_quantised else ''} — "
+                                   + ("BASELINE configs[2]" if world == 1 else
+                                      ("BASELINE configs[3]: one fixed atlas in N strips of texel rows" if strong else "configs[2] scaled: N x 2048^2 texels")),
+                       "mesh": f"synthetic fBm heightfield, {args.grid}x{args.grid} vertices, seed 3 (aobaker_amd/scenes.py terrain_scene): "
+                               "the BASELINE terrain itself, not a stand-in",
                        "triangles": flat.triangle_count(), "atlas": [W, H], "spp": args.spp,
-                       "surfels": counts["surfels"], "rays": total_rays, "sharding": f"texel strips x{world}",
-                       "bvh_nodes": stats.node_count, "bvh_depth": stats.bvh_depth},
-            "stage_ms": {"bvh_build": round(stats.ms_bvh_build, 3), "trace_kernel": round(kernel_ms, 3)},
-            "bake_wallclock_ms": round(ms_per_step, 3),
-            "roofline": roofline, "cpu_baseline": cpu,
+                       "surfels": counts["surfels"], "rays": total_rays, "sharding": f"strips of texel rows x{world}",
+                       "rows": [[bounds[r], bounds[r + 1]] for r in range(world)],
+                       "bvh_nodes": stats.node_count, "bvh_depth": stats.bvh_depth,
+                       "host": "python ranks, one process per GPU, torch.distributed nccl (= RCCL) point-to-point gather to rank 0"},
+            "stage_ms": {"bvh_build": round(stats.ms_bvh_build, 3), "trace_kernel": round(kernel_ms, 3),
+                         "rank_build_raster_trace": [round(v, 3) for v in rank_ms]},
+            "bake_wallclock_ms": dict(wallclock or {}, device_step_ms=round(ms_per_step, 3)),
+            "roofline": roofline, "cpu_baseline": cpu, "cpp_host": cpp,
         }
+        if world > 1:
+            line["balance"] = {"enabled": not args.no_balance, "warmup_history": history}
+            if strong:
+                line["strong_scaling_base"] = strong_scaling_base(W, args.spp)
         print(json.dumps(line), flush=True)
-    baker.close()
-    BakeEngine.Dispose()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cpp_host_leg(scene, world, args):
+    """`aobake_mgpu` on the same scene: one process, one host thread + one RCCL rank per device (MultiGpu.cpp)."""
+    import tempfile
+    from aobaker_amd import scenefile
+    exe = os.path.join(ROOT, "aobaker_amd", "host", "aobake_mgpu")
+    if not os.path.exists(exe):
+        return {"error": f"{exe} has not been built"}
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "scene.aobs")
+            scenefile.write_scene(scene, path)
+            cmd = [exe, "--scene", path, "--gpus", str(world), "--steps", str(max(1, min(args.steps, 5))), "--warmup", str(max(2, min(args.warmup, 3))),
+                   "--spp", str(args.spp), "--sampler", "1", "--accumulate", "1", "--seed", "3", "--any-hit", "1", "--normal-fp16", "0"]
+            if args.no_balance:
+                cmd.append("--no-balance")
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        if out.returncode != 0:
+            return {"error": f"rc {out.returncode}: {out.stderr.strip()[-300:]}"}
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:                       # the leg is a report, never a reason to lose the bench line
+        return {"error": repr(e)[:300]}
+
+
+def strong_scaling_base(atlas, spp):
+    """The single-GPU time of the SAME fixed atlas the N > 1 value is to be read against (measured, committed)."""
+    p = os.path.join(ROOT, "profiles", "strong_scaling_base.json")
+    try:
+        with open(p) as f:
+            rec = json.load(f)
+        if rec.get("atlas") == atlas and rec.get("spp") == spp:
+            return rec
+    except Exception:
+        pass
+    return None
+
+
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def counter_record(opts, args, W, H, world):
+    """profiles/k_trace_counters.json if it was measured on this kernel source and this configuration, else (None, why)."""
+    p = os.path.join(ROOT, "profiles", "k_trace_counters.json")
+    try:
+        with open(p) as f:
+            rec = json.load(f)
+    except Exception:
+        return None, "no profiles/k_trace_counters.json"
+    want = {"atlas": [W, H], "spp": args.spp, "grid": args.grid, "n_gpus": world, "bvh_width": opts.bvh_width, "bvh_quantised": opts.bvh_quantised,
+            "bvh_builder": opts.bvh_builder}
+    if rec.get("source_sha256_16") != kernel_source_hash():
+        return None, f"counters were measured on kernel source {rec.get('source_sha256_16')}, this is {kernel_source_hash()}"
+    if rec.get("config") != want:
+        return None, "counters were measured on another configuration"
+    return rec, None
+
+
+def roofline_record(opts, args, W, H, world, visits, my_rays, kernel_ms):
+    n_inner, n_leaf = visits
+    # SURVEY §8(d) as written: 64 B per node packet fetched (the quantised 4-ary node is 64 B; a leaf visit is counted as one
+    # packet too) + (32 B surfel + 8 B result cell) / spp
+    b_ray = 64.0 * (n_inner + n_leaf) + 40.0 / args.spp
+    # the build's own accounting, kept beside it: the real packet sizes (64-B quantised 4-ary node, 48 B per leaf triangle
+    # fetched), 64 B of the surfel's trace record per ray and the 8-B cell per surfel
+    inner_bytes = ((64.0 if opts.bvh_quantised else 128.0) if opts.bvh_width == 4 else (32.0 if opts.bvh_quantised else 64.0))
+    b_ray_build = inner_bytes * n_inner + 48.0 * n_leaf + 64.0 + 8.0 / args.spp
+    achieved = my_rays * b_ray / (kernel_ms * 1e-3) / 1e9
+    rec, why = counter_record(opts, args, W, H, world)
+    traffic = hbm_frac = valu_frac = lane_occ = None
+    if rec:
+        traffic = rec["hbm_side_bytes_per_launch"]
+        hbm_frac = round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        valu_frac = rec.get("valu_issue_frac")
+        lane_occ = rec.get("valu_lane_occupancy")
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "frac_note": "algorithmic node bytes / HBM peak (SURVEY §8(d)); > 1 means the fetches are cache-served — the binding roof is "
+                         "VALU issue, see valu_issue_frac",
+            "hbm_counter_frac": hbm_frac, "valu_issue_frac": valu_frac, "valu_lane_occupancy": lane_occ,
+            "counters": (rec or {}).get("provenance") or why,
+            "kernel": "k_trace", "kernel_ms": round(kernel_ms, 3), "kernel_source_sha256_16": kernel_source_hash(),
+            "bytes_per_ray": round(b_ray, 1), "bytes_per_ray_build": round(b_ray_build, 1),
+            "frac_build": round(my_rays * b_ray_build / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "node_visits_per_ray": round(n_inner + n_leaf, 3), "inner_visits_per_ray": round(n_inner, 3), "leaf_visits_per_ray": round(n_leaf, 3),
+            "inner_packet_bytes": inner_bytes, "rays_per_launch": my_rays}
 
 
 def host_cores():
@@ -225,9 +436,9 @@ def _subsample(surfels, one_in):
 
 
 def visits_per_ray(flat, opts, W, H):
-    """Mean BVH node fetches per ray, counted by the oracle on 1/256 of the texels."""
+    """Mean BVH node fetches per ray, counted by the oracle on 1/256 of the texels (1/1024 on atlases above 2048^2)."""
     orc, nodes, surfels = _oracle_inputs(flat, opts)
-    sub = _subsample(surfels, 256)
+    sub = _subsample(surfels, 256 if W * H <= 2048 * 2048 else 1024)
     _, st = orc.trace(nodes, sub, None, opts, W, H, threads=host_cores())
     return st.inner_visits / max(1, st.rays), st.leaf_visits / max(1, st.rays)
 
@@ -260,18 +471,6 @@ def cpu_baseline(flat, opts, W, H, seconds):
              "sample": f"a fixed pseudo-random 1/{one_in} of the texels of the same atlas ({len(sub)} surfels, {st.rays} rays, "
                        f"{dt:.1f} s); trace stage only, same BVH/sampler/rays as the GPU",
              "extrapolated_full_trace_s": len(surfels) * opts.sample_count / (st.rays / dt)}, visits)
-
-
-def measured_traffic():
-    """HBM bytes per k_trace launch from the committed rocprofv3 PMC passes (profiles/), or None."""
-    p = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(p):
-        try:
-            with open(p) as f:
-                return json.load(f).get("k_trace_hbm_bytes_per_launch")
-        except Exception:
-            return None
-    return None
 
 
 if __name__ == "__main__":

@@ -1661,6 +1661,105 @@ void orc_morton_codes(const OrcTriangle* tris, uint64_t n, int adaptive, uint64_
 }
 
 /* ------------------------------------------------------------------------ */
+/* two-level walk (instancing): top-level tree over instances, shared bottom-level trees   */
+
+/* The structure of kernels/CL/intersect_bvh2level_skiplinks.cl:134-307 — a top-level hierarchy whose leaves are shapes
+ * with a world-to-object transform and a bottom-level tree of their own (Shape :75-92), the ray transformed on entry
+ * (transform_ray :123-131, :246-253: point and vector by the inverse matrix rows, NOT renormalised, so t keeps its
+ * meaning) and restored on return (:278-288) — walked here with the SAME traversal discipline as the flat tree
+ * (traverse(): child boxes in the parent, near child first, stack), so that visit counts of the two structures compare
+ * like for like.  The top-level tree is an AobBvhNode[] whose "triangles" are the instances' world boxes
+ * (v0 = box min, v1 = box max; prim_id = instance index); a leaf there means "enter the instance".
+ * st_top counts top-level inner visits in inner_visits and instance entries in leaf_visits; st_bottom counts the
+ * bottom-level trees' inner visits and triangle tests. */
+int orc_two_level_intersect(const AobBvhNode* tlas, uint64_t tlas_count, const OrcInstance* instances,
+                            const AobBvhNode* const* blas_nodes, const uint64_t* blas_counts,
+                            const OrcRay* rays, uint64_t n, int32_t any_hit, OrcIntersection* hits,
+                            OrcTraceStats* st_top, OrcTraceStats* st_bottom)
+{
+    int error = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const OrcRay* r = &rays[i];
+        if (r->extra[1] == 0) continue;
+        st_top->rays++;
+        const f3 o = f3_make(r->o[0], r->o[1], r->o[2]), d = f3_make(r->d[0], r->d[1], r->d[2]);
+        float closest_t = r->o[3];
+        int hit = 0; uint32_t hit_shape = 0, hit_prim = 0;
+        if (tlas_count) {
+            const f3 invdir = safe_invdir(d);
+            const f3 oxinvdir = f3_make(-o.x * invdir.x, -o.y * invdir.y, -o.z * invdir.z);
+            uint32_t stack[ORC_STACK]; int sp = 0;
+            stack[sp++] = AOB_INVALID_ADDR;
+            uint32_t addr = 0;
+            while (addr != AOB_INVALID_ADDR) {
+                const AobBvhNode* nd = &tlas[addr];
+                if (nd->addr_left != AOB_INVALID_ADDR) {
+                    st_top->inner_visits++;
+                    float s0x, s0y, s1x, s1y;
+                    intersect_bbox(nd->lmin_or_v0, nd->lmax_or_v1, invdir, oxinvdir, closest_t, &s0x, &s0y);
+                    intersect_bbox(nd->rmin_or_v2, nd->rmax, invdir, oxinvdir, closest_t, &s1x, &s1y);
+                    const int c0 = s0x <= s0y, c1 = s1x <= s1y, c1first = c1 && (s0x > s1x);
+                    if (c0 || c1) {
+                        uint32_t deferred;
+                        if (c1first || !c0) { addr = nd->addr_right; deferred = nd->addr_left; }
+                        else { addr = nd->addr_left; deferred = nd->addr_right; }
+                        if (c0 && c1) { if (sp >= ORC_STACK) return AOB_ERR_BVH_TOO_DEEP; stack[sp++] = deferred; }
+                        continue;
+                    }
+                } else {
+                    /* a top-level leaf: enter the instance (intersect_bvh2level_skiplinks.cl:225-256) */
+                    st_top->leaf_visits++;
+                    const OrcInstance* in = &instances[nd->prim_id];
+                    const float* m = in->world_to_object;
+                    const f3 oo = f3_make(fmaf(m[2], o.z, fmaf(m[1], o.y, m[0] * o.x)) + m[3],
+                                          fmaf(m[6], o.z, fmaf(m[5], o.y, m[4] * o.x)) + m[7],
+                                          fmaf(m[10], o.z, fmaf(m[9], o.y, m[8] * o.x)) + m[11]);
+                    const f3 od = f3_make(fmaf(m[2], d.z, fmaf(m[1], d.y, m[0] * d.x)),
+                                          fmaf(m[6], d.z, fmaf(m[5], d.y, m[4] * d.x)),
+                                          fmaf(m[10], d.z, fmaf(m[9], d.y, m[8] * d.x)));
+                    float t; uint32_t leaf;
+                    const int h = traverse_addr(blas_nodes[in->blas], blas_counts[in->blas], oo, od, closest_t, any_hit, &t, st_bottom,
+                                                &error, NULL, &leaf);
+                    if (h && t < closest_t) {
+                        closest_t = t; hit = 1; hit_shape = in->shape_id; hit_prim = blas_nodes[in->blas][leaf].prim_id;
+                        if (any_hit) break;
+                    }
+                }
+                addr = stack[--sp];
+            }
+        }
+        st_top->hits += (uint64_t)hit;
+        if (hits) {
+            OrcIntersection* hrec = &hits[i];
+            if (hit) { hrec->shape_id = (int32_t)hit_shape; hrec->prim_id = (int32_t)hit_prim; hrec->uvwt[0] = hrec->uvwt[1] = hrec->uvwt[2] = 0.0f; hrec->uvwt[3] = closest_t; }
+            else { hrec->shape_id = -1; hrec->prim_id = -1; }
+        }
+    }
+    return error;
+}
+
+/* traverse() over ray records with visit counts (the flat tree's side of the comparison). */
+int orc_flat_intersect(const AobBvhNode* nodes, uint64_t node_count, const OrcRay* rays, uint64_t n, int32_t any_hit,
+                       OrcIntersection* hits, OrcTraceStats* st)
+{
+    int error = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const OrcRay* r = &rays[i];
+        if (r->extra[1] == 0) continue;
+        st->rays++;
+        float t; uint32_t addr;
+        const int hit = traverse_addr(nodes, node_count, f3_make(r->o[0], r->o[1], r->o[2]), f3_make(r->d[0], r->d[1], r->d[2]),
+                                      r->o[3], any_hit, &t, st, &error, NULL, &addr);
+        st->hits += (uint64_t)hit;
+        if (hits) {
+            if (hit) { hits[i].shape_id = (int32_t)nodes[addr].shape_id; hits[i].prim_id = (int32_t)nodes[addr].prim_id; hits[i].uvwt[3] = t; }
+            else { hits[i].shape_id = -1; hits[i].prim_id = -1; }
+        }
+    }
+    return error;
+}
+
+/* ------------------------------------------------------------------------ */
 /* resolve + bleed + format conversion                                       */
 
 static inline int32_t as_i32(uint32_t u) { return (int32_t)u; }

@@ -165,6 +165,23 @@ void orc_process_intersections(const AobSurfel* surfels, uint64_t begin, uint64_
  * the reference's bbox record form (8 floats each; NULL: not wanted). */
 void orc_morton_codes(const OrcTriangle* tris, uint64_t n, int adaptive, uint64_t* codes, float* prim_boxes8, float* scene_box8);
 
+/* ---- two-level walk (instancing; kernels/CL/intersect_bvh2level_skiplinks.cl:75-131,134-307) ---------------------- */
+
+/* One shape of the top level: rows m0, m1, m2 of its world-to-object matrix in column-vector form (Shape::m0..m2,
+ * :84-87; the reference hands RadeonRays transpose(inverse(model)), BakeEngine.cpp:390-393), the id its hits report
+ * and which bottom-level tree it shares. */
+typedef struct OrcInstance { float world_to_object[12]; uint32_t shape_id; uint32_t blas; } OrcInstance;
+/* Closest (any_hit 0) or any (1) hit of ray records against top-level tree + instances + bottom-level trees, with the
+ * stack discipline of traverse() on both levels.  hits may be NULL (counting only).  st_top: inner_visits = top-level
+ * node fetches, leaf_visits = instances entered; st_bottom: the bottom-level trees' node fetches and triangle tests. */
+int orc_two_level_intersect(const AobBvhNode* tlas, uint64_t tlas_count, const OrcInstance* instances,
+                            const AobBvhNode* const* blas_nodes, const uint64_t* blas_counts,
+                            const OrcRay* rays, uint64_t n, int32_t any_hit, OrcIntersection* hits,
+                            OrcTraceStats* st_top, OrcTraceStats* st_bottom);
+/* The flat tree over the same records, counted the same way. */
+int orc_flat_intersect(const AobBvhNode* nodes, uint64_t node_count, const OrcRay* rays, uint64_t n, int32_t any_hit,
+                       OrcIntersection* hits, OrcTraceStats* st);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,8 @@ def load():
         "orc_occluded_rays": (None, [vp, u64, vp, u64, vp]),
         "orc_process_intersections": (None, [vp, u64, u64, vp, vp, P(capi.AobOptions), f32, i32, i32, vp]),
         "orc_morton_codes": (None, [vp, u64, C.c_int, vp, vp, vp]),
+        "orc_two_level_intersect": (C.c_int, [vp, u64, vp, vp, vp, vp, u64, i32, vp, P(OrcTraceStats), P(OrcTraceStats)]),
+        "orc_flat_intersect": (C.c_int, [vp, u64, vp, u64, i32, vp, P(OrcTraceStats)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -348,6 +350,77 @@ def morton_codes(tris, adaptive=0):
     scene = np.zeros(8, dtype=np.float32)
     load().orc_morton_codes(tris.ctypes.data, n, int(adaptive), codes.ctypes.data, boxes.ctypes.data, scene.ctypes.data)
     return codes[:n], boxes[:n], scene
+
+
+INSTANCE = np.dtype([("world_to_object", "<f4", 12), ("shape_id", "<u4"), ("blas", "<u4")])
+
+
+def flat_intersect(nodes, rays, any_hit=False, want_hits=True):
+    """traverse() over ray records with node-visit counts: (hits or None, OrcTraceStats)."""
+    nodes, rays = np.ascontiguousarray(nodes), np.ascontiguousarray(rays)
+    hits = np.zeros(max(1, len(rays)), dtype=INTERSECTION) if want_hits else None
+    st = OrcTraceStats()
+    rc = load().orc_flat_intersect(nodes.ctypes.data if len(nodes) else None, len(nodes), rays.ctypes.data, len(rays), int(bool(any_hit)),
+                                   None if hits is None else hits.ctypes.data, C.byref(st))
+    if rc != 0:
+        raise RuntimeError(f"orc_flat_intersect failed: {rc}")
+    return (None if hits is None else hits[:len(rays)]), st
+
+
+def two_level_intersect(tlas, instances, blas_list, rays, any_hit=False, want_hits=True):
+    """The two-level walk (intersect_bvh2level_skiplinks.cl's structure, traverse()'s discipline):
+    (hits or None, top-level stats, bottom-level stats)."""
+    tlas, rays = np.ascontiguousarray(tlas), np.ascontiguousarray(rays)
+    instances = np.ascontiguousarray(instances, dtype=INSTANCE)
+    blas_list = [np.ascontiguousarray(b) for b in blas_list]
+    ptrs = (C.c_void_p * len(blas_list))(*[b.ctypes.data for b in blas_list])
+    counts = (C.c_uint64 * len(blas_list))(*[len(b) for b in blas_list])
+    hits = np.zeros(max(1, len(rays)), dtype=INTERSECTION) if want_hits else None
+    top, bottom = OrcTraceStats(), OrcTraceStats()
+    rc = load().orc_two_level_intersect(tlas.ctypes.data if len(tlas) else None, len(tlas), instances.ctypes.data, ptrs, counts,
+                                        rays.ctypes.data, len(rays), int(bool(any_hit)), None if hits is None else hits.ctypes.data,
+                                        C.byref(top), C.byref(bottom))
+    if rc != 0:
+        raise RuntimeError(f"orc_two_level_intersect failed: {rc}")
+    return (None if hits is None else hits[:len(rays)]), top, bottom
+
+
+def two_level_scene(scene, builder=None, adaptive=None):
+    """Top-level tree, instances and bottom-level trees of a Scene (aobaker_amd.scene): one instance per (object, section) in
+    scene order — shape id = mesh index + 1, as the flat build numbers them — sections whose meshes hold the same vertex
+    positions and indices share one bottom-level tree (built in OBJECT space), the top level is built over the instances'
+    world boxes with the same builder.  Returns (tlas, instances, blas_list)."""
+    blas_list, blas_key, instances, boxes = [], {}, [], []
+    shape = 0
+    for i in range(scene.GetObjectCount()):
+        obj = scene.GetObject(i)
+        model = np.asarray(obj.BuildTransform(), dtype=np.float64).reshape(4, 4)      # row-vector: world = [p 1] model
+        inv = np.linalg.inv(model)
+        for s in range(obj.GetSectionCount()):
+            mesh = obj.GetSection(s).GetPreviewMesh()
+            shape += 1
+            v = np.ascontiguousarray(mesh.GetVertices()["Position"], dtype=np.float32)
+            idx = np.ascontiguousarray(mesh.GetIndices(), dtype=np.uint32)
+            key = (v.tobytes(), idx.tobytes())
+            if key not in blas_key:
+                tri = np.zeros(len(idx) // 3, dtype=TRIANGLE)
+                tri["v"] = v[idx[:3 * (len(idx) // 3)].reshape(-1, 3)]
+                tri["shape_id"] = 0
+                tri["prim_id"] = np.arange(len(tri), dtype=np.uint32)
+                blas_key[key] = len(blas_list)
+                blas_list.append(bvh_build(tri, builder, adaptive)[0])
+            world = (np.concatenate([v.astype(np.float64), np.ones((len(v), 1))], axis=1) @ model)[:, :3].astype(np.float32)
+            boxes.append((world.min(axis=0), world.max(axis=0)))
+            inst = np.zeros(1, dtype=INSTANCE)
+            inst["world_to_object"][0] = inv.T[:3, :].reshape(-1).astype(np.float32)     # column-vector rows m0, m1, m2
+            inst["shape_id"], inst["blas"] = shape, blas_key[key]
+            instances.append(inst)
+    fake = np.zeros(len(boxes), dtype=TRIANGLE)
+    for k, (lo, hi) in enumerate(boxes):
+        fake["v"][k, 0], fake["v"][k, 1], fake["v"][k, 2] = lo, hi, lo
+    fake["prim_id"] = np.arange(len(boxes), dtype=np.uint32)
+    tlas = bvh_build(fake, builder, adaptive)[0]
+    return tlas, np.concatenate(instances), blas_list
 
 
 def default_options():

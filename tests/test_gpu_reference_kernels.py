@@ -221,13 +221,13 @@ def ramp_scene(g):
 
 HLBVH_SCENES = {
     "cube": lambda: scenes.cube_scene(32),                                  # 12 triangles, 6 codes: the index fallback
-    "ramp17": lambda: ramp_scene(17),                                       # 512 triangles: one 1024-thread workgroup
+    "ramp12": lambda: ramp_scene(12),                                       # 242 triangles: one 256-work-item workgroup
     "ramp40": lambda: ramp_scene(40),                                       # 3 042 triangles, 48 workgroups
     "terrain_small": lambda: scenes.terrain_scene(grid=20, atlas=32),       # real terrains collide in 30 bits: skipped if so
 }
 
 
-@pytest.mark.parametrize("name", ["cube", "ramp17", "ramp40", "terrain_small"])
+@pytest.mark.parametrize("name", ["cube", "ramp12", "ramp40", "terrain_small"])
 def test_reference_kernels_hlbvh_build_matches_library_and_oracle(engine, orc, name):
     """build_hlbvh.cl on the GPU — calculate_morton_code_main, (host sort), emit_hierarchy_main, refit_bounds_main —
     against `bvh_builder = 0, morton_adaptive = 0` of the library and the oracle.  The reference sorts 30-bit codes, the
@@ -246,7 +246,7 @@ def test_reference_kernels_hlbvh_build_matches_library_and_oracle(engine, orc, n
         if len(np.unique(codes30)) != len(np.unique(codes63)):
             pytest.skip(f"{name}: {len(np.unique(codes63)) - len(np.unique(codes30))} 63-bit codes collide in their top 30 bits")
         order = np.argsort(codes30, kind="stable")
-        one_group = n <= 1024
+        one_group = n <= 256            # the code object's max_flat_workgroup_size (OpenCL default)
         # refit_bounds_main has no fence between a child's box store and its sibling's read of it (build_hlbvh.cl:283-312):
         # across workgroups that is a race on this chip, inside one workgroup (one CU, one L1) it is not
         if one_group:
@@ -281,8 +281,8 @@ def _hierarchy_one_group(mod, sorted_codes, prim_boxes, sorted_indices):
             rk.DeviceBuffer(nbytes=16 * (2 * n - 1), fill=0xff), rk.DeviceBuffer(nbytes=32 * (2 * n - 1), fill=0),
             rk.DeviceBuffer(nbytes=4 * (2 * n - 1), fill=0)]
     try:
-        mod.launch("emit_hierarchy_main", n, [bufs[0], bufs[1], bufs[2], C.c_int32(n), bufs[3], bufs[4]], block=1024)
-        mod.launch("refit_bounds_main", n, [bufs[4], C.c_int32(n), bufs[3], bufs[5]], block=1024)
+        mod.launch("emit_hierarchy_main", n, [bufs[0], bufs[1], bufs[2], C.c_int32(n), bufs[3], bufs[4]], block=256)
+        mod.launch("refit_bounds_main", n, [bufs[4], C.c_int32(n), bufs[3], bufs[5]], block=256)
         return bufs[3].read(rk.HLBVH_NODE, 2 * n - 1), bufs[4].read(rk.BBOX, 2 * n - 1)
     finally:
         for b in bufs:

@@ -108,15 +108,32 @@ def test_scene_file_roundtrip(tmp_path):
     assert len(raw) == 16 + 16 + 36 + 4 + 12 + 48 * mesh.GetVertexCount() + 4 * mesh.GetIndexCount()
 
 
-def test_bench_helpers_and_committed_traffic():
-    """bench.py's roofline inputs that do not need a GPU: the committed PMC traffic figure and the texel subsample."""
+def test_bench_helpers_and_committed_counters():
+    """bench.py's roofline inputs that do not need a GPU: the committed PMC record is used only for the kernel source and
+    the configuration it was measured on, and the texel subsample is a fixed pseudo-random set."""
     import json
     import os
+    import types
     import bench
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    traffic = bench.measured_traffic()
-    committed = json.load(open(os.path.join(root, "profiles", "traffic.json")))
-    assert traffic == committed["k_trace_hbm_bytes_per_launch"] and 1e9 < traffic < 1e12
+    opts = capi.default_options()
+    args = types.SimpleNamespace(spp=256, grid=708)
+    rec, why = bench.counter_record(opts, args, 2048, 2048, 1)
+    path = os.path.join(root, "profiles", "k_trace_counters.json")
+    if os.path.exists(path):
+        committed = json.load(open(path))
+        if committed["source_sha256_16"] == bench.kernel_source_hash():
+            assert rec is not None and 1e9 < rec["hbm_side_bytes_per_launch"] < 1e12 and 0 < rec["valu_issue_frac"] <= 1.0
+        else:
+            assert rec is None and "kernel source" in why        # a stale record is refused, not reported
+    else:
+        assert rec is None
+    other, why = bench.counter_record(opts, types.SimpleNamespace(spp=64, grid=708), 1024, 1024, 1)
+    assert other is None                                           # another configuration never inherits the figure
+    r = bench.roofline_record(opts, args, 2048, 2048, 1, (15.0, 1.8), 1 << 30, 76.0)
+    assert r["bytes_per_ray"] == round(64.0 * 16.8 + 40.0 / 256, 1)             # SURVEY §8(d) as written
+    assert r["frac"] == round((1 << 30) * (64.0 * 16.8 + 40.0 / 256) / 76e-3 / 1e9 / 8000.0, 4)
+    assert r["bytes_per_ray_build"] == round(64.0 * 15.0 + 48.0 * 1.8 + 64.0 + 8.0 / 256, 1)
     surfels = np.zeros(64 * 64, dtype=capi.surfel_dtype())
     surfels["texel_x"], surfels["texel_y"] = np.tile(np.arange(64), 64), np.repeat(np.arange(64), 64)
     sub = bench._subsample(surfels, 16)
@@ -125,6 +142,60 @@ def test_bench_helpers_and_committed_traffic():
     assert set(zip(sub["texel_x"].tolist(), sub["texel_y"].tolist())) == set(zip(again["texel_x"].tolist(), again["texel_y"].tolist()))
     on_lattice = np.mean((sub["texel_x"] % 8 == 0) & (sub["texel_y"] % 8 == 0))
     assert on_lattice < 0.06                                     # not aligned with the terrain's noise lattice (1/64 expected)
+
+
+def test_bench_launches_its_own_ranks_or_says_why_not():
+    """`python bench.py --gpus 2` without a launcher starts its own rank processes; on a box with fewer devices (here:
+    none) it says so in one JSON line and exits 0 instead of dying on a missing WORLD_SIZE."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] is None and "needs 2 devices" in line["skipped"]
+
+
+def test_rebalance_rows_levels_the_ranks_and_matches_the_cpp_host():
+    """aobaker_amd.dist.rebalance_rows == aob_rebalance_rows (MultiGpu.cpp), and re-cutting by measured cost converges."""
+    import ctypes as C
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host = C.CDLL(os.path.join(root, "aobaker_amd", "host", "libaobaker_host.so"))
+    rng = np.random.default_rng(4)
+
+    def cpp_rebalance(bounds, ms, height):
+        n = len(ms)
+        out = (C.c_int32 * (n + 1))()
+        assert host.aobhost_rebalance_rows((C.c_int32 * (n + 1))(*bounds), (C.c_double * n)(*ms), n, height, 8, out) == 0
+        return list(out)
+
+    for height in (64, 1000, 2048, 4096, 8192):
+        for parts in (1, 2, 3, 4, 8):
+            eq = aod.equal_rows(height, parts)
+            out = (C.c_int32 * (parts + 1))()
+            assert host.aobhost_equal_rows(height, parts, 8, out) == 0 and list(out) == eq
+            assert eq[0] == 0 and eq[-1] == height and all(a <= b for a, b in zip(eq, eq[1:])) and all(b % 8 == 0 for b in eq[:-1])
+            for _ in range(5):
+                ms = rng.uniform(0.0, 50.0, parts).tolist()
+                got = aod.rebalance_rows(eq, ms, height)
+                assert got == cpp_rebalance(eq, ms, height)
+                assert got[0] == 0 and got[-1] == height and all(a <= b for a, b in zip(got, got[1:]))
+    # a cost profile like the terrain's (cheap borders): measure -> re-cut converges to level ranks
+    height, parts = 4096, 8
+    density = 1.0 - 0.35 * np.abs(np.linspace(-1, 1, height)) ** 4          # cost per row
+    cum = np.concatenate([[0.0], np.cumsum(density)])
+    bounds = aod.equal_rows(height, parts)
+    spread = []
+    for _ in range(4):
+        ms = [cum[bounds[r + 1]] - cum[bounds[r]] for r in range(parts)]
+        spread.append(max(ms) / (sum(ms) / parts))
+        bounds = aod.rebalance_rows(bounds, ms, height)
+    assert spread[0] > 1.05 and spread[-1] < 1.02            # cuts snap to 8-row tile rows: 1.6 % of a 512-row strip
 
 
 def test_row_windows_partition_the_atlas_on_tile_rows():
