@@ -1760,6 +1760,212 @@ int orc_flat_intersect(const AobBvhNode* nodes, uint64_t node_count, const OrcRa
 }
 
 /* ------------------------------------------------------------------------ */
+/* measurement helpers (tests/measure_tree_variants.py): what a change of tree or node width would buy, counted on   */
+/* the CPU before anything is built for the GPU                                                                       */
+
+/* traverse4q over ray records on GIVEN arrays (so that a caller can permute child slots, or pass another tree's
+ * arrays); stats of all rays, and of the rays that hit alone. */
+int orc_walk4q(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const AobLeafTri* tris,
+               const OrcRay* rays, uint64_t n, int32_t any_hit, OrcTraceStats* all, OrcTraceStats* of_hit_rays)
+{
+    int error = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const OrcRay* r = &rays[i];
+        if (r->extra[1] == 0) continue;
+        OrcTraceStats st; memset(&st, 0, sizeof st);
+        float t;
+        const int hit = traverse4q(nq, count4, fr, tris, f3_make(r->o[0], r->o[1], r->o[2]), f3_make(r->d[0], r->d[1], r->d[2]),
+                                   r->o[3], any_hit, &t, &st, &error, NULL);
+        all->rays++; all->inner_visits += st.inner_visits; all->leaf_visits += st.leaf_visits; all->hits += (uint64_t)hit;
+        if (hit && of_hit_rays) { of_hit_rays->rays++; of_hit_rays->inner_visits += st.inner_visits; of_hit_rays->leaf_visits += st.leaf_visits; of_hit_rays->hits++; }
+    }
+    return error;
+}
+
+/* Node visits of a 2^levels-ary collapse of a BVH2 (every `levels` levels become one node; leaf pairs one slot), walked
+ * any-hit in slot order or closest-hit nearest first, on the fp32 boxes.  inner_visits = wide nodes fetched,
+ * leaf_visits = triangle tests, and *box_tests = child boxes tested (a wide node tests all its children). */
+typedef struct { uint32_t ref; float pmin[3], pmax[3]; } KChild;
+static int kary_children(const AobBvhNode* nodes2, uint32_t leaf_base, uint32_t root, int levels, int pairs, KChild* out)
+{
+    /* breadth-wise expansion of `root` by `levels` levels; a leaf or a pair stops early */
+    int k = 0;
+    const AobBvhNode* me = &nodes2[root];
+    out[k].ref = me->addr_left; memcpy(out[k].pmin, me->lmin_or_v0, 12); memcpy(out[k].pmax, me->lmax_or_v1, 12); k++;
+    out[k].ref = me->addr_right; memcpy(out[k].pmin, me->rmin_or_v2, 12); memcpy(out[k].pmax, me->rmax, 12); k++;
+    for (int l = 1; l < levels; l++) {
+        KChild next[64]; int m = 0;
+        for (int j = 0; j < k; j++) {
+            const uint32_t c = out[j].ref;
+            if (c >= leaf_base || (pairs && is_leaf_pair(nodes2, c, leaf_base))) { next[m++] = out[j]; continue; }
+            const AobBvhNode* ch = &nodes2[c];
+            next[m].ref = ch->addr_left; memcpy(next[m].pmin, ch->lmin_or_v0, 12); memcpy(next[m].pmax, ch->lmax_or_v1, 12); m++;
+            next[m].ref = ch->addr_right; memcpy(next[m].pmin, ch->rmin_or_v2, 12); memcpy(next[m].pmax, ch->rmax, 12); m++;
+        }
+        memcpy(out, next, sizeof(KChild) * (size_t)m); k = m;
+    }
+    return k;
+}
+
+int orc_kary_visits(const AobBvhNode* nodes2, uint64_t node_count2, const OrcRay* rays, uint64_t n, int32_t levels, int32_t pairs,
+                    int32_t any_hit, OrcTraceStats* st, uint64_t* box_tests)
+{
+    if (levels < 1 || levels > 5 || node_count2 < 3) return AOB_ERR_INVALID_ARGUMENT;
+    const uint32_t leaf_base = (uint32_t)((node_count2 + 1) / 2 - 1);
+    for (uint64_t i = 0; i < n; i++) {
+        const OrcRay* r = &rays[i];
+        if (r->extra[1] == 0) continue;
+        st->rays++;
+        const f3 o = f3_make(r->o[0], r->o[1], r->o[2]), d = f3_make(r->d[0], r->d[1], r->d[2]);
+        const f3 invdir = safe_invdir(d);
+        const f3 oxinvdir = f3_make(-o.x * invdir.x, -o.y * invdir.y, -o.z * invdir.z);
+        float closest_t = r->o[3];
+        int hit = 0;
+        uint32_t stack[1024]; int sp = 0;
+        stack[sp++] = 0;
+        while (sp) {
+            const uint32_t node = stack[--sp];
+            if (node >= leaf_base || (pairs && is_leaf_pair(nodes2, node, leaf_base))) {
+                const uint32_t first = node >= leaf_base ? node : nodes2[node].addr_left;
+                const int cnt = node >= leaf_base ? 1 : 2;
+                float best = closest_t;
+                for (int q = 0; q < cnt; q++) {
+                    const AobBvhNode* lf = &nodes2[first + (uint32_t)q];
+                    st->leaf_visits++;
+                    const float t = intersect_triangle(o, d, f3_make(lf->lmin_or_v0[0], lf->lmin_or_v0[1], lf->lmin_or_v0[2]),
+                                                       f3_make(lf->lmax_or_v1[0], lf->lmax_or_v1[1], lf->lmax_or_v1[2]),
+                                                       f3_make(lf->rmin_or_v2[0], lf->rmin_or_v2[1], lf->rmin_or_v2[2]), closest_t);
+                    if (t < best) best = t;
+                }
+                if (best < closest_t) { closest_t = best; hit = 1; if (any_hit) break; }
+                continue;
+            }
+            st->inner_visits++;
+            KChild ch[64];
+            const int k = kary_children(nodes2, leaf_base, node, levels, pairs, ch);
+            *box_tests += (uint64_t)k;
+            float key[64]; int idx[64]; int m = 0;
+            for (int j = 0; j < k; j++) {
+                float t0, t1;
+                intersect_bbox(ch[j].pmin, ch[j].pmax, invdir, oxinvdir, closest_t, &t0, &t1);
+                if (t0 <= t1) { key[m] = any_hit ? (float)j : t0; idx[m] = j; m++; }
+            }
+            /* defer farthest (or last) first so that the nearest (or first) is popped next */
+            for (int a = 1; a < m; a++) { const float kk = key[a]; const int ii = idx[a]; int b = a - 1; while (b >= 0 && key[b] > kk) { key[b + 1] = key[b]; idx[b + 1] = idx[b]; b--; } key[b + 1] = kk; idx[b + 1] = ii; }
+            if (sp + m > 1024) return AOB_ERR_BVH_TOO_DEEP;
+            for (int a = m - 1; a >= 0; a--) stack[sp++] = ch[idx[a]].ref;
+        }
+        st->hits += (uint64_t)hit;
+    }
+    return 0;
+}
+
+/* A top-down binned-SAH BVH2 (16 bins per axis, one triangle per leaf) in the AobBvhNode layout — the tree quality a
+ * treelet-restructuring pass over the PLOC tree could approach at best.  CPU only; never built on the GPU. */
+typedef struct { uint32_t begin, end, index; } SahTask;
+uint64_t orc_bvh_build_sah(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes, uint32_t* depth_out)
+{
+    if (depth_out) *depth_out = 0;
+    if (n == 0) return 0;
+    Box* pb = (Box*)malloc(sizeof(Box) * n);
+    float (*cen)[3] = malloc(sizeof(float[3]) * n);
+    uint32_t* order = (uint32_t*)malloc(4 * n);
+    for (uint64_t i = 0; i < n; i++) {
+        order[i] = (uint32_t)i;
+        for (int k = 0; k < 3; k++) {
+            pb[i].pmin[k] = fminf(fminf(tris[i].v[0][k], tris[i].v[1][k]), tris[i].v[2][k]);
+            pb[i].pmax[k] = fmaxf(fmaxf(tris[i].v[0][k], tris[i].v[1][k]), tris[i].v[2][k]);
+            cen[i][k] = 0.5f * (pb[i].pmin[k] + pb[i].pmax[k]);
+        }
+    }
+    const uint64_t node_count = 2 * n - 1;
+    memset(nodes, 0, sizeof(AobBvhNode) * node_count);
+    if (n == 1) {
+        memcpy(nodes[0].lmin_or_v0, tris[0].v[0], 12); memcpy(nodes[0].lmax_or_v1, tris[0].v[1], 12); memcpy(nodes[0].rmin_or_v2, tris[0].v[2], 12);
+        nodes[0].addr_left = AOB_INVALID_ADDR; nodes[0].shape_id = tris[0].shape_id; nodes[0].prim_id = tris[0].prim_id;
+        free(pb); free(cen); free(order); return 1;
+    }
+    /* a node over order[begin, end): inner index handed out in creation order; a range of one triangle is leaf n-1+begin */
+    SahTask* todo = (SahTask*)malloc(sizeof(SahTask) * n);
+    uint32_t* depth_of = (uint32_t*)calloc(n, 4);
+    uint64_t top = 0; uint32_t next_inner = 1, max_depth = 0;
+    todo[top].begin = 0; todo[top].end = (uint32_t)n; todo[top].index = 0; top++;
+    const uint32_t leaf_base = (uint32_t)(n - 1);
+    enum { BINS = 16 };
+    while (top) {
+        const SahTask t = todo[--top];
+        const uint32_t b = t.begin, e = t.end, cnt = e - b;
+        float cmin[3] = { INFINITY, INFINITY, INFINITY }, cmax[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for (uint32_t i = b; i < e; i++) for (int k = 0; k < 3; k++) { cmin[k] = fminf(cmin[k], cen[order[i]][k]); cmax[k] = fmaxf(cmax[k], cen[order[i]][k]); }
+        int best_axis = -1, best_split = 0; float best_cost = INFINITY;
+        for (int ax = 0; ax < 3; ax++) {
+            const float ext = cmax[ax] - cmin[ax];
+            if (!(ext > 0.0f)) continue;
+            Box bb[BINS]; uint32_t bc[BINS];
+            for (int q = 0; q < BINS; q++) { bc[q] = 0; for (int k = 0; k < 3; k++) { bb[q].pmin[k] = INFINITY; bb[q].pmax[k] = -INFINITY; } }
+            for (uint32_t i = b; i < e; i++) {
+                int q = (int)((cen[order[i]][ax] - cmin[ax]) / ext * (float)BINS); if (q >= BINS) q = BINS - 1; if (q < 0) q = 0;
+                bc[q]++; box_union(&bb[q], &bb[q], &pb[order[i]]);
+            }
+            float right_area[BINS]; uint32_t right_cnt[BINS];
+            Box acc; for (int k = 0; k < 3; k++) { acc.pmin[k] = INFINITY; acc.pmax[k] = -INFINITY; }
+            uint32_t c = 0;
+            for (int q = BINS - 1; q > 0; q--) {
+                c += bc[q]; if (bc[q]) box_union(&acc, &acc, &bb[q]);
+                const float dx = acc.pmax[0] - acc.pmin[0], dy = acc.pmax[1] - acc.pmin[1], dz = acc.pmax[2] - acc.pmin[2];
+                right_area[q] = c ? dx * dy + dy * dz + dz * dx : 0.0f; right_cnt[q] = c;
+            }
+            for (int k = 0; k < 3; k++) { acc.pmin[k] = INFINITY; acc.pmax[k] = -INFINITY; }
+            c = 0;
+            for (int q = 0; q < BINS - 1; q++) {
+                c += bc[q]; if (bc[q]) box_union(&acc, &acc, &bb[q]);
+                if (c == 0 || right_cnt[q + 1] == 0) continue;
+                const float dx = acc.pmax[0] - acc.pmin[0], dy = acc.pmax[1] - acc.pmin[1], dz = acc.pmax[2] - acc.pmin[2];
+                const float cost = (dx * dy + dy * dz + dz * dx) * (float)c + right_area[q + 1] * (float)right_cnt[q + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = ax; best_split = q + 1; }
+            }
+        }
+        uint32_t mid;
+        if (best_axis < 0) mid = b + cnt / 2;       /* all centres coincide: split the list in half */
+        else {
+            const float ext = cmax[best_axis] - cmin[best_axis];
+            uint32_t i = b, j = e;
+            while (i < j) {
+                int q = (int)((cen[order[i]][best_axis] - cmin[best_axis]) / ext * (float)BINS); if (q >= BINS) q = BINS - 1; if (q < 0) q = 0;
+                if (q < best_split) i++; else { j--; const uint32_t tmp = order[i]; order[i] = order[j]; order[j] = tmp; }
+            }
+            mid = i;
+            if (mid == b || mid == e) mid = b + cnt / 2;
+        }
+        const uint32_t ranges[2][2] = { { b, mid }, { mid, e } };
+        uint32_t child[2];
+        for (int s2 = 0; s2 < 2; s2++) {
+            const uint32_t cb = ranges[s2][0], ce = ranges[s2][1];
+            if (ce - cb == 1) { child[s2] = leaf_base + cb; if (depth_of[t.index] + 1 > max_depth) max_depth = depth_of[t.index] + 1; }
+            else {
+                child[s2] = next_inner++;
+                depth_of[child[s2]] = depth_of[t.index] + 1;
+                todo[top].begin = cb; todo[top].end = ce; todo[top].index = child[s2]; top++;
+            }
+            Box cbx; for (int k = 0; k < 3; k++) { cbx.pmin[k] = INFINITY; cbx.pmax[k] = -INFINITY; }
+            for (uint32_t i = cb; i < ce; i++) box_union(&cbx, &cbx, &pb[order[i]]);
+            AobBvhNode* nd = &nodes[t.index];
+            if (s2 == 0) { memcpy(nd->lmin_or_v0, cbx.pmin, 12); memcpy(nd->lmax_or_v1, cbx.pmax, 12); nd->addr_left = child[0]; }
+            else { memcpy(nd->rmin_or_v2, cbx.pmin, 12); memcpy(nd->rmax, cbx.pmax, 12); nd->addr_right = child[1]; }
+        }
+    }
+    for (uint64_t p = 0; p < n; p++) {
+        AobBvhNode* nd = &nodes[leaf_base + p];
+        const OrcTriangle* tr = &tris[order[p]];
+        memcpy(nd->lmin_or_v0, tr->v[0], 12); memcpy(nd->lmax_or_v1, tr->v[1], 12); memcpy(nd->rmin_or_v2, tr->v[2], 12);
+        nd->addr_left = AOB_INVALID_ADDR; nd->addr_right = 0; nd->shape_id = tr->shape_id; nd->prim_id = tr->prim_id;
+    }
+    if (depth_out) *depth_out = max_depth;
+    free(depth_of); free(todo); free(order); free(cen); free(pb);
+    return node_count;
+}
+
+/* ------------------------------------------------------------------------ */
 /* resolve + bleed + format conversion                                       */
 
 static inline int32_t as_i32(uint32_t u) { return (int32_t)u; }

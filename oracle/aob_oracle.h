@@ -182,6 +182,13 @@ int orc_two_level_intersect(const AobBvhNode* tlas, uint64_t tlas_count, const O
 int orc_flat_intersect(const AobBvhNode* nodes, uint64_t node_count, const OrcRay* rays, uint64_t n, int32_t any_hit,
                        OrcIntersection* hits, OrcTraceStats* st);
 
+/* ---- measurement helpers (tests/measure_tree_variants.py) ---------------------------------------------------------- */
+int orc_walk4q(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const AobLeafTri* tris,
+               const OrcRay* rays, uint64_t n, int32_t any_hit, OrcTraceStats* all, OrcTraceStats* of_hit_rays);
+int orc_kary_visits(const AobBvhNode* nodes2, uint64_t node_count2, const OrcRay* rays, uint64_t n, int32_t levels, int32_t pairs,
+                    int32_t any_hit, OrcTraceStats* st, uint64_t* box_tests);
+uint64_t orc_bvh_build_sah(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes, uint32_t* depth);
+
 #ifdef __cplusplus
 }
 #endif

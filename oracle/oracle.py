@@ -75,6 +75,9 @@ def load():
         "orc_morton_codes": (None, [vp, u64, C.c_int, vp, vp, vp]),
         "orc_two_level_intersect": (C.c_int, [vp, u64, vp, vp, vp, vp, u64, i32, vp, P(OrcTraceStats), P(OrcTraceStats)]),
         "orc_flat_intersect": (C.c_int, [vp, u64, vp, u64, i32, vp, P(OrcTraceStats)]),
+        "orc_walk4q": (C.c_int, [vp, u64, vp, vp, vp, u64, i32, P(OrcTraceStats), P(OrcTraceStats)]),
+        "orc_kary_visits": (C.c_int, [vp, u64, vp, u64, i32, i32, i32, P(OrcTraceStats), P(u64)]),
+        "orc_bvh_build_sah": (u64, [vp, u64, vp, P(u32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -421,6 +424,40 @@ def two_level_scene(scene, builder=None, adaptive=None):
     fake["prim_id"] = np.arange(len(boxes), dtype=np.uint32)
     tlas = bvh_build(fake, builder, adaptive)[0]
     return tlas, np.concatenate(instances), blas_list
+
+
+def walk4q(nodes4q, frame, leaf_tris, rays, any_hit=True):
+    """(stats of all rays, stats of the rays that hit) of traverse4q on the given arrays."""
+    nodes4q = np.ascontiguousarray(nodes4q, dtype=np.uint32)
+    frame = np.ascontiguousarray(frame, dtype=np.float32)
+    leaf_tris, rays = np.ascontiguousarray(leaf_tris), np.ascontiguousarray(rays)
+    a, h = OrcTraceStats(), OrcTraceStats()
+    rc = load().orc_walk4q(nodes4q.ctypes.data, len(nodes4q), frame.ctypes.data, leaf_tris.ctypes.data, rays.ctypes.data, len(rays),
+                           int(bool(any_hit)), C.byref(a), C.byref(h))
+    if rc != 0:
+        raise RuntimeError(f"orc_walk4q failed: {rc}")
+    return a, h
+
+
+def kary_visits(nodes2, rays, levels, pairs=True, any_hit=True):
+    """(stats, box tests) of a 2^levels-ary collapse of the BVH2 walked on fp32 boxes."""
+    nodes2, rays = np.ascontiguousarray(nodes2), np.ascontiguousarray(rays)
+    st, boxes = OrcTraceStats(), C.c_uint64()
+    rc = load().orc_kary_visits(nodes2.ctypes.data, len(nodes2), rays.ctypes.data, len(rays), levels, int(bool(pairs)), int(bool(any_hit)),
+                                C.byref(st), C.byref(boxes))
+    if rc != 0:
+        raise RuntimeError(f"orc_kary_visits failed: {rc}")
+    return st, boxes.value
+
+
+def bvh_build_sah(tris):
+    """Top-down binned-SAH BVH2 (measurement only)."""
+    tris = np.ascontiguousarray(tris)
+    n = len(tris)
+    nodes = np.zeros(max(1, 2 * n), dtype=capi.node_dtype())
+    depth = C.c_uint32()
+    cnt = int(load().orc_bvh_build_sah(tris.ctypes.data, n, nodes.ctypes.data, C.byref(depth)))
+    return nodes[:cnt], depth.value
 
 
 def default_options():

@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 n=0
 for c in "$@"; do
     n=$((n + 1))
-    timeout -k 10 150 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$O/pass$n" -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > "$O/pass$n.log" 2>&1 || { echo "pass $n ($c) failed"; exit 1; }
+    timeout -k 10 150 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$O/pass$n" -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-cpp-host --no-wallclock > "$O/pass$n.log" 2>&1 || { echo "pass $n ($c) failed"; exit 1; }
     echo "pass $n done: $c"
 done
 python3 "$R/tools/pmc_summary.py" "$O" > "$O/summary.json" && cat "$O/summary.json"
