@@ -5,13 +5,15 @@
  * include, link, load or call this.  Callers: tests/, __graft_entry__.smoke()
  * and bench.py's cpu_baseline leg.
  *
- * PARITY UNPINNED: the reference (epicabsol/aobaker) has no tests, golden
- * vectors or fixtures for this path, and neither its D3D11/HLSL pipeline nor
- * the stripped RadeonRays 2.0 library can be built or run here (SURVEY.md
- * §8(c)).  The oracle is pinned only by (i) the widely known MSVC rand()
- * sequence the reference's sampler draws from, (ii) closed-form geometry
- * (tests/test_oracle_*.py) and (iii) the in-tree OpenCL arithmetic it follows
- * line by line (kernels/CL/common.cl, intersect_bvh2_lds.cl, build_hlbvh.cl).
+ * PARITY: the reference (epicabsol/aobaker) has no tests, golden vectors or fixtures for this path, and its host
+ * program (D3D11/HLSL + the stripped RadeonRays 2.0 library) cannot be built here.  What CAN be
+ * built is the device code RadeonRays runs: oracle/ref_kernels.mk compiles kernels/CL/intersect_bvh2_lds.cl,
+ * build_hlbvh.cl and intersect_bvh2level_skiplinks.cl from /root/reference for gfx950, and
+ * tests/test_gpu_reference_kernels.py runs them on the GPU against this file — traverse(), intersect_triangle(),
+ * intersect_bbox(), the Morton codes and the LBVH hierarchy + refit are PINNED that way, bit for bit, and so are the
+ * ray records (orc_generate_rays) and the scoring (orc_process_intersections) through the cells they produce from the
+ * reference kernel's hits.  The rasteriser and the resolve have no runnable reference: they stay pinned only by the
+ * closed forms and known-answer tests of tests/test_oracle_kat.py, and by the MSVC rand() sequence for the sampler.
  *
  * Every function cites the reference file:line it restates.  The POD types
  * of the boundary (AobOptions, AobSceneDesc, AobSurfel, AobBvhNode,

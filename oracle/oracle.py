@@ -2,7 +2,8 @@
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
 bench.py's cpu_baseline leg.  The product (aobaker_amd/) never imports this.
-PARITY UNPINNED against the reference binary (see aob_oracle.h).
+Traversal, intersection and the LBVH build are pinned against the reference's own OpenCL kernels run on the GPU
+(oracle/ref_kernels.mk, tests/test_gpu_reference_kernels.py); see aob_oracle.h for what is not.
 """
 from __future__ import annotations
 

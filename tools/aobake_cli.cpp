@@ -4,7 +4,7 @@
 // 1-channel 8-bit textures).
 //
 //   aobake_cli --scene <file.aobs> --out <prefix> [--spp N] [--sampler 0|1] [--accumulate 0|1]
-//   aobake_cli --obj <file.obj> [--atlas W [--atlas-height H]] [--channels C] [--bpc B] --out <prefix> [--png] [--exr] ...
+//   aobake_cli --obj <file.obj> [--atlas W [--atlas-height H]] [--channels C] [--bpc B] --out <prefix> [--png] [--exr] [--gpus N] ...
 //
 // --obj imports a Wavefront OBJ through BakeObject::LoadFromFile (the reference's import conventions, Assets.cpp);
 // --png also saves every AO texture through BakeTexture::SavePNG, as the reference's "Save AO..." button does;
@@ -43,6 +43,7 @@ int main(int argc, char** argv)
 		else if (a == "--atlas-height") atlas_h = std::atoi(next());
 		else if (a == "--channels") channels = std::atoi(next());
 		else if (a == "--bpc") bpc = std::atoi(next());
+		else if (a == "--gpus") BakeEngine::SetDeviceCount(std::atoi(next()));   // 0 = every visible device (include/aobaker_multi.h)
 		else if (a == "--png") png = true;
 		else if (a == "--exr") exr = true;
 		else if (a == "--out") out = next();
