@@ -164,7 +164,7 @@ void aob_default_options(AobOptions* o)
     o->raster_mode = AOB_RASTER_REFERENCE;
     o->raster_layers = AOB_LAYERS_LAST;
     // schedule of k_trace: the measured optima on BASELINE configs[2]
-    o->trace_refill_idle = 24;
+    o->trace_refill_idle = 0;     // by scoring mode: 42 where a ray is a miss counter (COSINE sampler, any hit), else 24 (trace.hip)
     o->trace_leaf_wait = 16;
     o->trace_parts = 4;
     o->trace_part_min = 16;

@@ -423,7 +423,9 @@ void k_emit_nodes4q(uint32_t count4, const float4* __restrict__ nodes4, const fl
     for (int j = 0; j < 4; j++) {
         const float4 lo = nodes4[8ull * i + j], hi = nodes4[8ull * i + 4 + j];
         uint32_t ref = __float_as_uint(lo.w);
-        uint4 o = make_uint4(0u, 0u, 0u, ref);
+        // an empty slot is an INVERTED box — min plane 0x7fff, max plane 0 on every axis: its near distance exceeds its far
+        // distance for every ray, so the walk needs no test of the ref (trace.hip)
+        uint4 o = make_uint4(0x8000ffffu, 0x8000ffffu, 0x8000ffffu, ref);
         if (ref != 0xffffffffu) {
             if (ref < 0x80000000u) o.w = packed_index[ref];
             o.x = 0x80008000u | quant_down(lo.x, frame[0], frame[3]) | quant_up(hi.x, frame[0], frame[3]) << 16;

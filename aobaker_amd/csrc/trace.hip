@@ -41,6 +41,8 @@ namespace aob {
 static constexpr int kWave = 64;                  // threads per workgroup: one wavefront
 static constexpr uint32_t kInvalid = 0xffffffffu;
 typedef float v2f __attribute__((ext_vector_type(2)));    // a register pair for v_pk_fma_f32
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 as_uint4(v4u v) { return make_uint4(v.x, v.y, v.z, v.w); }
 
 struct TraceParams {
     const float4* nodes;
@@ -126,6 +128,8 @@ void k_trace(TraceParams p)
         q_origin = make_f3(fmaf(-32768.0f, q_scale.x, q_origin.x), fmaf(-32768.0f, q_scale.y, q_origin.y), fmaf(-32768.0f, q_scale.z, q_origin.z));
         q_scale = make_f3(q_scale.x * 32768.0f, q_scale.y * 32768.0f, q_scale.z * 32768.0f);
     }
+    // the quantised 4-ary nodes as a raw buffer (base in SGPRs, 4 GiB window: 64 Mi nodes — trace_range checks the count)
+    const __amdgpu_buffer_rsrc_t nodes_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.nodes4q, 0, 0xffffffff, 0x00020000);
     // overflow stack entry e of this lane lives at gstack[(e * gridDim.x + blockIdx.x) * 64 + lane] (computed on use:
     // the path is cold and the registers are better spent on occupancy)
     auto gs_slot = [&](int e) -> uint32_t* { return p.gstack + ((uint64_t)e * gridDim.x + blockIdx.x) * kWave + lane; };
@@ -370,8 +374,12 @@ void k_trace(TraceParams p)
         if (inner) {
           if (QUANT == 2) {
             // ---- 4-ary node: four slab tests per visit, children ranked only when the order matters ----
-            const uint4* np = p.nodes4q + 4ull * addr;
-            const uint4 c0 = np[0], c1 = np[1], c2 = np[2], c3 = np[3];
+            // buffer loads: a 32-bit byte offset off an SGPR resource (one v_lshlrev) instead of a 64-bit address per lane
+            const uint32_t noff = addr << 6;
+            const uint4 c0 = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(nodes_rsrc, noff, 0, 0)),
+                        c1 = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(nodes_rsrc, noff + 16u, 0, 0)),
+                        c2 = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(nodes_rsrc, noff + 32u, 0, 0)),
+                        c3 = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(nodes_rsrc, noff + 48u, 0, 0));
             auto slab = [&](const uint4& c, float& tn) -> bool {
                 // two v_perm_b32 and one v_pk_fma_f32 per axis: (t_near, t_far) = (f_near, f_far) * invdir + oxinvdir
                 constexpr uint32_t kHalf = 0x3f000000u;
@@ -394,9 +402,9 @@ void k_trace(TraceParams p)
                 return tn <= tf;
             };
             float k0, k1, k2, k3;
-            // an empty slot is excluded by its ref; slot 0 of a node is never empty
-            const bool h0 = slab(c0, k0), h1 = slab(c1, k1) && c1.w != kInvalid, h2 = slab(c2, k2) && c2.w != kInvalid,
-                       h3 = slab(c3, k3) && c3.w != kInvalid;
+            // an empty slot holds an inverted box (min plane above max plane on every axis, bvh_build.hip k_emit_nodes4q): its
+            // near distance exceeds its far distance whatever the ray, so it fails the test by itself — no compare of the ref
+            const bool h0 = slab(c0, k0), h1 = slab(c1, k1), h2 = slab(c2, k2), h3 = slab(c3, k3);
             if (!(h0 || h1 || h2 || h3)) {
                 addr = pop();
             } else if (ANYHIT) {
@@ -577,6 +585,7 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
         p.node_count = (uint32_t)b->node_count;
         p.leaf_base = b->triangle_count ? (uint32_t)(b->triangle_count - 1) : 0u;
         if (quant == 2) p.leaf_base = 0x80000000u;          // 4-ary refs: leaf = 0x80000000 | triangle, inner = node index
+        if (quant == 2 && b->triangle_count >= (1ull << 26)) { set_error("the quantised 4-ary walk addresses its nodes with 32-bit byte offsets: at most 2^26 triangles (use bvh_width 2)"); return AOB_ERR_UNSUPPORTED; }
         p.spp = o.sample_count;
         p.seed_hash = host_pcg(o.seed);
         p.tmax = o.ray_tmax; p.falloff = o.falloff_distance;
@@ -588,7 +597,10 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
         p.inv_tmax = 1.0f / p.tmax;
         p.bias = o.ray_bias;
         p.hidden_from_others = b->hidden_from_others;
-        p.refill_idle = knob(o.trace_refill_idle, 24);
+        // Measured (profiles/r02/trace_knob_sweep.jsonl, shapes.jsonl): with unit weights and any-hit scoring the walk is fastest
+        // when 42 lanes wait for a refill (fresh rays of one sample start together and share the top of the tree: configs[2]
+        // 76.2 -> 74.1 ms, configs[1] +5 %); closest-hit and weighted scoring keep 24 (configs[4] loses 4.5 % at 42)
+        p.refill_idle = knob(o.trace_refill_idle, (o.sampler == AOB_SAMPLER_COSINE && o.use_any_hit) ? 42 : 24);
         p.leaf_wait = knob(o.trace_leaf_wait, 16);
         cosine_grid(o.sample_count, p.grid);
         // one launch per section: two sections of a material may cover the same texel, and

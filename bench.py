@@ -325,7 +325,7 @@ def cpp_host_leg(scene, world, args):
                    "--spp", str(args.spp), "--sampler", "1", "--accumulate", "1", "--seed", "3", "--any-hit", "1", "--normal-fp16", "0"]
             if args.no_balance:
                 cmd.append("--no-balance")
-            out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=180)
         if out.returncode != 0:
             return {"error": f"rc {out.returncode}: {out.stderr.strip()[-300:]}"}
         return json.loads(out.stdout.strip().splitlines()[-1])

@@ -107,7 +107,8 @@ typedef struct AobOptions {
     /* Schedule of the fused trace kernel (trace.hip).  These six move work between wavefronts and never change a result
      * cell (tests/test_gpu_parity.py::test_trace_schedule_knobs_do_not_change_results).  aob_default_options writes the
      * values measured fastest on MI355X for BASELINE configs[2]; 0 in any of them also means "that default". */
-    int32_t  trace_refill_idle;   /* lanes of a wavefront without a ray that trigger the refill section: 1..64, default 24 */
+    int32_t  trace_refill_idle;   /* lanes of a wavefront without a ray that trigger the refill section: 1..64; default 0 = by
+                                     scoring mode: 42 with the COSINE sampler and any-hit scoring, 24 otherwise            */
     int32_t  trace_leaf_wait;     /* lanes parked at a leaf that trigger the leaf section: 1..64, default 16               */
     int32_t  trace_parts;         /* sample parts a tile's rays are cut into (units of one work queue), default 4          */
     int32_t  trace_part_min;      /* a part holds at least this many samples, default 16                                   */
@@ -233,7 +234,8 @@ typedef struct AobBvh2QNode { uint32_t w[8]; } AobBvh2QNode;
 typedef struct AobQuantFrame { float origin[3]; float scale[3]; } AobQuantFrame;
 /* 64 B 4-ary node with quantised child boxes (same grid and rounding as AobBvh2QNode): child j is
  * w[4j..4j+2] = x, y, z words and w[4j+3] = ref_j (as in AobBvh4Node); an empty slot has
- * ref = AOB_INVALID_ADDR and zero words.  A word is (0x8000 | min) | (0x8000 | max) << 16: bit 15 of each
+ * ref = AOB_INVALID_ADDR and the words 0x8000ffff — an inverted box (min plane 0x7fff, max plane 0) that no ray enters, so the
+ * walk does not test the ref.  A word is (0x8000 | min) | (0x8000 | max) << 16: bit 15 of each
  * half is set so that the bytes {0x3f, half>>8, half&0xff, 0x00} are the IEEE float 1 + q/32768 — one
  * v_perm_b32 per plane in the traversal; decode q = half & 0x7fff.  The array is packed (no records for the
  * collapsed-away levels): inner refs index this array, not AobBvh4Node[].  Walked one lane per ray

@@ -998,7 +998,7 @@ uint64_t orc_bvh4q_build(const AobBvh4Node* nodes4, uint64_t count4, const AobQu
             const float* lo = nodes4[i].lo[j]; const float* hi = nodes4[i].hi[j];
             uint32_t ref; memcpy(&ref, &lo[3], 4);
             uint32_t* w = &o->w[4 * j];
-            w[0] = w[1] = w[2] = 0; w[3] = ref;
+            w[0] = w[1] = w[2] = 0x8000ffffu; w[3] = ref;       /* an empty slot: the inverted box (min plane 0x7fff, max plane 0) no ray enters */
             if (ref == AOB_INVALID_ADDR) continue;
             if (!(ref & AOB_LEAF_FLAG)) w[3] = packed[ref];
             for (int k = 0; k < 3; k++)
@@ -1068,7 +1068,8 @@ static inline int traverse4q(const AobBvh4QNode* nq, uint64_t count4, const AobQ
                 if (any_hit) t0 = t0 != t0 ? 0.0f : fminf(fmaxf(t0, 0.0f), 1.0f);
                 else { t0 = fmaxf(t0, 0.0f); t1 = fminf(t1, closest_t); }
                 ref[j] = c[3];
-                chit[j] = t0 <= t1 && ref[j] != AOB_INVALID_ADDR;
+                chit[j] = t0 <= t1;                      /* an empty slot's inverted box fails this by itself */
+                if (chit[j] && ref[j] == AOB_INVALID_ADDR) { *error = AOB_ERR_INVALID_ARGUMENT; *t_out = t_max; return 0; }   /* (never: asserted) */
                 key[j] = chit[j] ? t0 : INFINITY;
                 nhit += chit[j];
             }
@@ -1711,12 +1712,15 @@ int orc_two_level_intersect(const AobBvhNode* tlas, uint64_t tlas_count, const O
                     st_top->leaf_visits++;
                     const OrcInstance* in = &instances[nd->prim_id];
                     const float* m = in->world_to_object;
-                    const f3 oo = f3_make(fmaf(m[2], o.z, fmaf(m[1], o.y, m[0] * o.x)) + m[3],
-                                          fmaf(m[6], o.z, fmaf(m[5], o.y, m[4] * o.x)) + m[7],
-                                          fmaf(m[10], o.z, fmaf(m[9], o.y, m[8] * o.x)) + m[11]);
-                    const f3 od = f3_make(fmaf(m[2], d.z, fmaf(m[1], d.y, m[0] * d.x)),
-                                          fmaf(m[6], d.z, fmaf(m[5], d.y, m[4] * d.x)),
-                                          fmaf(m[10], d.z, fmaf(m[9], d.y, m[8] * d.x)));
+                    /* transform_point / transform_vector (:105-121) are written `m.s0*p.x + m.s1*p.y + m.s2*p.z (+ m.s3)`; OpenCL C
+                     * contracts that to fma(m.s2, p.z, fma(m.s0, p.x, m.s1*p.y)) (+ m.s3) — the SECOND product is the rounded one
+                     * (the ROCm clang's code for the reference's source; the GPU test pins it) */
+                    const f3 oo = f3_make(fmaf(m[2], o.z, fmaf(m[0], o.x, m[1] * o.y)) + m[3],
+                                          fmaf(m[6], o.z, fmaf(m[4], o.x, m[5] * o.y)) + m[7],
+                                          fmaf(m[10], o.z, fmaf(m[8], o.x, m[9] * o.y)) + m[11]);
+                    const f3 od = f3_make(fmaf(m[2], d.z, fmaf(m[0], d.x, m[1] * d.y)),
+                                          fmaf(m[6], d.z, fmaf(m[4], d.x, m[5] * d.y)),
+                                          fmaf(m[10], d.z, fmaf(m[8], d.x, m[9] * d.y)));
                     float t; uint32_t leaf;
                     const int h = traverse_addr(blas_nodes[in->blas], blas_counts[in->blas], oo, od, closest_t, any_hit, &t, st_bottom,
                                                 &error, NULL, &leaf);

@@ -163,3 +163,94 @@ def hierarchy(module: Module, sorted_codes: np.ndarray, prim_boxes: np.ndarray, 
     finally:
         for b in bufs:
             b.free()
+
+
+# ---- intersect_bvh2level_skiplinks.cl ------------------------------------------------------------------------------
+
+SHAPE = np.dtype([("id", "<i4"), ("bvh_idx", "<i4"), ("disabled", "<u4"), ("padding", "<i4"), ("m", "<f4", (4, 4)),
+                  ("velocity_linear", "<f4", 4), ("velocity_angular", "<f4", 4)])          # Shape :75-92, 112 B
+FACE = np.dtype([("idx", "<i4", 3), ("shape_id", "<i4"), ("prim_id", "<i4")])              # Face :94-102, 20 B
+
+
+def _skiplinks(nodes2, out, payload_of_leaf):
+    """Appends the BVH2 `nodes2` (AobBvhNode[]: child boxes in the parent, leaves at [n-1, 2n-1)) to `out` in the layout
+    intersect_bvh2level_skiplinks.cl walks (:41-47): one bbox per node, the left child right behind its parent, pmin.w = -1
+    for an inner node or (payload << 4 | 1) for a leaf, pmax.w = the node to go to after this subtree (-1: none).
+    Returns the root's index in `out`."""
+    n = (len(nodes2) + 1) // 2
+    leaf_base = n - 1
+    base = len(out)
+    if n == 1:
+        v = np.stack([nodes2[0]["lmin_or_v0"], nodes2[0]["lmax_or_v1"], nodes2[0]["rmin_or_v2"]])
+        out.append((v.min(axis=0), float((payload_of_leaf(0) << 4) | 1), v.max(axis=0), -1.0))
+        return base
+    size = np.ones(len(nodes2), dtype=np.int64)
+    order, stack = [], [0]
+    while stack:
+        i = stack.pop()
+        order.append(i)
+        if i < leaf_base:
+            stack += [int(nodes2[i]["addr_left"]), int(nodes2[i]["addr_right"])]
+    for i in reversed(order):
+        if i < leaf_base:
+            size[i] = 1 + size[int(nodes2[i]["addr_left"])] + size[int(nodes2[i]["addr_right"])]
+    root = nodes2[0]
+    root_box = (np.minimum(root["lmin_or_v0"], root["rmin_or_v2"]), np.maximum(root["lmax_or_v1"], root["rmax"]))
+    todo = [(0, root_box, -1)]                     # (BVH2 node, its box, next) — a stack that emits in preorder
+    while todo:
+        i, (lo, hi), nxt = todo.pop()
+        at = len(out)
+        if i >= leaf_base:
+            out.append((lo, float((payload_of_leaf(i - leaf_base) << 4) | 1), hi, float(nxt)))
+            continue
+        out.append((lo, -1.0, hi, float(nxt)))
+        nd = nodes2[i]
+        l, r = int(nd["addr_left"]), int(nd["addr_right"])
+        right_at = at + 1 + int(size[l])
+        todo.append((r, (nd["rmin_or_v2"], nd["rmax"]), nxt))
+        todo.append((l, (nd["lmin_or_v0"], nd["lmax_or_v1"]), right_at))       # popped first: lands at at + 1
+    return base
+
+
+def two_level_buffers(tlas, instances, blas_list):
+    """The reference's buffers for a two-level scene made by oracle.two_level_scene: (nodes bbox[], vertices float4[],
+    faces Face[], shapes Shape[], root_idx)."""
+    out, verts, faces, roots = [], [], [], []
+    for b in blas_list:
+        n = (len(b) + 1) // 2
+        leaves = b[n - 1:] if n > 1 else b
+        first_face = len(faces)
+        for k, lf in enumerate(leaves):
+            v0 = len(verts)
+            verts += [np.append(lf["lmin_or_v0"], 0), np.append(lf["lmax_or_v1"], 0), np.append(lf["rmin_or_v2"], 0)]
+            faces.append(((v0, v0 + 1, v0 + 2), 0, int(lf["prim_id"])))
+        roots.append(_skiplinks(b, out, lambda p, f=first_face: f + p))
+    shapes = np.zeros(len(instances), dtype=SHAPE)
+    for k, inst in enumerate(instances):
+        shapes[k]["id"] = int(inst["shape_id"])
+        shapes[k]["bvh_idx"] = roots[int(inst["blas"])]
+        shapes[k]["m"][:3] = inst["world_to_object"].reshape(3, 4)
+        shapes[k]["m"][3] = (0, 0, 0, 1)
+    ntl = (len(tlas) + 1) // 2
+    tl_leaves = tlas[ntl - 1:] if ntl > 1 else tlas
+    root_idx = _skiplinks(tlas, out, lambda p: int(tl_leaves[p]["prim_id"]))
+    nodes = np.zeros(len(out), dtype=BBOX)
+    for k, (lo, w0, hi, w1) in enumerate(out):
+        nodes[k]["pmin"][:3], nodes[k]["pmin"][3], nodes[k]["pmax"][:3], nodes[k]["pmax"][3] = lo, w0, hi, w1
+    f = np.zeros(len(faces), dtype=FACE)
+    for k, (idx, sid, pid) in enumerate(faces):
+        f[k]["idx"], f[k]["shape_id"], f[k]["prim_id"] = idx, sid, pid
+    return nodes, np.array(verts, dtype=np.float32), f, shapes, root_idx
+
+
+def intersect_two_level(module: Module, nodes, vertices, faces, shapes, root_idx, rays: np.ndarray, fill_hits: np.ndarray):
+    """intersect_main of intersect_bvh2level_skiplinks.cl (:134-307)."""
+    n = len(rays)
+    bufs = [DeviceBuffer(nodes), DeviceBuffer(vertices), DeviceBuffer(faces), DeviceBuffer(shapes), DeviceBuffer(rays),
+            DeviceBuffer(np.array([n], dtype=np.int32)), DeviceBuffer(fill_hits)]
+    try:
+        module.launch("intersect_main", n, [bufs[0], bufs[1], bufs[2], bufs[3], C.c_int32(int(root_idx)), bufs[4], bufs[5], bufs[6]])
+        return bufs[6].read(fill_hits.dtype, len(fill_hits))
+    finally:
+        for b in bufs:
+            b.free()

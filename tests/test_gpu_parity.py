@@ -83,7 +83,7 @@ def test_bvh4_nodes_bit_exact(engine, orc, name):
     # a plane is stored as 0x8000 | q (the bytes of the float 1 + q/32768); the decoded boxes contain the fp32 boxes
     used = refs != capi.INVALID_ADDR
     assert ((w[:, :, :3][used] & 0x80008000) == 0x80008000).all()
-    assert (w[:, :, :3][~used] == 0).all()
+    assert (w[:, :, :3][~used] == 0x8000ffff).all()          # empty slots: the inverted box no ray enters
     f64 = frame.astype(np.float64)
     lo = (f64[:3] + (w[:, :, :3] & 0x7fff).astype(np.float64) * f64[3:]).astype(np.float32)
     hi = (f64[:3] + ((w[:, :, :3] >> 16) & 0x7fff).astype(np.float64) * f64[3:]).astype(np.float32)

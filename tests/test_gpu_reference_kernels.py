@@ -287,3 +287,37 @@ def _hierarchy_one_group(mod, sorted_codes, prim_boxes, sorted_indices):
     finally:
         for b in bufs:
             b.free()
+
+
+def test_reference_kernels_two_level_instancing_matches_oracle(engine, orc):
+    """The reference stack's instancing path, intersect_bvh2level_skiplinks.cl :134-307 — a top-level hierarchy over
+    shapes, each with a world-to-object transform and a shared bottom-level tree, the ray transformed on entry (:105-131,
+    :246-253) — run on the GPU on a 13-object scene (12 transformed copies of one rock sharing one tree + the ground):
+    the closest hit of every ray equals the oracle's two-level walk (orc_two_level_intersect: the walk DESIGN.md §8's
+    flat-versus-two-level measurement is made with) in shape, primitive and t, bit for bit — and the flat walk over the
+    flattened scene up to the rounding of object-space arithmetic."""
+    sc = scenes.instanced_scene(instances=12, rock_n=20, atlas=128, seed=5)
+    flat = FlatScene(sc)
+    opts = make_options(orc, sample_count=16, sampler=capi.SAMPLER_COSINE, seed=5, normal_fp16=capi.FP16_OFF)
+    flat_nodes, _ = orc.bvh_build(orc.scene_triangles(flat.desc))
+    surfels, _ = orc.rasterize(flat.desc, 0, opts)
+    rays = orc.generate_rays(surfels[::5], None, opts, 128, t_max=1.25)
+    tlas, instances, blas = orc.two_level_scene(sc)
+    nodes, vertices, faces, shapes, root = rk.two_level_buffers(tlas, instances, blas)
+    assert nodes.dtype.itemsize == 32 and shapes.dtype.itemsize == 112 and faces.dtype.itemsize == 20
+    with rk.Module("intersect_bvh2level_skiplinks_exact.co") as mod:
+        got = rk.intersect_two_level(mod, nodes, vertices, faces, shapes, root, rays, filled(orc.INTERSECTION, len(rays)))
+    want, top, bottom = orc.two_level_intersect(tlas, instances, blas, rays, any_hit=False)
+    active = rays["extra"][:, 1] != 0
+    assert active.all() and top.hits > 0
+    assert np.array_equal(got["shape_id"], want["shape_id"])
+    hit = want["shape_id"] != -1
+    assert np.array_equal(got["prim_id"][hit], want["prim_id"][hit])
+    assert bits(got["uvwt"][hit, 3]).tobytes() == bits(want["uvwt"][hit, 3]).tobytes()
+    # ... and the flat tree the library walks finds the same surfaces
+    fh, _ = orc.flat_intersect(flat_nodes, rays, False)
+    same = (fh["shape_id"] != -1) == hit
+    assert same.mean() > 0.998
+    both = same & hit & (fh["shape_id"] == want["shape_id"])
+    assert both.sum() > 0.995 * hit.sum()
+    assert np.abs(fh["uvwt"][both, 3] - want["uvwt"][both, 3]).max() < 1e-4

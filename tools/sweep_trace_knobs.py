@@ -57,6 +57,10 @@ def main():
     for fine in (2, 4, 8, 16, 1000000):
         run(trace_fine_div=fine)
     run(trace_bands=2)
+    # the two thresholds together (they trade against each other: both decide how many lanes walk in the inner section)
+    for refill in (12, 16, 20, 24, 32):
+        for leaf_wait in (8, 12, 16, 20):
+            run(trace_refill_idle=refill, trace_leaf_wait=leaf_wait)
     BakeEngine.Dispose()
 
 
