@@ -60,12 +60,16 @@ def random_options(rng):
     o.ray_chunk_size = int(rng.choice([0xFFFFFF, 4096, 640, 64]))      # the compat sampler's chunk-local table index wraps
     if o.raster_layers == capi.LAYERS_ALL:
         o.raster_mode = capi.RASTER_REFERENCE     # the layers are centre-sampled
+    # the schedule of the trace kernel (drawn last, like everything added later): it must never show in a texel
+    if rng.uniform() < 0.5:
+        o.trace_refill_idle = int(rng.choice([0, 1, 7, 24, 42, 64])); o.trace_leaf_wait = int(rng.choice([0, 1, 5, 16, 40, 64]))
+        o.trace_parts = int(rng.choice([0, 1, 3, 8])); o.trace_part_min = int(rng.choice([0, 1, 4, 16])); o.trace_fine_div = int(rng.choice([0, 1, 3, 8]))
+        o.trace_bands = int(rng.integers(0, 3))
     return o
 
 
-@pytest.mark.parametrize("block", range(8))
-def test_random_scenes_and_options(engine, orc, block):
-    for seed in range(1000 + 50 * block, 1000 + 50 * (block + 1)):
+def bake_and_compare(engine, orc, seeds):
+    for seed in seeds:
         rng = np.random.default_rng(seed)
         o = random_options(rng)
         bpc = 1 if o.accumulate == capi.ACCUMULATE_QUANTISED else 4
@@ -76,3 +80,24 @@ def test_random_scenes_and_options(engine, orc, block):
         for i in range(gpu_scene.GetMaterialCount()):
             g, c = gpu_scene.GetMaterial(i).GetAOTexture().GetData(), cpu_scene.GetMaterial(i).GetAOTexture().GetData()
             assert np.array_equal(g, c), (seed, i, {n: getattr(o, n) for n, _ in capi.AobOptions._fields_ if n != "reserved"})
+
+
+@pytest.mark.parametrize("block", range(8))
+def test_random_scenes_and_options(engine, orc, block):
+    bake_and_compare(engine, orc, range(1000 + 50 * block, 1000 + 50 * (block + 1)))
+
+
+if __name__ == "__main__":
+    # soak: PYTHONPATH=. python tests/test_gpu_fuzz.py FIRST COUNT   (seeds beyond the 400 the suite runs; same generator)
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from aobaker_amd import BakeEngine
+    from oracle import oracle
+    first, count = int(sys.argv[1]), int(sys.argv[2])
+    BakeEngine.Init(0)
+    for lo in range(first, first + count, 250):
+        bake_and_compare(BakeEngine, oracle, range(lo, min(lo + 250, first + count)))
+        print(f"seeds {lo}..{min(lo + 250, first + count) - 1}: identical", flush=True)
+    BakeEngine.Options = None
+    BakeEngine.Dispose()

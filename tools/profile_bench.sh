@@ -1,8 +1,13 @@
 #!/bin/bash
-# GPU call: full GPU suite on the current build, bench, kernel stats, PMC passes + counters record
+# tools/profile_bench.sh [OUTDIR] — everything DESIGN.md §6 and profiles/ quote, from one command on the GPU box:
+#   the -m gpu suite (stops if it is not green), tools/run_shapes.py, `bench.py --steps 20 --warmup 5`, the rocprofv3
+#   --kernel-trace --stats summary of the bench command, the FETCH_SIZE calibration kernels, one --pmc pass per counter
+#   group over one bench step, and tools/pmc_record.py -> OUTDIR/k_trace_counters.json (copy it to profiles/).
+# Counter passes use --kernel-trace only and each is bounded by `timeout -k 10`.  Run from the repo root:
+#   bash tools/profile_bench.sh gpurun_out/profile
 set -u
 R=$PWD
-O=gpurun_out/r2h
+O=${1:-gpurun_out/profile}
 mkdir -p $O $O/calib
 timeout -k 10 600 python -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1; rc=$?; echo "pytest rc=$rc" >> $O/pytest.log; tail -4 $O/pytest.log
 [ $rc -eq 0 ] || exit 1
