@@ -73,6 +73,8 @@ struct DeviceMaterial {
 struct AobBake {
     AobOptions opt;
     hipStream_t stream = nullptr;
+    uint8_t*  arena = nullptr;          // ONE device allocation: every buffer sized at creation is a slice of it (api.hip)
+    size_t    arena_bytes = 0;
     std::vector<aob::DeviceMesh> meshes;
     std::vector<aob::DeviceMaterial> materials;
     uint64_t triangle_count = 0;
@@ -125,6 +127,14 @@ struct AobBake {
 };
 
 namespace aob {
+// hipFree for a buffer that may be a slice of the bake's arena (then it is not freed on its own)
+inline void release_device(const AobBake* b, void* p)
+{
+    if (!p) return;
+    const uint8_t* q = (const uint8_t*)p;
+    if (b->arena && q >= b->arena && q < b->arena + b->arena_bytes) return;
+    hipFree(p);
+}
 // stage launchers (each enqueues on bake->stream; only the ones that say so synchronise)
 int build_bvh(AobBake* b);                                   // bvh_build.hip
 int ensure_nodes(AobBake* b);                                // the fp32 BVH2 node array (`nodes`), from the tree that is built

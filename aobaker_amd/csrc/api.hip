@@ -78,29 +78,37 @@ static bool valid_format(int channels, int bpc)
     return false;
 }
 
-template <class T>
-static int dev_alloc(T** p, uint64_t count)
+// Device memory of a bake is ONE allocation: every buffer aob_bake_create sizes is a 256-byte aligned slice of `arena`
+// (50 hipFree calls, each a device synchronisation, made destroying a bake cost 5.8 ms — 7 % of the one-shot aob_bake of
+// BASELINE configs[2]; one hipFree costs 0.1).  want() records a slice, carve() allocates and hands the slices out.
+struct ArenaPlan {
+    struct Want { void** slot; size_t bytes; };
+    std::vector<Want> wants;
+    template <class T> void want(T** p, uint64_t count) { *p = nullptr; wants.push_back({ (void**)p, sizeof(T) * (count ? count : 1) }); }
+    void want_bytes(void** p, size_t bytes) { *p = nullptr; wants.push_back({ p, bytes ? bytes : 1 }); }
+};
+
+static int carve(AobBake* b, const ArenaPlan& plan)
 {
-    *p = nullptr;
-    if (!count) count = 1;
-    AOB_HIP(hipMalloc((void**)p, sizeof(T) * count));
+    size_t total = 0;
+    for (const auto& w : plan.wants) total += (w.bytes + 255) & ~(size_t)255;
+    AOB_HIP(hipMalloc((void**)&b->arena, total ? total : 256));
+    b->arena_bytes = total;
+    size_t at = 0;
+    for (const auto& w : plan.wants) { *w.slot = b->arena + at; at += (w.bytes + 255) & ~(size_t)255; }
     return AOB_OK;
 }
 
 static void free_bake(AobBake* b)
 {
     if (!b) return;
-    for (auto& m : b->meshes) { hipFree(m.positions); hipFree(m.normals); hipFree(m.uvs); hipFree(m.indices); }
+    // buffers that were allocated (or re-allocated: the surfel lists of overlapping sections can outgrow W*H) on their own
     for (auto& m : b->materials) {
-        hipFree(m.cover); hipFree(m.prev_layer); hipFree(m.block_sums); hipFree(m.surfels); hipFree(m.section_index); hipFree(m.frames); hipFree(m.perm); hipFree(m.tile_sums); hipFree(m.tile_row_prefix);
+        release_device(b, m.prev_layer); release_device(b, m.surfels); release_device(b, m.section_index); release_device(b, m.frames); release_device(b, m.perm);
         if (m.tile_row_prefix_host) hipHostFree(m.tile_row_prefix_host);
-        hipFree(m.results); hipFree(m.image);
     }
-    hipFree(b->tri_verts); hipFree(b->prim_bounds); hipFree(b->scene_bounds_enc);
-    hipFree(b->codes[0]); hipFree(b->codes[1]); hipFree(b->prim_idx[0]); hipFree(b->prim_idx[1]);
-    hipFree(b->sort_temp); hipFree(b->child_left); hipFree(b->child_right); hipFree(b->parent);
-    hipFree(b->node_bounds); hipFree(b->refit_flags); hipFree(b->depth_dev); hipFree(b->node_height); hipFree(b->ploc_sums); hipFree(b->ploc_totals); hipFree(b->nodes); hipFree(b->nodes4); hipFree(b->leaf_tris); hipFree(b->nodes2q); hipFree(b->nodes4q); hipFree(b->packed_index); hipFree(b->node4q_count_dev); hipFree(b->quant_frame);
-    hipFree(b->hemisphere); hipFree(b->gstack); hipFree(b->trace_unit_next); hipFree(b->hidden_from_others);
+    release_device(b, b->gstack);
+    if (b->arena) hipFree(b->arena);
     if (b->pinned) hipHostFree(b->pinned);
     for (auto& e : b->ev) if (e) hipEventDestroy(e);
     for (auto& e : b->ev_trace) if (e) hipEventDestroy(e);
@@ -235,12 +243,12 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
     for (auto& e : b->ev_trace) AOB_CH(hipEventCreate(&e));
     for (auto& e : b->ev_ploc) AOB_CH(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     AOB_CH(hipHostMalloc((void**)&b->pinned, 64));
-    AOB_CH(hipMalloc((void**)&b->trace_unit_next, 8 * sizeof(uint32_t)));
     AOB_CH(hipDeviceGetAttribute(&b->cu_count, hipDeviceAttributeMultiprocessorCount, g_device));
     AOB_CH(hipEventRecord(b->ev[0], b->stream));
 
-    // S1 upload (BakeEngine.cpp:370-398): de-interleave the strided vertex attributes
-    std::vector<float> staging;
+    // ---- plan: what every stage needs, sized once ----
+    ArenaPlan plan;
+    plan.want(&b->trace_unit_next, 8);
     b->meshes.resize(scene->mesh_count);
     uint64_t tri_total = 0;
     for (uint32_t i = 0; i < scene->mesh_count; i++) {
@@ -255,10 +263,91 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
         if (d.flags) b->any_mesh_flags = true;
         memcpy(d.model, src.model, sizeof d.model);
         tri_total += d.triangle_count;
-        AOB_C(dev_alloc(&d.positions, 3ull * src.vertex_count));
-        AOB_C(dev_alloc(&d.normals, 3ull * src.vertex_count));
-        AOB_C(dev_alloc(&d.uvs, 2ull * src.vertex_count));
-        AOB_C(dev_alloc(&d.indices, 3ull * d.triangle_count));
+        plan.want(&d.positions, 3ull * src.vertex_count);
+        plan.want(&d.normals, 3ull * src.vertex_count);
+        plan.want(&d.uvs, 2ull * src.vertex_count);
+        plan.want(&d.indices, 3ull * d.triangle_count);
+    }
+    b->triangle_count = tri_total;
+    const uint64_t n = tri_total;
+    // shape ids start at 1 (RadeonRays/radeon_rays.h:238): bit s of the set is mesh s - 1
+    std::vector<uint32_t> bits((scene->mesh_count + 1 + 31) / 32 + 1, 0u);
+    for (uint32_t i = 0; i < scene->mesh_count; i++)
+        if (b->meshes[i].flags & AOB_MESH_HIDDEN_FROM_OTHERS) bits[(i + 1) >> 5] |= 1u << ((i + 1) & 31);
+    plan.want(&b->hidden_from_others, bits.size());
+
+    // BVH workspace
+    plan.want(&b->tri_verts, 3 * n);
+    plan.want(&b->prim_bounds, n);
+    plan.want(&b->scene_bounds_enc, 8);
+    plan.want(&b->codes[0], n); plan.want(&b->codes[1], n);
+    plan.want(&b->prim_idx[0], n); plan.want(&b->prim_idx[1], n);
+    plan.want(&b->child_left, n); plan.want(&b->child_right, n);
+    plan.want(&b->parent, 2 * n);
+    plan.want(&b->node_bounds, 2 * n);
+    plan.want(&b->refit_flags, n);
+    plan.want(&b->depth_dev, 1);
+    plan.want(&b->node_height, n);
+    plan.want(&b->ploc_sums, n / 1024 + 4);
+    plan.want(&b->ploc_totals, 8);
+    plan.want(&b->nodes, 2 * n);
+    plan.want(&b->nodes4, 8 * n);
+    plan.want(&b->leaf_tris, 3 * n);
+    plan.want(&b->nodes2q, 2 * n);
+    plan.want(&b->nodes4q, 4 * n);
+    plan.want(&b->packed_index, n);
+    plan.want(&b->node4q_count_dev, 1);
+    plan.want(&b->quant_frame, 8);
+    if (n) {
+        // temporary storage of the sort and of the scan (a size query: no pointer is dereferenced)
+        size_t temp = 0;
+        AOB_CH(rocprim::radix_sort_pairs(nullptr, temp, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                         (size_t)n, 0u, 63u, b->stream));
+        size_t temp_scan = 0;
+        AOB_CH(rocprim::exclusive_scan(nullptr, temp_scan, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)n, rocprim::plus<uint32_t>(), b->stream));
+        if (temp_scan > temp) temp = temp_scan;
+        b->sort_temp_bytes = temp;
+        plan.want_bytes(&b->sort_temp, temp);
+    }
+
+    b->materials.resize(scene->material_count);
+    for (uint32_t i = 0; i < scene->material_count; i++) {
+        const AobMaterialDesc& src = scene->materials[i];
+        DeviceMaterial& d = b->materials[i];
+        d.width = src.width; d.height = src.height; d.channels = src.channels; d.bytes_per_channel = src.bytes_per_channel;
+        d.host_data = src.data;
+        d.ao_max_range = src.ao_max_range;
+        const uint64_t cells = (uint64_t)d.width * d.height;
+        d.scan_blocks = (uint32_t)((cells + 2047) / 2048);
+        plan.want(&d.cover, cells);
+        plan.want(&d.block_sums, (uint64_t)d.scan_blocks + 1);
+        plan.want(&d.results, cells);
+        plan.want(&d.image, cells * d.channels * d.bytes_per_channel);
+        plan.want(&d.surfels, cells);
+        plan.want(&d.section_index, cells);
+        plan.want(&d.frames, 4 * cells);
+        plan.want(&d.perm, cells);
+        const uint64_t tiles_x = (uint64_t)(d.width + 7) / 8, tiles_y = (uint64_t)(d.height + 7) / 8;
+        plan.want(&d.tile_sums, (tiles_x * tiles_y * 64 + 2047) / 2048 + 1);
+        plan.want(&d.tile_row_prefix, tiles_y + 1);
+        AOB_CH(hipHostMalloc((void**)&d.tile_row_prefix_host, sizeof(uint32_t) * (tiles_y + 1)));
+        d.surfel_capacity = cells;
+        d.section_offsets.push_back(0);
+    }
+    if (options->sampler == AOB_SAMPLER_REFERENCE_COMPAT) {
+        // S0 (BakeEngine.cpp:348-356): only the entries a chunk can index are generated
+        b->hemisphere_entries = chunk_texel_max(*options) * (uint64_t)options->sample_count;
+        plan.want(&b->hemisphere, 3 * b->hemisphere_entries);
+    }
+
+    // ---- one allocation ----
+    AOB_C(carve(b, plan));
+
+    // ---- S1 upload (BakeEngine.cpp:370-398): de-interleave the strided vertex attributes ----
+    std::vector<float> staging;
+    for (uint32_t i = 0; i < scene->mesh_count; i++) {
+        const AobMeshDesc& src = scene->meshes[i];
+        DeviceMesh& d = b->meshes[i];
         if (src.vertex_count) {
             staging.resize(8ull * src.vertex_count);
             float* sp = staging.data(); float* sn = sp + 3ull * src.vertex_count; float* su = sn + 3ull * src.vertex_count;
@@ -275,86 +364,14 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
         if (d.triangle_count)
             AOB_CH(hipMemcpyAsync(d.indices, src.indices, 12ull * d.triangle_count, hipMemcpyHostToDevice, b->stream));
     }
-    b->triangle_count = tri_total;
-    const uint64_t n = tri_total;
-    {
-        // shape ids start at 1 (RadeonRays/radeon_rays.h:238): bit s of the set is mesh s - 1
-        std::vector<uint32_t> bits((scene->mesh_count + 1 + 31) / 32 + 1, 0u);
-        for (uint32_t i = 0; i < scene->mesh_count; i++)
-            if (b->meshes[i].flags & AOB_MESH_HIDDEN_FROM_OTHERS) bits[(i + 1) >> 5] |= 1u << ((i + 1) & 31);
-        AOB_C(dev_alloc(&b->hidden_from_others, bits.size()));
-        AOB_CH(hipMemcpy(b->hidden_from_others, bits.data(), sizeof(uint32_t) * bits.size(), hipMemcpyHostToDevice));
-    }
-
-    // BVH workspace, sized once
-    AOB_C(dev_alloc(&b->tri_verts, 3 * n));
-    AOB_C(dev_alloc(&b->prim_bounds, n));
-    AOB_C(dev_alloc(&b->scene_bounds_enc, 8));
-    AOB_C(dev_alloc(&b->codes[0], n)); AOB_C(dev_alloc(&b->codes[1], n));
-    AOB_C(dev_alloc(&b->prim_idx[0], n)); AOB_C(dev_alloc(&b->prim_idx[1], n));
-    AOB_C(dev_alloc(&b->child_left, n)); AOB_C(dev_alloc(&b->child_right, n));
-    AOB_C(dev_alloc(&b->parent, 2 * n));
-    AOB_C(dev_alloc(&b->node_bounds, 2 * n));
-    AOB_C(dev_alloc(&b->refit_flags, n));
-    AOB_C(dev_alloc(&b->depth_dev, 1));
-    AOB_C(dev_alloc(&b->node_height, n));
-    AOB_C(dev_alloc(&b->ploc_sums, n / 1024 + 4));
-    AOB_C(dev_alloc(&b->ploc_totals, 8));
-    AOB_C(dev_alloc(&b->nodes, 2 * n));
-    AOB_C(dev_alloc(&b->nodes4, 8 * n));
-    AOB_C(dev_alloc(&b->leaf_tris, 3 * n));
-    AOB_C(dev_alloc(&b->nodes2q, 2 * n));
-    AOB_C(dev_alloc(&b->nodes4q, 4 * n));
-    AOB_C(dev_alloc(&b->packed_index, n));
-    AOB_C(dev_alloc(&b->node4q_count_dev, 1));
-    AOB_C(dev_alloc(&b->quant_frame, 8));
-    if (n) {
-        size_t temp = 0;
-        AOB_CH(rocprim::radix_sort_pairs(nullptr, temp, b->codes[0], b->codes[1], b->prim_idx[0], b->prim_idx[1],
-                                         (size_t)n, 0u, 63u, b->stream));
-        size_t temp_scan = 0;
-        AOB_CH(rocprim::exclusive_scan(nullptr, temp_scan, b->refit_flags, b->packed_index, 0u, (size_t)n, rocprim::plus<uint32_t>(), b->stream));
-        if (temp_scan > temp) temp = temp_scan;
-        b->sort_temp_bytes = temp;
-        AOB_CH(hipMalloc(&b->sort_temp, temp ? temp : 1));
-    }
-
-    b->materials.resize(scene->material_count);
-    for (uint32_t i = 0; i < scene->material_count; i++) {
-        const AobMaterialDesc& src = scene->materials[i];
-        DeviceMaterial& d = b->materials[i];
-        d.width = src.width; d.height = src.height; d.channels = src.channels; d.bytes_per_channel = src.bytes_per_channel;
-        d.host_data = src.data;
-        d.ao_max_range = src.ao_max_range;
-        const uint64_t cells = (uint64_t)d.width * d.height;
-        d.scan_blocks = (uint32_t)((cells + 2047) / 2048);
-        AOB_C(dev_alloc(&d.cover, cells));
-        AOB_C(dev_alloc(&d.block_sums, (uint64_t)d.scan_blocks + 1));
-        AOB_C(dev_alloc(&d.results, cells));
-        AOB_C(dev_alloc(&d.image, cells * d.channels * d.bytes_per_channel));
-        AOB_C(dev_alloc(&d.surfels, cells));
-        AOB_C(dev_alloc(&d.section_index, cells));
-        AOB_C(dev_alloc(&d.frames, 4 * cells));
-        AOB_C(dev_alloc(&d.perm, cells));
-        {
-            const uint64_t tiles_x = (uint64_t)(d.width + 7) / 8, tiles_y = (uint64_t)(d.height + 7) / 8;
-            AOB_C(dev_alloc(&d.tile_sums, (tiles_x * tiles_y * 64 + 2047) / 2048 + 1));
-            AOB_C(dev_alloc(&d.tile_row_prefix, tiles_y + 1));
-            AOB_CH(hipHostMalloc((void**)&d.tile_row_prefix_host, sizeof(uint32_t) * (tiles_y + 1)));
-        }
-        d.surfel_capacity = cells;
-        AOB_CH(hipMemsetAsync(d.results, 0, sizeof(AobResult) * cells, b->stream));
-        d.section_offsets.push_back(0);
-    }
-
-    if (options->sampler == AOB_SAMPLER_REFERENCE_COMPAT) {
-        // S0 (BakeEngine.cpp:348-356): only the entries a chunk can index are generated
-        b->hemisphere_entries = chunk_texel_max(*options) * (uint64_t)options->sample_count;
-        std::vector<float> table(3 * b->hemisphere_entries);
+    AOB_CH(hipMemcpyAsync(b->hidden_from_others, bits.data(), sizeof(uint32_t) * bits.size(), hipMemcpyHostToDevice, b->stream));
+    for (auto& d : b->materials)
+        AOB_CH(hipMemsetAsync(d.results, 0, sizeof(AobResult) * (uint64_t)d.width * d.height, b->stream));
+    std::vector<float> table;
+    if (b->hemisphere_entries) {
+        table.resize(3 * b->hemisphere_entries);
         hemisphere_table(table.data(), b->hemisphere_entries);
-        AOB_C(dev_alloc(&b->hemisphere, 3 * b->hemisphere_entries));
         AOB_CH(hipMemcpyAsync(b->hemisphere, table.data(), sizeof(float) * table.size(), hipMemcpyHostToDevice, b->stream));
-        AOB_CH(hipStreamSynchronize(b->stream));
     }
     AOB_CH(hipEventRecord(b->ev[1], b->stream));
     AOB_CH(hipStreamSynchronize(b->stream));

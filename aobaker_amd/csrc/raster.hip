@@ -429,10 +429,8 @@ static int ensure_surfel_capacity(AobBake* b, DeviceMaterial& m, uint64_t need)
         AOB_HIP(hipMemcpyAsync(nf, m.frames, sizeof(float4) * 4 * m.surfel_count, hipMemcpyDeviceToDevice, b->stream));
         AOB_HIP(hipStreamSynchronize(b->stream));
     }
-    if (m.surfels) AOB_HIP(hipFree(m.surfels));
-    if (m.section_index) AOB_HIP(hipFree(m.section_index));
-    if (m.frames) AOB_HIP(hipFree(m.frames));
-    if (m.perm) AOB_HIP(hipFree(m.perm));
+    AOB_HIP(hipStreamSynchronize(b->stream));
+    release_device(b, m.surfels); release_device(b, m.section_index); release_device(b, m.frames); release_device(b, m.perm);   // (slices of the arena stay)
     m.surfels = ns; m.section_index = ni; m.frames = nf; m.perm = np; m.surfel_capacity = cap;
     return AOB_OK;
 }
