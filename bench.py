@@ -65,6 +65,9 @@ def parse_args():
     ap.add_argument("--no-cpp-host", action="store_true")
     ap.add_argument("--no-wallclock", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="gloo: REHEARSAL of the N-rank run where RCCL cannot form (ranks sharing one GPU): strips travel through host memory")
+    ap.add_argument("--oversubscribe", action="store_true", help="rehearsal: rank r uses device r %% (visible devices)")
     return ap.parse_args()
 
 
@@ -84,7 +87,7 @@ def visible_devices():
 def launch_ranks(args):
     import socket
     have = visible_devices()
-    if have < args.gpus:
+    if have < (1 if args.oversubscribe else args.gpus):
         msg = f"bench.py --gpus {args.gpus} needs {args.gpus} devices, {have} visible on this box: nothing was run"
         print(msg, file=sys.stderr)
         print(json.dumps({"metric": "AO rays/sec", "value": None, "unit": "rays/s", "n_gpus": args.gpus, "skipped": msg}), flush=True)
@@ -134,12 +137,19 @@ def main():
     from aobaker_amd import dist as aod
     from aobaker_amd.scene import FlatScene
 
+    if args.oversubscribe:
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     host_group = None
+    rehearsal = args.backend == "gloo"
+    comm_device = "cpu" if rehearsal else "cuda"            # where the small control tensors of the collectives live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         host_group = dist.new_group(backend="gloo")         # host-side waits that keep the GPUs idle (cpp_host leg)
 
     strong = args.scaling == "strong"
@@ -199,7 +209,16 @@ def main():
             baker.sync()
             mine = (time.perf_counter() - t) * 1e3
             all_cells = [(bounds[r] * W, bounds[r + 1] * W - 1) for r in range(world)]
-            aod.gather_strips(cells, all_cells[rank], rank, world, 0, False, all_cells)
+            if rehearsal:
+                # through host memory: a copy of the whole cell array, the same gather on it, rank 0's strips copied back
+                host_cells = cells.cpu()
+                aod.gather_strips(host_cells, all_cells[rank], rank, world, 0, False, all_cells)
+                if rank == 0:
+                    for c0, c1 in all_cells[1:]:
+                        if c0 <= c1:
+                            cells[c0:c1 + 1].copy_(host_cells[c0:c1 + 1])
+            else:
+                aod.gather_strips(cells, all_cells[rank], rank, world, 0, False, all_cells)
             torch.cuda.synchronize()
         if rank == 0:
             baker.resolve(0)
@@ -221,8 +240,8 @@ def main():
         step()
         if world > 1 and not args.no_balance:
             # re-cut the strips in proportion to what every rank's strip just cost (host clock: build + raster + trace)
-            t = torch.tensor([step_ms[-1]], dtype=torch.float64, device="cuda")
-            every = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+            t = torch.tensor([step_ms[-1]], dtype=torch.float64, device=comm_device)
+            every = [torch.zeros(1, dtype=torch.float64, device=comm_device) for _ in range(world)]
             dist.all_gather(every, t)
             ms = [float(v.item()) for v in every]
             history.append({"rows": list(bounds), "rank_ms": [round(v, 3) for v in ms]})
@@ -236,19 +255,26 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     stats = baker.stats()
+    image_crc = None
+    if rank == 0:
+        import zlib
+        m = flat.material_array[0]
+        img = np.zeros(m.width * m.height * m.channels * m.bytes_per_channel, dtype=np.uint8)
+        baker.download(0, img)                              # after the timed region: the resolved atlas of the last step
+        image_crc = zlib.crc32(img.tobytes())
     my_rays = counts["mine"] * args.spp
     rank_ms = [sum(step_ms) / len(step_ms)]
     if world > 1:
-        t = torch.tensor([counts["mine"]], dtype=torch.int64, device="cuda")
+        t = torch.tensor([counts["mine"]], dtype=torch.int64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         counts["surfels"] = int(t.item())
-        t = torch.tensor(rank_ms, dtype=torch.float64, device="cuda")
-        every = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+        t = torch.tensor(rank_ms, dtype=torch.float64, device=comm_device)
+        every = [torch.zeros(1, dtype=torch.float64, device=comm_device) for _ in range(world)]
         dist.all_gather(every, t)
         rank_ms = [float(v.item()) for v in every]
     else:
@@ -294,7 +320,9 @@ def main():
                        "surfels": counts["surfels"], "rays": total_rays, "sharding": f"strips of texel rows x{world}",
                        "rows": [[bounds[r], bounds[r + 1]] for r in range(world)],
                        "bvh_nodes": stats.node_count, "bvh_depth": stats.bvh_depth,
-                       "host": "python ranks, one process per GPU, torch.distributed nccl (= RCCL) point-to-point gather to rank 0"},
+                       "image_crc32": image_crc,
+                       "host": ("REHEARSAL: ranks share devices, strips gathered with gloo through host memory" if rehearsal else
+                                "python ranks, one process per GPU, torch.distributed nccl (= RCCL) point-to-point gather to rank 0")},
             "stage_ms": {"bvh_build": round(stats.ms_bvh_build, 3), "trace_kernel": round(kernel_ms, 3),
                          "rank_build_raster_trace": [round(v, 3) for v in rank_ms]},
             "bake_wallclock_ms": dict(wallclock or {}, device_step_ms=round(ms_per_step, 3)),

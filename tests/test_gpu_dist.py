@@ -48,3 +48,31 @@ def test_results_alias_and_rccl_on_library_memory(engine):
         img = np.zeros(128 * 128 * 4, dtype=np.uint8)
         b.download(0, img)
         assert 0.3 < img.view(np.float32).mean() < 1.0
+
+
+def _bench(*args):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *[str(a) for a in args]], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, (out.returncode, out.stderr[-3000:])
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_bench_rank_processes_rehearsed_on_one_gpu(ranks):
+    """`python bench.py --gpus N` end to end with N real rank processes — self-launch, strips of texel rows, cost re-cuts
+    during warm-up, gather to rank 0, resolve — rehearsed on the one GPU of the test box: the ranks share the device and the
+    strips travel through host memory with gloo (RCCL wants one rank per device); every other line of the N-rank path is
+    the one the driver's multi-GPU run executes.  The resolved atlas equals the one-rank atlas."""
+    common = ["--atlas", 256, "--grid", 96, "--spp", 32, "--steps", 2, "--warmup", 3, "--no-cpp-host", "--no-cpu-baseline", "--no-wallclock"]
+    one = _bench("--gpus", 1, *common)
+    many = _bench("--gpus", ranks, "--backend", "gloo", "--oversubscribe", *common)
+    assert many["n_gpus"] == ranks and many["scaling"] == "strong" and many["value"] > 0
+    assert many["config"]["atlas"] == [256, 256] and many["config"]["surfels"] == one["config"]["surfels"] == 256 * 256
+    rows = many["config"]["rows"]
+    assert len(rows) == ranks and rows[0][0] == 0 and rows[-1][1] == 256 and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+    assert len(many["balance"]["warmup_history"]) == 3 and len(many["stage_ms"]["rank_build_raster_trace"]) == ranks
+    assert many["config"]["image_crc32"] == one["config"]["image_crc32"]
