@@ -85,15 +85,15 @@ int ref_launch(void* module, const char* kernel, uint32_t blocks, uint32_t block
     REF_HIP(hipEventCreate(&e1));
     REF_HIP(hipEventRecord(e0, nullptr));
     hipError_t e = hipModuleLaunchKernel(f, blocks, 1, 1, block_size, 1, 1, 0, nullptr, args, nullptr);
-    if (e != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); return fail("hipModuleLaunchKernel", e); }
+    if (e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return fail("hipModuleLaunchKernel", e); }
     REF_HIP(hipEventRecord(e1, nullptr));
     e = hipDeviceSynchronize();
-    if (e != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); return fail("hipDeviceSynchronize", e); }
+    if (e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return fail("hipDeviceSynchronize", e); }
     float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
     if (ms_out) *ms_out = ms;
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     return 0;
 }
 
