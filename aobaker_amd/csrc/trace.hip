@@ -130,6 +130,15 @@ void k_trace(TraceParams p)
     }
     // the quantised 4-ary nodes as a raw buffer (base in SGPRs, 4 GiB window: 64 Mi nodes — trace_range checks the count)
     const __amdgpu_buffer_rsrc_t nodes_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.nodes4q, 0, 0xffffffff, 0x00020000);
+    // any hit: the root node in scalar registers — the rays of a refill start together and visit it together (refill section)
+    constexpr bool ROOT_AT_REFILL = QUANT == 2 && ANYHIT;
+    uint4 root0 = make_uint4(0u, 0u, 0u, 0u), root1 = root0, root2 = root0, root3 = root0;
+    if (ROOT_AT_REFILL && p.node_count) {
+        auto uniform4 = [](uint4 v) -> uint4 {
+            return make_uint4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y), __builtin_amdgcn_readfirstlane(v.z), __builtin_amdgcn_readfirstlane(v.w));
+        };
+        root0 = uniform4(p.nodes4q[0]); root1 = uniform4(p.nodes4q[1]); root2 = uniform4(p.nodes4q[2]); root3 = uniform4(p.nodes4q[3]);
+    }
     // overflow stack entry e of this lane lives at gstack[(e * gridDim.x + blockIdx.x) * 64 + lane] (computed on use:
     // the path is cold and the registers are better spent on occupancy)
     auto gs_slot = [&](int e) -> uint32_t* { return p.gstack + ((uint64_t)e * gridDim.x + blockIdx.x) * kWave + lane; };
@@ -244,6 +253,61 @@ void k_trace(TraceParams p)
         active = false;
     };
 
+    // ---- one visit of a quantised 4-ary node: four slab tests, the next node and the deferred children ----
+    auto visit4 = [&](const uint4& c0, const uint4& c1, const uint4& c2, const uint4& c3) {
+            auto slab = [&](const uint4& c, float& tn) -> bool {
+                // two v_perm_b32 and one v_pk_fma_f32 per axis: (t_near, t_far) = (f_near, f_far) * invdir + oxinvdir
+                constexpr uint32_t kHalf = 0x3f000000u;
+                const v2f fx = { __uint_as_float(__builtin_amdgcn_perm(kHalf, c.x, nsel.x)), __uint_as_float(__builtin_amdgcn_perm(kHalf, c.x, fsel.x)) };
+                const v2f fy = { __uint_as_float(__builtin_amdgcn_perm(kHalf, c.y, nsel.y)), __uint_as_float(__builtin_amdgcn_perm(kHalf, c.y, fsel.y)) };
+                const v2f fz = { __uint_as_float(__builtin_amdgcn_perm(kHalf, c.z, nsel.z)), __uint_as_float(__builtin_amdgcn_perm(kHalf, c.z, fsel.z)) };
+                const v2f tx = __builtin_elementwise_fma(fx, (v2f){ invdir.x, invdir.x }, (v2f){ oxinvdir.x, oxinvdir.x });
+                const v2f ty = __builtin_elementwise_fma(fy, (v2f){ invdir.y, invdir.y }, (v2f){ oxinvdir.y, oxinvdir.y });
+                const v2f tz = __builtin_elementwise_fma(fz, (v2f){ invdir.z, invdir.z }, (v2f){ oxinvdir.z, oxinvdir.z });
+                float tf;
+                if (ANYHIT) {
+                    // distances in units of tmax: the ray's span is [0, 1].  A box wholly beyond 1 passes (its near distance
+                    // clamps to 1 <= far) — harmless, the triangle test has the last word (traverse4q in the oracle does the same)
+                    tn = fminf(fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0f), 1.0f);
+                    tf = fminf(fminf(tx.y, ty.y), tz.y);
+                } else {
+                    tn = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0f);
+                    tf = fminf(fminf(fminf(tx.y, ty.y), tz.y), closest_t);
+                }
+                return tn <= tf;
+            };
+            float k0, k1, k2, k3;
+            // an empty slot holds an inverted box (min plane above max plane on every axis, bvh_build.hip k_emit_nodes4q): its
+            // near distance exceeds its far distance whatever the ray, so it fails the test by itself — no compare of the ref
+            const bool h0 = slab(c0, k0), h1 = slab(c1, k1), h2 = slab(c2, k2), h3 = slab(c3, k3);
+            if (!(h0 || h1 || h2 || h3)) {
+                addr = pop();
+            } else if (ANYHIT) {
+                // any-hit: the answer does not depend on the visiting order — follow the first hit child, defer the rest
+                if (h3 && (h0 || h1 || h2)) push(c3.w);
+                if (h2 && (h0 || h1)) push(c2.w);
+                if (h1 && h0) push(c1.w);
+                addr = h0 ? c0.w : (h1 ? c1.w : (h2 ? c2.w : c3.w));
+            } else {
+                // closest hit: nearest child first, the others deferred farthest first, ties by child index
+                // (the 4-ary form of intersect_bvh2_lds.cl:123-153; the oracle's traverse4q order)
+                const float e0 = h0 ? k0 : INFINITY, e1 = h1 ? k1 : INFINITY, e2 = h2 ? k2 : INFINITY, e3 = h3 ? k3 : INFINITY;
+                const int b01 = e0 <= e1, b02 = e0 <= e2, b03 = e0 <= e3, b12 = e1 <= e2, b13 = e1 <= e3, b23 = e2 <= e3;
+                const int r0 = (1 - b01) + (1 - b02) + (1 - b03), r1 = b01 + (1 - b12) + (1 - b13);
+                const int r2 = b02 + b12 + (1 - b23), r3 = b03 + b13 + b23;
+                const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+                auto place = [&](bool h, int r, uint32_t ref) {
+                    if (h && r > 0) {
+                        const int e = sp + (nh - 1) - r;
+                        if (e < LDS_N) lds_stack[e * kWave + lane] = ref; else *gs_slot(e - LDS_N) = ref;
+                    }
+                };
+                place(h0, r0, c0.w); place(h1, r1, c1.w); place(h2, r2, c2.w); place(h3, r3, c3.w);
+                sp += nh - 1;
+                addr = (h0 && r0 == 0) ? c0.w : ((h1 && r1 == 0) ? c1.w : ((h2 && r2 == 0) ? c2.w : c3.w));
+            }
+    };
+
     for (;;) {
         const uint64_t active_m = __ballot(active);
         const bool more = q_count != 0u || gen_next < gen_end;
@@ -324,6 +388,17 @@ void k_trace(TraceParams p)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the queue writes land before other lanes read them
                 __builtin_amdgcn_wave_barrier();
             }
+            // the rays that have just started are at the root (node 0 is nobody's child), all at once: its four boxes come from
+            // scalar registers here, not through the vector memory path in the walk — one visit in ~15 and the fullest one
+            if (ROOT_AT_REFILL) {
+                // (the refs pass an empty asm: copies of them hoisted out of the loop would only be spilled)
+                uint4 r0 = root0, r1 = root1, r2 = root2, r3 = root3;
+                asm volatile("" : "+s"(r0.w), "+s"(r1.w), "+s"(r2.w), "+s"(r3.w));
+                if (active && addr == 0u) {
+                    visit4(r0, r1, r2, r3);
+                    if (addr == kInvalid) finish();      // missed every box of the root: the ray ends here, before the leaf section sees it
+                }
+            }
         }
 
         // ---- leaf section: :162-182 (closest) / :323-339 (any hit); the triangle is inlined in the node ----
@@ -380,57 +455,7 @@ void k_trace(TraceParams p)
                         c1 = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(nodes_rsrc, noff + 16u, 0, 0)),
                         c2 = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(nodes_rsrc, noff + 32u, 0, 0)),
                         c3 = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(nodes_rsrc, noff + 48u, 0, 0));
-            auto slab = [&](const uint4& c, float& tn) -> bool {
-                // two v_perm_b32 and one v_pk_fma_f32 per axis: (t_near, t_far) = (f_near, f_far) * invdir + oxinvdir
-                constexpr uint32_t kHalf = 0x3f000000u;
-                const v2f fx = { __uint_as_float(__builtin_amdgcn_perm(kHalf, c.x, nsel.x)), __uint_as_float(__builtin_amdgcn_perm(kHalf, c.x, fsel.x)) };
-                const v2f fy = { __uint_as_float(__builtin_amdgcn_perm(kHalf, c.y, nsel.y)), __uint_as_float(__builtin_amdgcn_perm(kHalf, c.y, fsel.y)) };
-                const v2f fz = { __uint_as_float(__builtin_amdgcn_perm(kHalf, c.z, nsel.z)), __uint_as_float(__builtin_amdgcn_perm(kHalf, c.z, fsel.z)) };
-                const v2f tx = __builtin_elementwise_fma(fx, (v2f){ invdir.x, invdir.x }, (v2f){ oxinvdir.x, oxinvdir.x });
-                const v2f ty = __builtin_elementwise_fma(fy, (v2f){ invdir.y, invdir.y }, (v2f){ oxinvdir.y, oxinvdir.y });
-                const v2f tz = __builtin_elementwise_fma(fz, (v2f){ invdir.z, invdir.z }, (v2f){ oxinvdir.z, oxinvdir.z });
-                float tf;
-                if (ANYHIT) {
-                    // distances in units of tmax: the ray's span is [0, 1].  A box wholly beyond 1 passes (its near distance
-                    // clamps to 1 <= far) — harmless, the triangle test has the last word (traverse4q in the oracle does the same)
-                    tn = fminf(fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0f), 1.0f);
-                    tf = fminf(fminf(tx.y, ty.y), tz.y);
-                } else {
-                    tn = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0f);
-                    tf = fminf(fminf(fminf(tx.y, ty.y), tz.y), closest_t);
-                }
-                return tn <= tf;
-            };
-            float k0, k1, k2, k3;
-            // an empty slot holds an inverted box (min plane above max plane on every axis, bvh_build.hip k_emit_nodes4q): its
-            // near distance exceeds its far distance whatever the ray, so it fails the test by itself — no compare of the ref
-            const bool h0 = slab(c0, k0), h1 = slab(c1, k1), h2 = slab(c2, k2), h3 = slab(c3, k3);
-            if (!(h0 || h1 || h2 || h3)) {
-                addr = pop();
-            } else if (ANYHIT) {
-                // any-hit: the answer does not depend on the visiting order — follow the first hit child, defer the rest
-                if (h3 && (h0 || h1 || h2)) push(c3.w);
-                if (h2 && (h0 || h1)) push(c2.w);
-                if (h1 && h0) push(c1.w);
-                addr = h0 ? c0.w : (h1 ? c1.w : (h2 ? c2.w : c3.w));
-            } else {
-                // closest hit: nearest child first, the others deferred farthest first, ties by child index
-                // (the 4-ary form of intersect_bvh2_lds.cl:123-153; the oracle's traverse4q order)
-                const float e0 = h0 ? k0 : INFINITY, e1 = h1 ? k1 : INFINITY, e2 = h2 ? k2 : INFINITY, e3 = h3 ? k3 : INFINITY;
-                const int b01 = e0 <= e1, b02 = e0 <= e2, b03 = e0 <= e3, b12 = e1 <= e2, b13 = e1 <= e3, b23 = e2 <= e3;
-                const int r0 = (1 - b01) + (1 - b02) + (1 - b03), r1 = b01 + (1 - b12) + (1 - b13);
-                const int r2 = b02 + b12 + (1 - b23), r3 = b03 + b13 + b23;
-                const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
-                auto place = [&](bool h, int r, uint32_t ref) {
-                    if (h && r > 0) {
-                        const int e = sp + (nh - 1) - r;
-                        if (e < LDS_N) lds_stack[e * kWave + lane] = ref; else *gs_slot(e - LDS_N) = ref;
-                    }
-                };
-                place(h0, r0, c0.w); place(h1, r1, c1.w); place(h2, r2, c2.w); place(h3, r3, c3.w);
-                sp += nh - 1;
-                addr = (h0 && r0 == 0) ? c0.w : ((h1 && r1 == 0) ? c1.w : ((h2 && r2 == 0) ? c2.w : c3.w));
-            }
+            visit4(c0, c1, c2, c3);
           } else {
             const float bound = ANYHIT ? p.tmax : closest_t;
             float s0x, s0y, s1x, s1y;
