@@ -130,15 +130,11 @@ void k_trace(TraceParams p)
     }
     // the quantised 4-ary nodes as a raw buffer (base in SGPRs, 4 GiB window: 64 Mi nodes — trace_range checks the count)
     const __amdgpu_buffer_rsrc_t nodes_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.nodes4q, 0, 0xffffffff, 0x00020000);
-    // any hit: the root node in scalar registers — the rays of a refill start together and visit it together (refill section)
-    constexpr bool ROOT_AT_REFILL = QUANT == 2 && ANYHIT;
-    uint4 root0 = make_uint4(0u, 0u, 0u, 0u), root1 = root0, root2 = root0, root3 = root0;
-    if (ROOT_AT_REFILL && p.node_count) {
-        auto uniform4 = [](uint4 v) -> uint4 {
-            return make_uint4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y), __builtin_amdgcn_readfirstlane(v.z), __builtin_amdgcn_readfirstlane(v.w));
-        };
-        root0 = uniform4(p.nodes4q[0]); root1 = uniform4(p.nodes4q[1]); root2 = uniform4(p.nodes4q[2]); root3 = uniform4(p.nodes4q[3]);
-    }
+    // any hit: the rays of a refill start together and visit the top of the tree together, in the refill section
+    constexpr bool SCALAR_STEPS = QUANT == 2 && ANYHIT;
+    // lanes on one node that make a scalar step worth its pass: all but a few of a refill's rays (measured on BASELINE configs[2]
+    // at 42 rays per refill: 16 / 24 / 32 / 40 / 48 lanes -> 73.3 / 71.9 / 71.2 / 70.9 / 72.4 ms; the root alone 71.8, none 73.9)
+    constexpr uint32_t kScalarMin = 40;
     // overflow stack entry e of this lane lives at gstack[(e * gridDim.x + blockIdx.x) * 64 + lane] (computed on use:
     // the path is cold and the registers are better spent on occupancy)
     auto gs_slot = [&](int e) -> uint32_t* { return p.gstack + ((uint64_t)e * gridDim.x + blockIdx.x) * kWave + lane; };
@@ -388,15 +384,32 @@ void k_trace(TraceParams p)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the queue writes land before other lanes read them
                 __builtin_amdgcn_wave_barrier();
             }
-            // the rays that have just started are at the root (node 0 is nobody's child), all at once: its four boxes come from
-            // scalar registers here, not through the vector memory path in the walk — one visit in ~15 and the fullest one
-            if (ROOT_AT_REFILL) {
-                // (the refs pass an empty asm: copies of them hoisted out of the loop would only be spilled)
-                uint4 r0 = root0, r1 = root1, r2 = root2, r3 = root3;
-                asm volatile("" : "+s"(r0.w), "+s"(r1.w), "+s"(r2.w), "+s"(r3.w));
-                if (active && addr == 0u) {
-                    visit4(r0, r1, r2, r3);
-                    if (addr == kInvalid) finish();      // missed every box of the root: the ray ends here, before the leaf section sees it
+            // ---- scalar steps ----
+            // The rays that have just started are at the root (node 0 is nobody's child), all at once, and the rays of one refill
+            // — one sample of neighbouring surfels — walk the top of the tree together.  While enough lanes stand on ONE
+            // node, that node is fetched by scalar loads and its four boxes are tested from scalar registers, here, outside the
+            // walk: those visits never reach the vector memory path, which is what bounds the walk.
+            if (SCALAR_STEPS && p.node_count) {
+                // (the node is read through the constant address space — nothing writes the nodes while this kernel runs —
+                // which is what lets the compiler use scalar loads; its address passes an empty asm so that the loads stay here)
+                typedef const __attribute__((address_space(4))) uint32_t* const_words;
+                uint32_t a0 = 0u;
+                for (int step = 0; step < 24; step++) {
+                    const uint4* ng = p.nodes4q + 4ull * a0;
+                    asm volatile("" : "+s"(ng));
+                    const const_words nw = (const_words)ng;
+                    const uint4 n0 = make_uint4(nw[0], nw[1], nw[2], nw[3]), n1 = make_uint4(nw[4], nw[5], nw[6], nw[7]),
+                                n2 = make_uint4(nw[8], nw[9], nw[10], nw[11]), n3 = make_uint4(nw[12], nw[13], nw[14], nw[15]);
+                    const bool here = active && addr == a0;
+                    if (here) {
+                        visit4(n0, n1, n2, n3);
+                        if (addr == kInvalid) finish();      // nothing left to visit: the ray ends here, before the leaf section sees it
+                    }
+                    // the next node: where the first lane of the group went, if enough of the others went with it
+                    const uint64_t on_m = __ballot(here && active && addr < p.leaf_base);
+                    if ((uint32_t)__popcll(on_m) < kScalarMin) break;
+                    a0 = (uint32_t)__builtin_amdgcn_readlane((int)addr, (int)__builtin_ctzll(on_m));
+                    if ((uint32_t)__popcll(__ballot(active && addr == a0)) < kScalarMin) break;
                 }
             }
         }
