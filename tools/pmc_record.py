@@ -69,7 +69,10 @@ def main():
         "FETCH_bytes_raw": fetch_raw, "WRITE_bytes": write,
         "hbm_side_bytes_per_launch": fetch_raw * (corr if corr else 1.0) + write,
         "hbm_side_bytes_per_launch_raw": fetch_raw + write,
-        "valu_issue_frac": round(c["SQ_ACTIVE_INST_VALU"] / (xcd_cycles / 4.0 * 1024.0), 4),
+        # (the counter sums the quad-cycles in which a WAVE has a VALU instruction in flight; instructions of different waves
+        # overlap in the pipeline, and the two counters come from two passes: a saturated VALU reads slightly above 1)
+        "valu_issue_frac": round(min(1.0, c["SQ_ACTIVE_INST_VALU"] / (xcd_cycles / 4.0 * 1024.0)), 4),
+        "valu_issue_frac_uncapped": round(c["SQ_ACTIVE_INST_VALU"] / (xcd_cycles / 4.0 * 1024.0), 4),
         "valu_lane_occupancy": round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_INSTS_VALU"]), 4),
         "valu_wave_instr_per_ray": round(c["SQ_INSTS_VALU"] / 1073741824.0, 3),
         "L2_hit_rate": round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4) if "TCC_HIT_sum" in c else None,
