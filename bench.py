@@ -22,7 +22,8 @@ The JSON line also carries
                 events on the library's own stream, against HBM peak.  `frac` can exceed 1: the model counts every node
                 fetch as memory traffic although L1 / L2 / Infinity Cache serve most of them; a fraction above 1 means
                 "cache-served", not "faster than HBM".  `traffic` / `hbm_counter_frac` (what the memory-side counters
-                saw) and `valu_issue_frac` (the roof that actually binds: VALU issue) come from the committed rocprofv3
+                saw), `valu_issue_frac` and the instruction counts per ray (the roofs that actually bind: VALU issue and the CU's
+                vector-memory path) come from the committed rocprofv3
                 PMC passes of THIS kernel source and THIS configuration (profiles/k_trace_counters.json) and are null
                 when either differs.
   cpu_baseline  the CPU oracle (a port, oracle/) timed on this box's host cores on a bounded texel subsample (N = 1 only).
@@ -418,9 +419,10 @@ def roofline_record(opts, args, W, H, world, visits, my_rays, kernel_ms):
         lane_occ = rec.get("valu_lane_occupancy")
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "frac_note": "algorithmic node bytes / HBM peak (SURVEY §8(d)); > 1 means the fetches are cache-served — the binding roof is "
-                         "VALU issue, see valu_issue_frac",
+            "frac_note": "algorithmic node bytes / HBM peak (SURVEY §8(d)); > 1 means the fetches are cache-served — what binds is VALU "
+                         "issue (valu_issue_frac) beside the CU's vector-memory path (vmem_wave_instr_per_ray; DESIGN.md §3.1 (d))",
             "hbm_counter_frac": hbm_frac, "valu_issue_frac": valu_frac, "valu_lane_occupancy": lane_occ,
+            "valu_wave_instr_per_ray": (rec or {}).get("valu_wave_instr_per_ray"), "vmem_wave_instr_per_ray": (rec or {}).get("vmem_wave_instr_per_ray"),
             "counters": (rec or {}).get("provenance") or why,
             "kernel": "k_trace", "kernel_ms": round(kernel_ms, 3), "kernel_source_sha256_16": kernel_source_hash(),
             "bytes_per_ray": round(b_ray, 1), "bytes_per_ray_build": round(b_ray_build, 1),

@@ -75,6 +75,7 @@ def main():
         "valu_issue_frac_uncapped": round(c["SQ_ACTIVE_INST_VALU"] / (xcd_cycles / 4.0 * 1024.0), 4),
         "valu_lane_occupancy": round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_INSTS_VALU"]), 4),
         "valu_wave_instr_per_ray": round(c["SQ_INSTS_VALU"] / 1073741824.0, 3),
+        "vmem_wave_instr_per_ray": round(c["SQ_INSTS_VMEM_RD"] / 1073741824.0, 3) if "SQ_INSTS_VMEM_RD" in c else None,
         "L2_hit_rate": round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4) if "TCC_HIT_sum" in c else None,
         "shader_cycles_per_xcd_in_pmc_pass": xcd_cycles,
         "wave_time_share": ({"issuing": round(c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], 4),
