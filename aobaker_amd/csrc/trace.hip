@@ -81,6 +81,7 @@ struct TraceParams {
     uint32_t self_hidden;          // ... and whether its rays ignore its own triangles
     int32_t refill_idle;           // lanes without a ray that trigger the refill section
     int32_t leaf_wait;             // lanes parked at a leaf that trigger the leaf section
+    uint32_t scalar_min;           // lanes on one node that make a scalar step (refill section) worth its pass
 };
 
 // exact float -> Q32.32 (a float times 2^32 is exact; the conversion truncates)
@@ -132,9 +133,9 @@ void k_trace(TraceParams p)
     const __amdgpu_buffer_rsrc_t nodes_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.nodes4q, 0, 0xffffffff, 0x00020000);
     // any hit: the rays of a refill start together and visit the top of the tree together, in the refill section
     constexpr bool SCALAR_STEPS = QUANT == 2 && ANYHIT;
-    // lanes on one node that make a scalar step worth its pass: all but a few of a refill's rays (measured on BASELINE configs[2]
-    // at 42 rays per refill: 16 / 24 / 32 / 40 / 48 lanes -> 73.3 / 71.9 / 71.2 / 70.9 / 72.4 ms; the root alone 71.8, none 73.9)
-    constexpr uint32_t kScalarMin = 40;
+    // lanes on one node that make a scalar step worth its pass: all but two of a refill's rays (p.scalar_min; measured on BASELINE
+    // configs[2] at 42 rays per refill: 16 / 24 / 32 / 40 / 48 lanes -> 73.3 / 71.9 / 71.2 / 70.9 / 72.4 ms; the root alone 71.8, none 73.9)
+    const uint32_t kScalarMin = p.scalar_min;
     // overflow stack entry e of this lane lives at gstack[(e * gridDim.x + blockIdx.x) * 64 + lane] (computed on use:
     // the path is cold and the registers are better spent on occupancy)
     auto gs_slot = [&](int e) -> uint32_t* { return p.gstack + ((uint64_t)e * gridDim.x + blockIdx.x) * kWave + lane; };
@@ -640,6 +641,7 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
         // 76.2 -> 74.1 ms, configs[1] +5 %); closest-hit and weighted scoring keep 24 (configs[4] loses 4.5 % at 42)
         p.refill_idle = knob(o.trace_refill_idle, (o.sampler == AOB_SAMPLER_COSINE && o.use_any_hit) ? 42 : 24);
         p.leaf_wait = knob(o.trace_leaf_wait, 16);
+        p.scalar_min = (uint32_t)max(8, p.refill_idle - 2);      // (slack 0 / 2 / 4 / 6 / 10: the same within 0.3 %)
         cosine_grid(o.sample_count, p.grid);
         // one launch per section: two sections of a material may cover the same texel, and
         // their contributions are added in section order (BakeEngine.cpp:473,659)
