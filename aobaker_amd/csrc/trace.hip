@@ -44,6 +44,31 @@ typedef float v2f __attribute__((ext_vector_type(2)));    // a register pair for
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 as_uint4(v4u v) { return make_uint4(v.x, v.y, v.z, v.w); }
 
+// Measurement hooks (tools/build_variants.py, profiles/r03/roofs/): N more vector-ALU instructions / N more 4-byte loads
+// from the lane's own node per inner visit.  Compiled out (0) in the product; they never change a result.
+#ifndef AOB_EXP_VALU
+#define AOB_EXP_VALU 0
+#endif
+#ifndef AOB_EXP_LOAD
+#define AOB_EXP_LOAD 0
+#endif
+#ifndef AOB_SLAB_FMA2
+#define AOB_SLAB_FMA2 1
+#endif
+#ifndef AOB_VISIT_BRANCHLESS
+#define AOB_VISIT_BRANCHLESS 1
+#endif
+
+#ifndef AOB_TRACE_STATS
+#define AOB_TRACE_STATS 0          // diagnostic build (tools/build_variants.py stats=-DAOB_TRACE_STATS=1): loop counters in g_trace_stats
+#endif
+#if AOB_TRACE_STATS
+__device__ unsigned long long g_trace_stats[16];
+#define AOB_STAT(i, v) do { if (lane == 0) st_[i] += (unsigned long long)(v); } while (0)
+#else
+#define AOB_STAT(i, v) do { } while (0)
+#endif
+
 struct TraceParams {
     const float4* nodes;
     const uint4* nodesq;           // QUANT 1: 2 x uint4 per node (AobBvh2QNode)
@@ -84,6 +109,36 @@ struct TraceParams {
     uint32_t scalar_min;           // lanes on one node that make a scalar step (refill section) worth its pass
 };
 
+// One slab test of the any-hit walk over quantised 4-ary nodes: two v_perm_b32 per axis build the near and the far plane's float
+// (byte selectors per ray: min for rays that travel up the axis, max for rays that travel down it), (t_near, t_far) = (f_near, f_far)
+// * invdir + oxinvdir in units of tmax: the ray's span is [0, 1].  A box wholly beyond 1 passes (its near distance clamps to 1 <=
+// far) — harmless, the triangle test has the last word (the oracle's traverse4q does the same).
+__device__ __forceinline__ bool slab4q_anyhit(const uint4& c, const f3& invdir, const f3& oxinvdir, const uint3& nsel, const uint3& fsel, float& tn)
+{
+    constexpr uint32_t kHalf = 0x3f000000u;
+    const float nx = __uint_as_float(__builtin_amdgcn_perm(kHalf, c.x, nsel.x)), fx = __uint_as_float(__builtin_amdgcn_perm(kHalf, c.x, fsel.x));
+    const float ny = __uint_as_float(__builtin_amdgcn_perm(kHalf, c.y, nsel.y)), fy = __uint_as_float(__builtin_amdgcn_perm(kHalf, c.y, fsel.y));
+    const float nz = __uint_as_float(__builtin_amdgcn_perm(kHalf, c.z, nsel.z)), fz = __uint_as_float(__builtin_amdgcn_perm(kHalf, c.z, fsel.z));
+#if AOB_SLAB_FMA2
+    // Six v_fma_f32, not three v_pk_fma_f32: a plain FMA issues in ~2.3 cycles and overlaps the ~4.2-cycle v_perm_b32 beside it; the
+    // packed one is a 4.2-cycle instruction itself (tools/valu_probe.hip, profiles/r03/roofs/valu_probe.jsonl): -3.9 % on BASELINE
+    // configs[2].  (The closest-hit walk, full of compares and selects already, loses 3 % with it and keeps the packed form.)
+    // Inline asm: the SLP vectoriser would pack them again.
+    auto fma1 = [](float a, float b, float cc) { float r; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(cc)); return r; };
+    const float tnx = fma1(nx, invdir.x, oxinvdir.x), tfx = fma1(fx, invdir.x, oxinvdir.x);
+    const float tny = fma1(ny, invdir.y, oxinvdir.y), tfy = fma1(fy, invdir.y, oxinvdir.y);
+    const float tnz = fma1(nz, invdir.z, oxinvdir.z), tfz = fma1(fz, invdir.z, oxinvdir.z);
+#else
+    const v2f tx = __builtin_elementwise_fma((v2f){ nx, fx }, (v2f){ invdir.x, invdir.x }, (v2f){ oxinvdir.x, oxinvdir.x });
+    const v2f ty = __builtin_elementwise_fma((v2f){ ny, fy }, (v2f){ invdir.y, invdir.y }, (v2f){ oxinvdir.y, oxinvdir.y });
+    const v2f tz = __builtin_elementwise_fma((v2f){ nz, fz }, (v2f){ invdir.z, invdir.z }, (v2f){ oxinvdir.z, oxinvdir.z });
+    const float tnx = tx.x, tfx = tx.y, tny = ty.x, tfy = ty.y, tnz = tz.x, tfz = tz.y;
+#endif
+    tn = fminf(fmaxf(fmaxf(fmaxf(tnx, tny), tnz), 0.0f), 1.0f);
+    return tn <= fminf(fminf(tfx, tfy), tfz);
+}
+
+
 // exact float -> Q32.32 (a float times 2^32 is exact; the conversion truncates)
 __device__ __forceinline__ long long f2fix(float v)
 {
@@ -119,6 +174,9 @@ void k_trace(TraceParams p)
     __shared__ uint4 queue[kWave * 2];                  // ray queue: {dir.xyz, slot}, {1/dir.xyz, weight}
 
     const uint32_t lane = threadIdx.x;
+#if AOB_TRACE_STATS
+    unsigned long long st_[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#endif
     f3 q_origin = make_f3(0.f, 0.f, 0.f), q_scale = make_f3(0.f, 0.f, 0.f);
     if (QUANT) {
         q_origin = make_f3(p.quant_frame[0], p.quant_frame[1], p.quant_frame[2]);
@@ -215,18 +273,31 @@ void k_trace(TraceParams p)
     bool hit = false;
     uint32_t slot = 0;                         // the ray's surfel
     uint32_t addr = kInvalid;
-    int sp = 1;
+    // Any hit: the lane's stack top is kept as a BYTE offset into lds_stack (entry e of this lane lives at e * 256 + lane * 4): a
+    // push or a pop is the LDS access itself and one add, no address arithmetic.  Closest hit keeps the entry index (its ranked
+    // placement of up to three children computes entry numbers anyway; with byte offsets it spilt five more registers and
+    // lost 40 %).  Entries from LDS_N up live in the HBM overflow array.
+    constexpr bool BYTE_SP = ANYHIT != 0;
+    constexpr int kSpUnit = BYTE_SP ? 256 : 1;
+    constexpr int kLdsTop = LDS_N * kSpUnit;
+    const int sp_first = BYTE_SP ? (int)lane * 4 + 256 : 1;          // entry 1 (entry 0 is the sentinel)
+    int spa = sp_first;
+    auto lds_entry = [&](int at) -> uint32_t& { return BYTE_SP ? *(uint32_t*)((char*)lds_stack + at) : lds_stack[at * kWave + lane]; };
+    auto gs_entry = [&](int at) -> uint32_t* { return gs_slot((BYTE_SP ? at >> 8 : at) - LDS_N); };
+#if AOB_EXP_VALU || AOB_EXP_LOAD
+    uint32_t exp_acc = 0;
+#endif
 
     auto push = [&](uint32_t v) {
-        if (sp < LDS_N) lds_stack[sp * kWave + lane] = v;
-        else *gs_slot(sp - LDS_N) = v;
-        sp++;
+        if (spa < kLdsTop) lds_entry(spa) = v;
+        else *gs_entry(spa) = v;
+        spa += kSpUnit;
     };
     auto pop = [&]() -> uint32_t {
-        sp--;
+        spa -= kSpUnit;
         uint32_t v;
-        if (sp < LDS_N) { v = lds_stack[sp * kWave + lane]; asm volatile("" : "+v"(v)); }
-        else { v = *gs_slot(sp - LDS_N); asm volatile("" : "+v"(v)); }
+        if (spa < kLdsTop) { v = lds_entry(spa); asm volatile("" : "+v"(v)); }
+        else { v = *gs_entry(spa); asm volatile("" : "+v"(v)); }
         return v;
     };
     // ProcessIntersectionsComputeShader.hlsl:69-90: the ray's score goes to its surfel's sums
@@ -251,9 +322,11 @@ void k_trace(TraceParams p)
     };
 
     // ---- one visit of a quantised 4-ary node: four slab tests, the next node and the deferred children ----
-    auto visit4 = [&](const uint4& c0, const uint4& c1, const uint4& c2, const uint4& c3) {
+    auto visit4 = [&](const uint4& c0, const uint4& c1, const uint4& c2, const uint4& c3, bool shallow) {
             auto slab = [&](const uint4& c, float& tn) -> bool {
-                // two v_perm_b32 and one v_pk_fma_f32 per axis: (t_near, t_far) = (f_near, f_far) * invdir + oxinvdir
+                if (ANYHIT) return slab4q_anyhit(c, invdir, oxinvdir, nsel, fsel, tn);
+                // closest hit: intersect_bvh2_lds.cl:54-63 on the plane floats — near clamped at 0, far at the closest hit so far.
+                // (Written out here: as a function shared with the any-hit form the register allocator spilt three more values, +40 %.)
                 constexpr uint32_t kHalf = 0x3f000000u;
                 const v2f fx = { __uint_as_float(__builtin_amdgcn_perm(kHalf, c.x, nsel.x)), __uint_as_float(__builtin_amdgcn_perm(kHalf, c.x, fsel.x)) };
                 const v2f fy = { __uint_as_float(__builtin_amdgcn_perm(kHalf, c.y, nsel.y)), __uint_as_float(__builtin_amdgcn_perm(kHalf, c.y, fsel.y)) };
@@ -261,26 +334,28 @@ void k_trace(TraceParams p)
                 const v2f tx = __builtin_elementwise_fma(fx, (v2f){ invdir.x, invdir.x }, (v2f){ oxinvdir.x, oxinvdir.x });
                 const v2f ty = __builtin_elementwise_fma(fy, (v2f){ invdir.y, invdir.y }, (v2f){ oxinvdir.y, oxinvdir.y });
                 const v2f tz = __builtin_elementwise_fma(fz, (v2f){ invdir.z, invdir.z }, (v2f){ oxinvdir.z, oxinvdir.z });
-                float tf;
-                if (ANYHIT) {
-                    // distances in units of tmax: the ray's span is [0, 1].  A box wholly beyond 1 passes (its near distance
-                    // clamps to 1 <= far) — harmless, the triangle test has the last word (traverse4q in the oracle does the same)
-                    tn = fminf(fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0f), 1.0f);
-                    tf = fminf(fminf(tx.y, ty.y), tz.y);
-                } else {
-                    tn = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0f);
-                    tf = fminf(fminf(fminf(tx.y, ty.y), tz.y), closest_t);
-                }
+                tn = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0f);
+                const float tf = fminf(fminf(fminf(tx.y, ty.y), tz.y), closest_t);
                 return tn <= tf;
             };
             float k0, k1, k2, k3;
             // an empty slot holds an inverted box (min plane above max plane on every axis, bvh_build.hip k_emit_nodes4q): its
             // near distance exceeds its far distance whatever the ray, so it fails the test by itself — no compare of the ref
             const bool h0 = slab(c0, k0), h1 = slab(c1, k1), h2 = slab(c2, k2), h3 = slab(c3, k3);
-            if (!(h0 || h1 || h2 || h3)) {
+            if (ANYHIT && AOB_VISIT_BRANCHLESS && shallow) {
+                // any-hit: the answer does not depend on the visiting order — follow the first hit child, defer the rest.
+                // Every lane of the wavefront has four free entries in LDS (`shallow`): all four refs are written at the stack top, each
+                // advancing it only if its box was hit, and the walk goes on with what a pop returns — the first hit child (or, with no
+                // hit at all, the entry deferred before).  Same nodes in the same order as the conditional pushes below, no branches.
+                lds_entry(spa) = c3.w; spa += h3 ? 256 : 0;
+                lds_entry(spa) = c2.w; spa += h2 ? 256 : 0;
+                lds_entry(spa) = c1.w; spa += h1 ? 256 : 0;
+                lds_entry(spa) = c0.w; spa += h0 ? 256 : 0;
+                spa -= 256;
+                addr = lds_entry(spa);
+            } else if (!(h0 || h1 || h2 || h3)) {
                 addr = pop();
             } else if (ANYHIT) {
-                // any-hit: the answer does not depend on the visiting order — follow the first hit child, defer the rest
                 if (h3 && (h0 || h1 || h2)) push(c3.w);
                 if (h2 && (h0 || h1)) push(c2.w);
                 if (h1 && h0) push(c1.w);
@@ -295,12 +370,12 @@ void k_trace(TraceParams p)
                 const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
                 auto place = [&](bool h, int r, uint32_t ref) {
                     if (h && r > 0) {
-                        const int e = sp + (nh - 1) - r;
-                        if (e < LDS_N) lds_stack[e * kWave + lane] = ref; else *gs_slot(e - LDS_N) = ref;
+                        const int e = spa + (nh - 1) - r;
+                        if (e < kLdsTop) lds_entry(e) = ref; else *gs_entry(e) = ref;
                     }
                 };
                 place(h0, r0, c0.w); place(h1, r1, c1.w); place(h2, r2, c2.w); place(h3, r3, c3.w);
-                sp += nh - 1;
+                spa += nh - 1;
                 addr = (h0 && r0 == 0) ? c0.w : ((h1 && r1 == 0) ? c1.w : ((h2 && r2 == 0) ? c2.w : c3.w));
             }
     };
@@ -309,9 +384,11 @@ void k_trace(TraceParams p)
         const uint64_t active_m = __ballot(active);
         const bool more = q_count != 0u || gen_next < gen_end;
         if (active_m == 0ull && !more) break;
+        AOB_STAT(0, 1);
 
         // ---- refill section ----
         if (more && (kWave - __popcll(active_m) >= p.refill_idle || active_m == 0ull)) {
+            AOB_STAT(5, 1);
             for (int pass = 0; pass < 2; pass++) {
                 const uint64_t idle_m = __ballot(!active);
                 if (q_count != 0u) {
@@ -346,12 +423,13 @@ void k_trace(TraceParams p)
                             oxinvdir = make_f3(oxinvdir.x * p.inv_tmax, oxinvdir.y * p.inv_tmax, oxinvdir.z * p.inv_tmax);
                         }
                         if (!ANYHIT) closest_t = p.tmax;            // any hit: the bound never moves off tmax, no register for it
-                        hit = false; sp = 1;
+                        hit = false; spa = sp_first;
                         active = true;
                         addr = 0;
                         if (p.node_count == 0) finish();          // empty scene: every ray misses
                     }
                     const uint32_t taken = min((uint32_t)__popcll(idle_m), q_count);
+                    AOB_STAT(6, taken);
                     q_head = (q_head + taken) & (kWave - 1u);
                     q_count -= taken;
                 }
@@ -359,6 +437,7 @@ void k_trace(TraceParams p)
                 if (pass == 1 || q_count != 0u || gen_next >= gen_end) break;
                 // the queue is empty: sample gen_next of all 64 surfels, one per lane
                 const int32_t i = gen_next++;
+                AOB_STAT(7, 1);
                 const int32_t cell_x = gen_cx, cell_y = gen_cy;
                 if (++gen_cx == p.grid.sx) { gen_cx = 0; gen_cy++; }
                 if (valid) {
@@ -403,7 +482,7 @@ void k_trace(TraceParams p)
                                 n2 = make_uint4(nw[8], nw[9], nw[10], nw[11]), n3 = make_uint4(nw[12], nw[13], nw[14], nw[15]);
                     const bool here = active && addr == a0;
                     if (here) {
-                        visit4(n0, n1, n2, n3);
+                        visit4(n0, n1, n2, n3, false);
                         if (addr == kInvalid) finish();      // nothing left to visit: the ray ends here, before the leaf section sees it
                     }
                     // the next node: where the first lane of the group went, if enough of the others went with it
@@ -423,6 +502,7 @@ void k_trace(TraceParams p)
         // 69.6 -> 68.6 ms on BASELINE configs[2]; thresholds 8 / 12 / 16 / 20 / 24: 69.6 / 69.0 / 68.6 / 68.7 / 69.7)
         // (any hit; closest-hit scoring — configs[4] — loses 1.5 % with it and keeps "nobody left walking")
         if (__popcll(__ballot(at_leaf)) >= p.leaf_wait || (uint32_t)__popcll(inner_m) < (ANYHIT ? 16u : 1u)) {
+            { const uint64_t leaf_m_ = __ballot(at_leaf); AOB_STAT(3, 1); AOB_STAT(4, __popcll(leaf_m_)); (void)leaf_m_; }
             if (at_leaf) {
                 // QUANT 2: the ref may name a PAIR of triangles, p and p + 1 (AOB_PAIR_FLAG): both are fetched in one go
                 const float bound = ANYHIT ? p.tmax : closest_t;
@@ -463,6 +543,7 @@ void k_trace(TraceParams p)
         }
 
         // ---- inner section: intersect_bvh2_lds.cl:108-160 ----
+        if (inner_m) { AOB_STAT(1, 1); AOB_STAT(2, __popcll(inner_m)); }
         if (inner) {
           if (QUANT == 2) {
             // ---- 4-ary node: four slab tests per visit, children ranked only when the order matters ----
@@ -472,7 +553,18 @@ void k_trace(TraceParams p)
                         c1 = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(nodes_rsrc, noff + 16u, 0, 0)),
                         c2 = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(nodes_rsrc, noff + 32u, 0, 0)),
                         c3 = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(nodes_rsrc, noff + 48u, 0, 0));
-            visit4(c0, c1, c2, c3);
+#if AOB_EXP_LOAD
+            for (int k = 0; k < AOB_EXP_LOAD; k++) exp_acc ^= __builtin_amdgcn_raw_buffer_load_b32(nodes_rsrc, noff + 12u + 16u * (uint32_t)k, 0, 0);
+#endif
+#if AOB_EXP_VALU
+            for (int k = 0; k < AOB_EXP_VALU; k++) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(exp_acc) : "v"(addr));
+#endif
+            // (wave-uniform: no lane that visits a node now has fewer than four free stack entries in LDS)
+            const bool shallow = ANYHIT && AOB_VISIT_BRANCHLESS && __ballot(spa >= kLdsTop - 3 * 256) == 0ull;
+#if AOB_TRACE_STATS
+            if (!shallow && lane == (uint32_t)__builtin_ctzll(inner_m)) atomicAdd(&g_trace_stats[11], 1ull);
+#endif
+            visit4(c0, c1, c2, c3, shallow);
           } else {
             const float bound = ANYHIT ? p.tmax : closest_t;
             float s0x, s0y, s1x, s1y;
@@ -514,6 +606,12 @@ void k_trace(TraceParams p)
         }
         if (active && addr == kInvalid) finish();     // the one place a ray ends
     }
+#if AOB_EXP_VALU || AOB_EXP_LOAD
+    asm volatile("" :: "v"(exp_acc));
+#endif
+#if AOB_TRACE_STATS
+    if (lane == 0) { for (int i_ = 0; i_ < 12; i_++) { atomicAdd(&g_trace_stats[i_], st_[i_]); st_[i_] = 0; } }
+#endif
     __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS atomics have landed
 
     // ProcessIntersectionsComputeShader.hlsl:89-90: one surfel per cell per launch.  A workgroup that traced all
@@ -705,3 +803,14 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
 }
 
 } // namespace aob
+
+#if AOB_TRACE_STATS
+// diagnostic builds only: read and clear the loop counters
+extern "C" int aob_debug_trace_stats(unsigned long long* out)
+{
+    unsigned long long zero[16] = { 0 };
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(aob::g_trace_stats), sizeof zero) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(aob::g_trace_stats), zero, sizeof zero) != hipSuccess) return -1;
+    return 0;
+}
+#endif

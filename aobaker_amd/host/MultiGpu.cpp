@@ -16,6 +16,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdarg>
@@ -144,6 +145,17 @@ struct AobMultiGpuBake::Impl
 	std::vector<std::vector<int32_t>> rows;              // [material] strip cuts, n + 1 entries
 	std::vector<int> status;
 	std::vector<std::string> errors;
+	std::atomic<bool> giving_up{false};                  // a rank's exchange failed or timed out: the others stop waiting
+	bool broken = false;                                 // the communicators were aborted: no further Step
+	double exchange_timeout_ms = 30000.0;
+
+	// After any exchange error the communicators are ABORTED: a rank must not sit in a grouped ncclRecv (or a stream that
+	// holds one) for a send that will never come.  The bake is unusable afterwards and says so.
+	void abort_comms()
+	{
+		for (ncclComm_t& c : comms) if (c) { ncclCommAbort(c); c = nullptr; }
+		broken = true;
+	}
 
 	template <class F> int on_all(F f)
 	{
@@ -194,6 +206,10 @@ AobMultiGpuBake* AobMultiGpuBake::Create(const AobSceneDesc* scene, const AobOpt
 	d.errors.assign((size_t)d.n, std::string());
 	d.results.assign((size_t)d.n, std::vector<uint8_t*>(scene->material_count, nullptr));
 	for (uint32_t i = 0; i < scene->material_count; i++) d.rows.push_back(aob_equal_rows(scene->materials[i].height, d.n));
+	int visible = 0;
+	if (hipGetDeviceCount(&visible) != hipSuccess) visible = 0;
+	for (int dev : devices)
+		if (dev < 0 || dev >= visible) { set_error("device %d is not on this box (%d visible)", dev, visible); delete self; return nullptr; }
 	const bool distinct = std::set<int>(devices.begin(), devices.end()).size() == devices.size();
 	d.use_rccl = distinct && d.n > 1;
 	if (!distinct) d.balance = false;      // ranks that share a device time each other's work: nothing to balance by
@@ -250,6 +266,7 @@ AobMultiGpuBake::~AobMultiGpuBake()
 int AobMultiGpuBake::Step(AobMultiStepStats* stats)
 {
 	Impl& d = *impl;
+	if (d.broken) { set_error("an earlier exchange failed and the RCCL communicators were aborted: create the bake again"); return AOB_ERR_DEVICE; }
 	const int n = d.n;
 	const size_t nmat = d.materials.size();
 	std::vector<double> rank_ms((size_t)n, 0.0);
@@ -307,9 +324,9 @@ int AobMultiGpuBake::Step(AobMultiStepStats* stats)
 		});
 		if (rc != AOB_OK) return rc;
 		const bool reduce = !d.by_rows && overlapping[0] != 0;
-		// phase 2: the one exchange step, then device 0 resolves
+		// phase 2a: every rank ENQUEUES its side of the one exchange step (nothing waits here)
+		d.giving_up = false;
 		rc = d.on_all([&, i, reduce](int r) -> int {
-			AobBake* b = d.bakes[(size_t)r];
 			uint8_t* mine = d.results[(size_t)r][i];
 			hipStream_t stream = d.streams[(size_t)r];
 			if (n > 1 && d.use_rccl)
@@ -351,12 +368,46 @@ int AobMultiGpuBake::Step(AobMultiStepStats* stats)
 						if (e != hipSuccess) { d.errors[0] = std::string("hipMemcpyAsync: ") + hipGetErrorString(e); return AOB_ERR_DEVICE; }
 					}
 			}
+			return AOB_OK;
+		});
+		// a rank that could not enqueue its send leaves rank 0's grouped receive without a partner: abort, never wait
+		if (rc != AOB_OK) { if (d.use_rccl) d.abort_comms(); return rc; }
+		// phase 2b: wait for the exchange by POLLING the stream and the communicator's asynchronous error (a blocking stream
+		// sync cannot be called off), then device 0 resolves
+		rc = d.on_all([&, i](int r) -> int {
+			AobBake* b = d.bakes[(size_t)r];
+			if (n > 1 && d.use_rccl)
+			{
+				const double t = now_ms();
+				for (;;)
+				{
+					const hipError_t q = hipStreamQuery(d.streams[(size_t)r]);
+					if (q == hipSuccess) break;
+					if (q != hipErrorNotReady) { d.errors[(size_t)r] = std::string("hipStreamQuery: ") + hipGetErrorString(q); d.giving_up = true; return AOB_ERR_DEVICE; }
+					ncclResult_t async = ncclSuccess;
+					const ncclResult_t e = ncclCommGetAsyncError(d.comms[(size_t)r], &async);
+					if (e != ncclSuccess || async != ncclSuccess)
+					{
+						d.errors[(size_t)r] = std::string("RCCL (asynchronous): ") + ncclGetErrorString(e != ncclSuccess ? e : async);
+						d.giving_up = true;
+						return AOB_ERR_DEVICE;
+					}
+					if (d.giving_up) { d.errors[(size_t)r] = "another rank's exchange failed"; return AOB_ERR_DEVICE; }
+					if (now_ms() - t > d.exchange_timeout_ms)
+					{
+						d.errors[(size_t)r] = "the exchange of result strips did not finish within " + std::to_string((int)(d.exchange_timeout_ms / 1000.0)) + " s";
+						d.giving_up = true;
+						return AOB_ERR_DEVICE;
+					}
+					std::this_thread::sleep_for(std::chrono::microseconds(20));
+				}
+			}
 			int s = AOB_OK;
 			if (r == 0) s = aob_bake_resolve(b, (int32_t)i);
 			if (s == AOB_OK) s = aob_bake_sync(b);
 			return s;
 		});
-		if (rc != AOB_OK) return rc;
+		if (rc != AOB_OK) { if (d.use_rccl && d.giving_up) d.abort_comms(); return rc; }
 	}
 	const double wall = now_ms() - t0;
 	if (stats)

@@ -69,6 +69,8 @@ def parse_args():
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="gloo: REHEARSAL of the N-rank run where RCCL cannot form (ranks sharing one GPU): strips travel through host memory")
     ap.add_argument("--oversubscribe", action="store_true", help="rehearsal: rank r uses device r %% (visible devices)")
+    ap.add_argument("--launch-timeout", type=float, default=540.0, help="self-launched ranks: seconds before the parent ends all of them and reports an error")
+    ap.add_argument("--collective-timeout", type=float, default=120.0, help="torch.distributed timeout (s): a dead peer is an error, not a wait")
     return ap.parse_args()
 
 
@@ -85,6 +87,49 @@ def visible_devices():
         return 0
 
 
+def supervise(commands, deadline_s, poll_s=0.2, grace_s=5.0):
+    """Run one child per (argv, env) pair and watch ALL of them.  As soon as any exits non-zero, or `deadline_s` passes, the
+    others are terminated (SIGTERM, SIGKILL after `grace_s`): a rank that died must not leave its peers waiting in a
+    collective until a store / RCCL timeout.  Returns (exit codes, stdout of child 0, stderr tail per child, reason or None)."""
+    import tempfile
+    outs, procs = [], []
+    for argv, env in commands:
+        so, se = tempfile.TemporaryFile("w+"), tempfile.TemporaryFile("w+")
+        outs.append((so, se))
+        procs.append(subprocess.Popen(argv, env=env, stdout=so, stderr=se, text=True))
+    t0 = time.monotonic()
+    reason = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            reason = f"rank {bad[0]} exited with code {codes[bad[0]]}"
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() - t0 > deadline_s:
+            reason = f"ranks still running after {deadline_s:.0f} s"
+            break
+        time.sleep(poll_s)
+    if reason:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t1 = time.monotonic()
+        while any(p.poll() is None for p in procs) and time.monotonic() - t1 < grace_s:
+            time.sleep(0.05)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    codes = [p.wait() for p in procs]
+    texts = []
+    for so, se in outs:
+        so.seek(0); se.seek(0)
+        texts.append((so.read(), se.read()))
+        so.close(); se.close()
+    return codes, texts[0][0], [t[1][-2000:] for t in texts], reason
+
+
 def launch_ranks(args):
     import socket
     have = visible_devices()
@@ -93,29 +138,37 @@ def launch_ranks(args):
         print(msg, file=sys.stderr)
         print(json.dumps({"metric": "AO rays/sec", "value": None, "unit": "rays/s", "n_gpus": args.gpus, "skipped": msg}), flush=True)
         return 0
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    for attempt in range(3):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        commands = []
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            commands.append(([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env))
+        codes, out0, errs, reason = supervise(commands, args.launch_timeout)
+        # the port was free when probed; another process may have taken it since: once more on another
+        if reason and attempt < 2 and any("address already in use" in e.lower() or "eaddrinuse" in e.lower() for e in errs):
+            print(f"bench.py: port {port} was taken, launching the ranks again", file=sys.stderr)
+            continue
+        break
     line = None
     for l in (out0 or "").splitlines():
         if l.startswith("{"):
             line = l
         else:
             print(l, file=sys.stderr)
-    if line:
-        print(line, flush=True)
-    if any(codes) or not line:
-        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+    for r, e in enumerate(errs):
+        if e.strip() and (reason or r == 0):
+            print(f"---- rank {r} stderr (tail) ----\n{e}", file=sys.stderr)
+    if reason or any(codes) or not line:
+        why = reason or ("rank 0 printed no result line" if not line else f"rank exit codes {codes}")
+        print(f"bench.py: {why}; rank exit codes {codes}", file=sys.stderr)
+        print(json.dumps({"metric": "AO rays/sec", "value": None, "unit": "rays/s", "n_gpus": args.gpus, "error": why, "rank_exit_codes": codes}), flush=True)
         return 1
+    print(line, flush=True)
     return 0
 
 
@@ -147,11 +200,16 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        import datetime
+        limit = datetime.timedelta(seconds=args.collective_timeout)
         if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=limit)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        host_group = dist.new_group(backend="gloo")         # host-side waits that keep the GPUs idle (cpp_host leg)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=limit)
+        host_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=max(args.collective_timeout, 300.0)))   # host-side waits that keep the GPUs idle (cpp_host leg)
+        # fault injection for the launcher's tests (tests/test_gpu_dist.py): this rank dies before the first gather
+        if os.environ.get("AOB_BENCH_FAIL_RANK") == str(rank):
+            raise SystemExit(f"rank {rank}: AOB_BENCH_FAIL_RANK")
 
     strong = args.scaling == "strong"
     if world == 1:

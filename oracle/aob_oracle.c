@@ -1864,6 +1864,93 @@ int orc_kary_visits(const AobBvhNode* nodes2, uint64_t node_count2, const OrcRay
     return 0;
 }
 
+/* The four slab tests of one quantised 4-ary node for a ray prepared as traverse4q prepares it (same arithmetic). */
+typedef struct { float fa[3], fb[3]; int down[3]; int any_hit; } Ray4q;
+static inline void ray4q_prepare(Ray4q* r, const AobQuantFrame* fr, f3 o, f3 d, float t_max, int any_hit)
+{
+    f3 invdir = safe_invdir(d);
+    const float inv[3] = { invdir.x, invdir.y, invdir.z };
+    const float oxi[3] = { -o.x * invdir.x, -o.y * invdir.y, -o.z * invdir.z };
+    const float inv_tmax = 1.0f / t_max;
+    for (int k = 0; k < 3; k++) {
+        const float origin2 = fmaf(-32768.0f, fr->scale[k], fr->origin[k]);
+        const float scale2 = fr->scale[k] * 32768.0f;
+        r->fb[k] = fmaf(origin2, inv[k], oxi[k]);
+        r->fa[k] = scale2 * inv[k];
+        if (any_hit) { r->fa[k] = r->fa[k] * inv_tmax; r->fb[k] = r->fb[k] * inv_tmax; }
+        uint32_t bits; memcpy(&bits, &inv[k], 4);
+        r->down[k] = (int)(bits >> 31);
+    }
+    r->any_hit = any_hit;
+}
+static inline int ray4q_box(const Ray4q* r, const uint32_t* c, float closest_t)
+{
+    float tn[3], tf[3];
+    for (int k = 0; k < 3; k++) {
+        const uint32_t nearh = r->down[k] ? c[k] >> 16 : c[k] & 0xffffu, farh = r->down[k] ? c[k] & 0xffffu : c[k] >> 16;
+        tn[k] = fmaf(plane_float(nearh), r->fa[k], r->fb[k]);
+        tf[k] = fmaf(plane_float(farh), r->fa[k], r->fb[k]);
+    }
+    float t0 = max3n(tn[0], tn[1], tn[2]), t1 = min3n(tf[0], tf[1], tf[2]);
+    if (r->any_hit) t0 = t0 != t0 ? 0.0f : fminf(fmaxf(t0, 0.0f), 1.0f);
+    else { t0 = fmaxf(t0, 0.0f); t1 = fminf(t1, closest_t); }
+    return t0 <= t1;
+}
+
+/* Measurement (tests/measure_entry_lists.py): the any-hit walk of k_trace's ENTRY mode, one ray at a time.  `entries` is a
+ * tile's entry list (trace.hip k_tile_entries): word e = node | (parent entry * 4 + parent slot) << 26, entry 0 the root.
+ * Phase 1 tests the four children of every entry whose own box the ray entered (bit 4e + j of the mask: child j of entry e
+ * was hit); phase 2 walks the hit children that are not entries themselves, last bit first, in traverse4q's order, and stops at
+ * the first triangle hit.  Counts what each phase costs; `hits` must equal traverse4q's (the visited set is the same). */
+int orc_entry_walk(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const AobLeafTri* tris,
+                   const OrcRay* rays, uint64_t n, const uint32_t* entries, int32_t n_entries, OrcEntryStats* out)
+{
+    if (count4 == 0 || n_entries < 1 || n_entries > 8) return AOB_ERR_INVALID_ARGUMENT;
+    uint32_t expanded = 0;
+    for (int e = 1; e < n_entries; e++) expanded |= 1u << ((entries[e] >> 26) & 31u);
+    for (uint64_t i = 0; i < n; i++) {
+        const OrcRay* rr = &rays[i];
+        if (rr->extra[1] == 0) continue;
+        const f3 o = f3_make(rr->o[0], rr->o[1], rr->o[2]), d = f3_make(rr->d[0], rr->d[1], rr->d[2]);
+        const float t_max = rr->o[3];
+        Ray4q r; ray4q_prepare(&r, fr, o, d, t_max, 1);
+        uint32_t mask = 0;
+        for (int e = 0; e < n_entries; e++) {
+            const uint32_t node = entries[e] & 0x3ffffffu;
+            if (e > 0 && !((mask >> ((entries[e] >> 26) & 31u)) & 1u)) continue;
+            out->entries_tested++;
+            for (int j = 0; j < 4; j++) if (ray4q_box(&r, &nq[node].w[4 * j], t_max)) mask |= 1u << (4 * e + j);
+        }
+        mask &= ~expanded;
+        out->rays++;
+        out->mask_bits += (uint64_t)__builtin_popcount(mask);
+        int hit = 0;
+        uint32_t stack[ORC_STACK4]; int sp = 0;
+        for (int b = 0; b < 32; b++) if ((mask >> b) & 1u) stack[sp++] = nq[entries[b >> 2] & 0x3ffffffu].w[4 * (b & 3) + 3];
+        while (sp > 0 && !hit) {
+            const uint32_t node = stack[--sp];
+            if (!(node & AOB_LEAF_FLAG)) {
+                out->inner_visits++;
+                int chit[4], nhit = 0;
+                for (int j = 0; j < 4; j++) { chit[j] = ray4q_box(&r, &nq[node].w[4 * j], t_max); nhit += chit[j]; }
+                if (sp + nhit > ORC_STACK4) return AOB_ERR_BVH_TOO_DEEP;
+                for (int j = 3; j >= 0; j--) if (chit[j]) stack[sp++] = nq[node].w[4 * j + 3];
+            } else {
+                const AobLeafTri* tr = &tris[node & ~(AOB_LEAF_FLAG | AOB_PAIR_FLAG)];
+                const int count = (node & AOB_PAIR_FLAG) ? 2 : 1;
+                for (int k = 0; k < count; k++) {
+                    out->leaf_visits++;
+                    const float t = intersect_triangle(o, d, f3_make(tr[k].v0[0], tr[k].v0[1], tr[k].v0[2]), f3_make(tr[k].v1[0], tr[k].v1[1], tr[k].v1[2]),
+                                                       f3_make(tr[k].v2[0], tr[k].v2[1], tr[k].v2[2]), t_max);
+                    if (t < t_max) hit = 1;
+                }
+            }
+        }
+        out->hits += (uint64_t)hit;
+    }
+    return 0;
+}
+
 /* A top-down binned-SAH BVH2 (16 bins per axis, one triangle per leaf) in the AobBvhNode layout — the tree quality a
  * treelet-restructuring pass over the PLOC tree could approach at best.  CPU only; never built on the GPU. */
 typedef struct { uint32_t begin, end, index; } SahTask;

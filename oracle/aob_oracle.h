@@ -190,6 +190,10 @@ int orc_walk4q(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr,
 int orc_kary_visits(const AobBvhNode* nodes2, uint64_t node_count2, const OrcRay* rays, uint64_t n, int32_t levels, int32_t pairs,
                     int32_t any_hit, OrcTraceStats* st, uint64_t* box_tests);
 uint64_t orc_bvh_build_sah(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes, uint32_t* depth);
+/* the any-hit walk with a tile's entry list (trace.hip, ENTRY mode), counted per phase: tests/measure_entry_lists.py */
+typedef struct OrcEntryStats { uint64_t rays, hits, inner_visits, leaf_visits, entries_tested, mask_bits; } OrcEntryStats;
+int orc_entry_walk(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const AobLeafTri* tris,
+                   const OrcRay* rays, uint64_t n, const uint32_t* entries, int32_t n_entries, OrcEntryStats* out);
 
 #ifdef __cplusplus
 }

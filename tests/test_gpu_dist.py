@@ -76,3 +76,26 @@ def test_bench_rank_processes_rehearsed_on_one_gpu(ranks):
     assert len(rows) == ranks and rows[0][0] == 0 and rows[-1][1] == 256 and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
     assert len(many["balance"]["warmup_history"]) == 3 and len(many["stage_ms"]["rank_build_raster_trace"]) == ranks
     assert many["config"]["image_crc32"] == one["config"]["image_crc32"]
+
+
+def test_bench_rank_failure_ends_the_run_with_an_error_line():
+    """A rank that dies before the first gather (fault injected: AOB_BENCH_FAIL_RANK) ends the whole N-rank run in seconds —
+    one JSON line with value null and the failing rank named, exit code non-zero — instead of the peers waiting in the
+    gather until a collective timeout."""
+    import json
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["AOB_BENCH_FAIL_RANK"] = "1"
+    t = time.monotonic()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--oversubscribe", "--atlas", "256", "--grid", "96",
+                          "--spp", "32", "--steps", "1", "--warmup", "1", "--no-cpp-host", "--no-cpu-baseline", "--no-wallclock"],
+                         capture_output=True, text=True, env=env, timeout=600)
+    took = time.monotonic() - t
+    assert out.returncode != 0
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["value"] is None and "rank 1 exited" in line["error"] and line["rank_exit_codes"][1] != 0
+    assert "AOB_BENCH_FAIL_RANK" in out.stderr
+    assert took < 120.0          # imports + scene generation of the surviving rank; never a collective timeout

@@ -160,6 +160,27 @@ def test_bench_launches_its_own_ranks_or_says_why_not():
     assert line["n_gpus"] == 2 and line["value"] is None and "needs 2 devices" in line["skipped"]
 
 
+def test_bench_supervisor_ends_the_other_ranks_when_one_dies():
+    """bench.supervise: a rank that exits non-zero must not leave its peers waiting in a collective — the parent terminates
+    them within seconds and names the rank; a clean run returns every rank's 0 and rank 0's stdout; a run past its deadline
+    is ended too."""
+    import sys
+    import time
+    import bench
+    py = sys.executable
+    hang = [py, "-c", "import time; print('started', flush=True); time.sleep(600)"]
+    t = time.monotonic()
+    codes, out0, errs, reason = bench.supervise([(hang, None), ([py, "-c", "import sys; sys.stderr.write('boom'); sys.exit(3)"], None), (hang, None)], 120.0)
+    assert time.monotonic() - t < 30.0
+    assert reason == "rank 1 exited with code 3" and codes[1] == 3 and codes[0] != 0 and codes[2] != 0
+    assert "started" in out0 and "boom" in errs[1]
+    codes, out0, errs, reason = bench.supervise([([py, "-c", "print('{\"ok\": 1}')"], None), ([py, "-c", "pass"], None)], 60.0)
+    assert codes == [0, 0] and reason is None and out0.strip() == '{"ok": 1}'
+    t = time.monotonic()
+    codes, _, _, reason = bench.supervise([(hang, None)], 1.0)
+    assert time.monotonic() - t < 20.0 and "still running" in reason and codes[0] != 0
+
+
 def test_rebalance_rows_levels_the_ranks_and_matches_the_cpp_host():
     """aobaker_amd.dist.rebalance_rows == aob_rebalance_rows (MultiGpu.cpp), and re-cutting by measured cost converges."""
     import ctypes as C

@@ -1,69 +1,248 @@
-// valu_probe.hip — how many cycles does one wave64 VALU instruction cost a SIMD of gfx950?
-// Settles the issue-rate model behind DESIGN.md §3.1 (k_trace is VALU-issue bound): independent v_fma_f32 /
-// v_pk_fma_f32 / v_perm_b32 / v_max3_f32 streams at 1, 2, 4 and 8 wavefronts per SIMD on every CU.
-// Build: hipcc -O3 --offload-arch=gfx950 tools/valu_probe.hip -o gpurun_out/valu_probe
+// valu_probe.hip — what does one wave64 vector instruction cost a SIMD of gfx950, IN SHADER CYCLES?
+//
+// Round 2's version timed the launches with HIP events and divided by 2.4 GHz; that reads a clock the chip does not
+// hold under a dense VALU loop.  This version stamps every wavefront with s_memtime (shader cycles) and s_memrealtime
+// (100 MHz) around its loop: cycles per wave-instruction per SIMD = median(delta s_memtime) / (instructions of the
+// SIMD's W co-resident wavefronts), and the in-kernel clock = delta s_memtime / delta s_memrealtime x 100 MHz
+// (MI355X_MICROARCH.md, DVFS give-back (6)); the throughput figure is launch time x that clock.  Every launch is 4 x W wavefronts per CU (one-wavefront workgroups, W per
+// SIMD), every CU busy.  Kinds: the opcodes k_trace's box test is made of, the VOP2 baseline, and three whole box tests
+// (the kernel's v_perm_b32 + v_pk_fma_f32 form and two candidates) — one JSON line each.
+// Build: make -C tools          Run: tools/_valu_probe > gpurun_out/valu_probe.jsonl
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdint>
 #include <cstdio>
 #include <vector>
 
-#define REP16(x) x x x x x x x x x x x x x x x x
+#define REP4(x) x x x x
+#define REP16(x) REP4(REP4(x))
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+enum Kind { FMA, PK_FMA, PERM, MAX3, MIN3_CLAMP, XOR, CNDMASK, ALIGNBIT, FMA_MIX, MUL, CMP, ADD_U32, LSHL_OR, RCP, MOV,
+            FMA_SGPR, PERM_SGPR, BOX_PERM_PK, BOX_ALIGN_MIX, BOX_PERM_FMA, SALU_AND,
+            MAX_F32, CNDMASK_VCC, AND_B32, LSHLREV, CVT_UBYTE, CVT_F16, BFE, AND_OR, SUB_F32, MIX_1S1F, MIX_1S2F, MIX_2S1F, MIX_1S3F, BOX_PERM_PK2, KIND_COUNT };
+static const char* kind_name[KIND_COUNT] = {
+    "v_fma_f32", "v_pk_fma_f32", "v_perm_b32", "v_max3_f32", "v_min3_f32", "v_xor_b32", "v_cndmask_b32", "v_alignbit_b32",
+    "v_fma_mix_f32", "v_mul_f32", "v_cmp_le_f32", "v_add_u32", "v_lshl_or_b32", "v_rcp_f32", "v_mov_b32",
+    "v_fma_f32 (one SGPR source)", "v_perm_b32 (one SGPR source)",
+    "box: 6 v_perm_b32 + 3 v_pk_fma_f32 + max3 + min3 + cmp (k_trace)", "box: 3 v_alignbit_b32 + 6 v_fma_mix_f32 + max3 + min3 + cmp",
+    "box: 6 v_perm_b32 + 6 v_fma_f32 + max3 + min3 + cmp", "s_and_b64",
+    "v_max_f32", "v_cndmask_b32 (vcc, VOP2)", "v_and_b32", "v_lshlrev_b32", "v_cvt_f32_ubyte1", "v_cvt_f32_f16", "v_bfe_u32", "v_and_or_b32", "v_sub_f32",
+    "mix: 1 v_perm_b32 + 1 v_fma_f32", "mix: 1 v_perm_b32 + 2 v_fma_f32", "mix: 2 v_perm_b32 + 1 v_fma_f32", "mix: 1 v_perm_b32 + 3 v_fma_f32",
+    "box: 6 v_perm_b32 + 3 v_pk_fma_f32 + max3 + min3 + cmp, no register copies" };
+// vector instructions per loop iteration
+static int kind_instr(int k)
+{
+    switch (k) {
+    case BOX_PERM_PK: case BOX_ALIGN_MIX: case BOX_PERM_PK2: return 16 * 12;
+    case BOX_PERM_FMA: return 16 * 15;
+    case MIX_1S1F: return 16 * 4; case MIX_1S2F: return 16 * 6; case MIX_2S1F: return 16 * 6; case MIX_1S3F: return 16 * 8;
+    default: return 64;
+    }
+}
 
 template <int KIND>
-__global__ __launch_bounds__(64) void k_probe(float* out, int iters)
+__global__ __launch_bounds__(64) void k_probe(uint64_t* stamps, float* out, int iters)
 {
-    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
     float b = 1.0001f, c = 0.5f;
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    v2f p0 = { a0, a1 }, p1 = { a2, a3 }, p2 = { a4, a5 }, p3 = { a6, a7 }, pb = { b, b }, pc = { c, c };
-    unsigned u0 = threadIdx.x, u1 = u0 * 3, u2 = u0 * 5, u3 = u0 * 7, sel = 0x07010c0c;
+    v2f p0 = { a0, a1 }, p1 = { a2, a3 }, p2 = { a0 + 4, a1 + 5 }, p3 = { a2 + 6, a3 + 7 }, pb = { b, b }, pc = { c, c };
+    unsigned u0 = threadIdx.x * 0x9e3779b9u, u1 = u0 * 3, u2 = u0 * 5, u3 = u0 * 7, sel = 0x0701000c, sel2 = 0x0703020c, rot = (threadIdx.x & 1) << 4;
+    unsigned sb = __builtin_amdgcn_readfirstlane(u0 | 0x80008000u);
+    float sf = __builtin_amdgcn_readfirstlane(__float_as_uint(b)) ? b : c;
+    asm volatile("" : "+s"(sb));
+    unsigned long long sm = 0x5555aaaa5555aaaaull, sn = ~0ull;
+    // a node's three plane words per box (the box kinds), per lane
+    unsigned nx = u0 | 0x80008000u, ny = u1 | 0x80008000u, nz = u2 | 0x80008000u;
+    float ix = 1.5f + a0 * 1e-3f, iy = -0.7f, iz = 2.25f, ox = -0.3f, oy = 0.9f, oz = -1.1f;
+    v2f pix = { ix, ix }, piy = { iy, iy }, piz = { iz, iz }, pox = { ox, ox }, poy = { oy, oy }, poz = { oz, oz };
+    const uint64_t t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int i = 0; i < iters; i++) {
-        if (KIND == 0) {
+        if (KIND == FMA) {
             REP16(asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5"
                                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));)
-        } else if (KIND == 1) {
+        } else if (KIND == PK_FMA) {
             REP16(asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5"
                                : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pb), "v"(pc));)
-        } else if (KIND == 2) {
-            REP16(asm volatile("v_perm_b32 %0, %0, %4, %5\n v_perm_b32 %1, %1, %4, %5\n v_perm_b32 %2, %2, %4, %5\n v_perm_b32 %3, %3, %4, %5"
-                               : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(u0), "v"(sel));)
-        } else {
+        } else if (KIND == PERM) {
+            REP16(asm volatile("v_perm_b32 %0, 0.5, %0, %4\n v_perm_b32 %1, 0.5, %1, %4\n v_perm_b32 %2, 0.5, %2, %4\n v_perm_b32 %3, 0.5, %3, %4"
+                               : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(sel));)
+        } else if (KIND == MAX3) {
             REP16(asm volatile("v_max3_f32 %0, %0, %4, %5\n v_max3_f32 %1, %1, %4, %5\n v_max3_f32 %2, %2, %4, %5\n v_max3_f32 %3, %3, %4, %5"
                                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));)
+        } else if (KIND == MIN3_CLAMP) {
+            REP16(asm volatile("v_min3_f32 %0, %0, %4, %5 clamp\n v_min3_f32 %1, %1, %4, %5 clamp\n v_min3_f32 %2, %2, %4, %5 clamp\n v_min3_f32 %3, %3, %4, %5 clamp"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));)
+        } else if (KIND == XOR) {
+            REP16(asm volatile("v_xor_b32 %0, %0, %4\n v_xor_b32 %1, %1, %4\n v_xor_b32 %2, %2, %4\n v_xor_b32 %3, %3, %4"
+                               : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(sel));)
+        } else if (KIND == CNDMASK) {
+            REP16(asm volatile("v_cndmask_b32 %0, %0, %4, %5\n v_cndmask_b32 %1, %1, %4, %5\n v_cndmask_b32 %2, %2, %4, %5\n v_cndmask_b32 %3, %3, %4, %5"
+                               : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(sel), "s"(sm));)
+        } else if (KIND == ALIGNBIT) {
+            REP16(asm volatile("v_alignbit_b32 %0, %0, %0, %4\n v_alignbit_b32 %1, %1, %1, %4\n v_alignbit_b32 %2, %2, %2, %4\n v_alignbit_b32 %3, %3, %3, %4"
+                               : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(rot));)
+        } else if (KIND == FMA_MIX) {
+            REP16(asm volatile("v_fma_mix_f32 %0, %4, %5, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %4, %5, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                               "v_fma_mix_f32 %2, %4, %5, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %4, %5, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(u0), "v"(b));)
+        } else if (KIND == MUL) {
+            REP16(asm volatile("v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));)
+        } else if (KIND == CMP) {
+            REP16(asm volatile("v_cmp_le_f32 vcc, %0, %1\n v_cmp_le_f32 vcc, %1, %2\n v_cmp_le_f32 vcc, %2, %3\n v_cmp_le_f32 vcc, %3, %0"
+                               : : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "vcc");)
+        } else if (KIND == ADD_U32) {
+            REP16(asm volatile("v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4"
+                               : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(sel));)
+        } else if (KIND == LSHL_OR) {
+            REP16(asm volatile("v_lshl_or_b32 %0, %0, 8, %4\n v_lshl_or_b32 %1, %1, 8, %4\n v_lshl_or_b32 %2, %2, 8, %4\n v_lshl_or_b32 %3, %3, 8, %4"
+                               : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(sel));)
+        } else if (KIND == RCP) {
+            REP16(asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+        } else if (KIND == MOV) {
+            REP16(asm volatile("v_mov_b32 %0, %4\n v_mov_b32 %1, %4\n v_mov_b32 %2, %4\n v_mov_b32 %3, %4"
+                               : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(sel));)
+        } else if (KIND == FMA_SGPR) {
+            REP16(asm volatile("v_fma_f32 %0, %4, %0, %5\n v_fma_f32 %1, %4, %1, %5\n v_fma_f32 %2, %4, %2, %5\n v_fma_f32 %3, %4, %3, %5"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "s"(sf), "v"(c));)
+        } else if (KIND == PERM_SGPR) {
+            REP16(asm volatile("v_perm_b32 %0, 0.5, %4, %5\n v_perm_b32 %1, 0.5, %4, %6\n v_perm_b32 %2, 0.5, %4, %5\n v_perm_b32 %3, 0.5, %4, %6"
+                               : "=v"(u0), "=v"(u1), "=v"(u2), "=v"(u3) : "s"(sb), "v"(sel), "v"(sel2));)
+        } else if (KIND == BOX_PERM_PK) {
+            // k_trace's box test (trace.hip visit4): planes as float bytes, near / far plane by the ray's selectors
+            REP16(asm volatile(
+                "v_perm_b32 %0, 0.5, %6, %9\n v_perm_b32 %1, 0.5, %6, %10\n v_perm_b32 %2, 0.5, %7, %9\n v_perm_b32 %3, 0.5, %7, %10\n"
+                "v_perm_b32 %4, 0.5, %8, %9\n v_perm_b32 %5, 0.5, %8, %10\n"
+                "v_pk_fma_f32 %[q0], %[q0], %[pix], %[pox]\n v_pk_fma_f32 %[q1], %[q1], %[piy], %[poy]\n v_pk_fma_f32 %[q2], %[q2], %[piz], %[poz]\n"
+                "v_max3_f32 %0, %0, %2, %4 clamp\n v_min3_f32 %1, %1, %3, %5\n v_cmp_le_f32 vcc, %0, %1"
+                : "+v"(p0.x), "+v"(p0.y), "+v"(p1.x), "+v"(p1.y), "+v"(p2.x), "+v"(p2.y)
+                : "v"(nx), "v"(ny), "v"(nz), "v"(sel), "v"(sel2), [q0] "v"(p0), [q1] "v"(p1), [q2] "v"(p2),
+                  [pix] "v"(pix), [piy] "v"(piy), [piz] "v"(piz), [pox] "v"(pox), [poy] "v"(poy), [poz] "v"(poz) : "vcc");)
+        } else if (KIND == BOX_ALIGN_MIX) {
+            // candidate: planes as fp16 halves (min | max << 16), rotated so that the near plane is the low half
+            REP16(asm volatile(
+                "v_alignbit_b32 %6, %9, %9, %12\n v_alignbit_b32 %7, %10, %10, %12\n v_alignbit_b32 %8, %11, %11, %12\n"
+                "v_fma_mix_f32 %0, %6, %13, %16 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %6, %13, %16 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                "v_fma_mix_f32 %2, %7, %14, %17 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %7, %14, %17 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                "v_fma_mix_f32 %4, %8, %15, %18 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %5, %8, %15, %18 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                "v_max3_f32 %0, %0, %2, %4 clamp\n v_min3_f32 %1, %1, %3, %5\n v_cmp_le_f32 vcc, %0, %1"
+                : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(p3.x), "=&v"(p3.y), "=&v"(u0), "=&v"(u1), "=&v"(u2)
+                : "v"(nx), "v"(ny), "v"(nz), "v"(rot), "v"(ix), "v"(iy), "v"(iz), "v"(ox), "v"(oy), "v"(oz) : "vcc");)
+        } else if (KIND == BOX_PERM_FMA) {
+            REP16(asm volatile(
+                "v_perm_b32 %0, 0.5, %6, %9\n v_perm_b32 %1, 0.5, %6, %10\n v_perm_b32 %2, 0.5, %7, %9\n v_perm_b32 %3, 0.5, %7, %10\n"
+                "v_perm_b32 %4, 0.5, %8, %9\n v_perm_b32 %5, 0.5, %8, %10\n"
+                "v_fma_f32 %0, %0, %11, %14\n v_fma_f32 %1, %1, %11, %14\n v_fma_f32 %2, %2, %12, %15\n v_fma_f32 %3, %3, %12, %15\n"
+                "v_fma_f32 %4, %4, %13, %16\n v_fma_f32 %5, %5, %13, %16\n"
+                "v_max3_f32 %0, %0, %2, %4 clamp\n v_min3_f32 %1, %1, %3, %5\n v_cmp_le_f32 vcc, %0, %1"
+                : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(p3.x), "=&v"(p3.y)
+                : "v"(nx), "v"(ny), "v"(nz), "v"(sel), "v"(sel2), "v"(ix), "v"(iy), "v"(iz), "v"(ox), "v"(oy), "v"(oz) : "vcc");)
+        } else if (KIND == MAX_F32) {
+            REP16(asm volatile("v_max_f32 %0, %0, %4\n v_max_f32 %1, %1, %4\n v_max_f32 %2, %2, %4\n v_max_f32 %3, %3, %4"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));)
+        } else if (KIND == CNDMASK_VCC) {
+            asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(a0), "v"(b) : "vcc");
+            REP16(asm volatile("v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc"
+                               : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(sel) : "vcc");)
+        } else if (KIND == AND_B32) {
+            REP16(asm volatile("v_and_b32 %0, %0, %4\n v_and_b32 %1, %1, %4\n v_and_b32 %2, %2, %4\n v_and_b32 %3, %3, %4"
+                               : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(sel));)
+        } else if (KIND == LSHLREV) {
+            REP16(asm volatile("v_lshlrev_b32 %0, 1, %0\n v_lshlrev_b32 %1, 1, %1\n v_lshlrev_b32 %2, 1, %2\n v_lshlrev_b32 %3, 1, %3"
+                               : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3));)
+        } else if (KIND == CVT_UBYTE) {
+            REP16(asm volatile("v_cvt_f32_ubyte1 %0, %4\n v_cvt_f32_ubyte1 %1, %4\n v_cvt_f32_ubyte1 %2, %4\n v_cvt_f32_ubyte1 %3, %4"
+                               : "=v"(a0), "=v"(a1), "=v"(a2), "=v"(a3) : "v"(u0));)
+        } else if (KIND == CVT_F16) {
+            REP16(asm volatile("v_cvt_f32_f16 %0, %4\n v_cvt_f32_f16 %1, %4\n v_cvt_f32_f16 %2, %4\n v_cvt_f32_f16 %3, %4"
+                               : "=v"(a0), "=v"(a1), "=v"(a2), "=v"(a3) : "v"(u0));)
+        } else if (KIND == BFE) {
+            REP16(asm volatile("v_bfe_u32 %0, %0, 1, 31\n v_bfe_u32 %1, %1, 1, 31\n v_bfe_u32 %2, %2, 1, 31\n v_bfe_u32 %3, %3, 1, 31"
+                               : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3));)
+        } else if (KIND == AND_OR) {
+            REP16(asm volatile("v_and_or_b32 %0, %0, %4, %5\n v_and_or_b32 %1, %1, %4, %5\n v_and_or_b32 %2, %2, %4, %5\n v_and_or_b32 %3, %3, %4, %5"
+                               : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(sel), "v"(sel2));)
+        } else if (KIND == SUB_F32) {
+            REP16(asm volatile("v_sub_f32 %0, %0, %4\n v_sub_f32 %1, %1, %4\n v_sub_f32 %2, %2, %4\n v_sub_f32 %3, %3, %4"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));)
+        } else if (KIND == MIX_1S1F) {
+            REP16(asm volatile("v_perm_b32 %0, 0.5, %0, %4\n v_fma_f32 %2, %2, %5, %6\n v_perm_b32 %1, 0.5, %1, %4\n v_fma_f32 %3, %3, %5, %6"
+                               : "+v"(u0), "+v"(u1), "+v"(a0), "+v"(a1) : "v"(sel), "v"(b), "v"(c));)
+        } else if (KIND == MIX_1S2F) {
+            REP16(asm volatile("v_perm_b32 %0, 0.5, %0, %6\n v_fma_f32 %2, %2, %7, %8\n v_fma_f32 %3, %3, %7, %8\n v_perm_b32 %1, 0.5, %1, %6\n v_fma_f32 %4, %4, %7, %8\n v_fma_f32 %5, %5, %7, %8"
+                               : "+v"(u0), "+v"(u1), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(sel), "v"(b), "v"(c));)
+        } else if (KIND == MIX_2S1F) {
+            REP16(asm volatile("v_perm_b32 %0, 0.5, %0, %6\n v_perm_b32 %1, 0.5, %1, %6\n v_fma_f32 %4, %4, %7, %8\n v_perm_b32 %2, 0.5, %2, %6\n v_perm_b32 %3, 0.5, %3, %6\n v_fma_f32 %5, %5, %7, %8"
+                               : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(a0), "+v"(a1) : "v"(sel), "v"(b), "v"(c));)
+        } else if (KIND == MIX_1S3F) {
+            REP16(asm volatile("v_perm_b32 %0, 0.5, %0, %6\n v_fma_f32 %2, %2, %7, %8\n v_fma_f32 %3, %3, %7, %8\n v_fma_f32 %4, %4, %7, %8\n"
+                               "v_perm_b32 %1, 0.5, %1, %6\n v_fma_f32 %5, %5, %7, %8\n v_fma_f32 %2, %2, %7, %8\n v_fma_f32 %3, %3, %7, %8"
+                               : "+v"(u0), "+v"(u1), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(sel), "v"(b), "v"(c));)
+        } else if (KIND == BOX_PERM_PK2) {
+            REP16(asm volatile(
+                "v_perm_b32 %[n0], 0.5, %[nx], %[sn]\n v_perm_b32 %[f0], 0.5, %[nx], %[sf]\n v_perm_b32 %[n1], 0.5, %[ny], %[sn]\n v_perm_b32 %[f1], 0.5, %[ny], %[sf]\n"
+                "v_perm_b32 %[n2], 0.5, %[nz], %[sn]\n v_perm_b32 %[f2], 0.5, %[nz], %[sf]\n"
+                "v_pk_fma_f32 %[q0], %[q0], %[pix], %[pox]\n v_pk_fma_f32 %[q1], %[q1], %[piy], %[poy]\n v_pk_fma_f32 %[q2], %[q2], %[piz], %[poz]\n"
+                "v_max3_f32 %[n0], %[n0], %[n1], %[n2] clamp\n v_min3_f32 %[f0], %[f0], %[f1], %[f2]\n v_cmp_le_f32 vcc, %[n0], %[f0]"
+                : [n0] "=&v"(a0), [f0] "=&v"(a1), [n1] "=&v"(a2), [f1] "=&v"(a3), [n2] "=&v"(p3.x), [f2] "=&v"(p3.y), [q0] "+v"(p0), [q1] "+v"(p1), [q2] "+v"(p2)
+                : [nx] "v"(nx), [ny] "v"(ny), [nz] "v"(nz), [sn] "v"(sel), [sf] "v"(sel2),
+                  [pix] "v"(pix), [piy] "v"(piy), [piz] "v"(piz), [pox] "v"(pox), [poy] "v"(poy), [poz] "v"(poz) : "vcc");)
+        } else if (KIND == SALU_AND) {
+            REP16(asm volatile("s_and_b64 %0, %0, %1\n s_and_b64 %0, %0, %1\n s_and_b64 %0, %0, %1\n s_and_b64 %0, %0, %1" : "+s"(sm) : "s"(sn) : "scc");)
         }
     }
-    float r = a0 + a1 + a2 + a3 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y + (float)(u0 ^ u1 ^ u2 ^ u3);
+    const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = t1 - t0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
+    float r = a0 + a1 + a2 + a3 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y + (float)(u0 ^ u1 ^ u2 ^ u3) + (float)sm;
     if (r == 12345.678f) out[0] = r;
 }
 
 template <int KIND>
-static void run(const char* name, float* out, int cus)
+static void run(uint64_t* d_stamps, float* out, int cus)
 {
-    const int iters = 4000;     // x 64 instructions
+    const int per_iter = kind_instr(KIND);
+    const int iters = 3000 * 64 / per_iter;
+    std::vector<uint64_t> h;
     for (int waves_per_simd : { 1, 2, 4, 8 }) {
-        dim3 grid(cus * 4 * waves_per_simd);
+        const int blocks = cus * 4 * waves_per_simd;
+        h.resize(2 * (size_t)blocks);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        hipLaunchKernelGGL(k_probe<KIND>, grid, dim3(64), 0, 0, out, 10);
+        for (int w = 0; w < 3; w++) hipLaunchKernelGGL(k_probe<KIND>, dim3(blocks), dim3(64), 0, 0, d_stamps, out, iters);    // warm the clock governor
         hipDeviceSynchronize();
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k_probe<KIND>, grid, dim3(64), 0, 0, out, iters);
+        hipLaunchKernelGGL(k_probe<KIND>, dim3(blocks), dim3(64), 0, 0, d_stamps, out, iters);
         hipEventRecord(e1);
         hipDeviceSynchronize();
         float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-        const double instr_per_simd = (double)iters * 64 * waves_per_simd;
-        printf("{\"probe\": \"%s\", \"waves_per_simd\": %d, \"ms\": %.3f, \"ns_per_wave_instr_per_simd\": %.4f, \"cycles_at_2.4GHz\": %.3f}\n",
-               name, waves_per_simd, ms, ms * 1e6 / instr_per_simd, ms * 1e6 / instr_per_simd * 2.4);
+        hipMemcpy(h.data(), d_stamps, h.size() * 8, hipMemcpyDeviceToHost);
+        std::vector<double> cyc(blocks), mhz(blocks);
+        for (int i = 0; i < blocks; i++) { cyc[i] = (double)h[2 * i]; mhz[i] = h[2 * i + 1] ? 100.0 * (double)h[2 * i] / (double)h[2 * i + 1] : 0.0; }
+        std::nth_element(cyc.begin(), cyc.begin() + blocks / 2, cyc.end());
+        std::nth_element(mhz.begin(), mhz.begin() + blocks / 2, mhz.end());
+        const double instr_per_simd = (double)iters * per_iter * waves_per_simd;
+        // throughput: launch time (HIP events) x the in-kernel clock.  (A wavefront's own s_memtime span divided by the SIMD's
+        // instructions reads low: the oldest wavefront of a SIMD is served first and ends early.)
+        const double ns = ms * 1e6 / instr_per_simd, cycles = ns * mhz[blocks / 2] * 1e-3;
+        printf("{\"probe\": \"%s\", \"waves_per_simd\": %d, \"instr_per_wave\": %lld, \"launch_ms\": %.3f, \"in_kernel_clock_mhz\": %.0f, "
+               "\"ns_per_wave_instr_per_simd\": %.4f, \"cycles_per_wave_instr_per_simd\": %.3f, \"median_wave_span_cycles_per_simd_instr\": %.3f}\n",
+               kind_name[KIND], waves_per_simd, (long long)iters * per_iter, ms, mhz[blocks / 2], ns, cycles, cyc[blocks / 2] / instr_per_simd);
+        fflush(stdout);
     }
 }
+
+template <int K> struct RunAll { static void go(uint64_t* s, float* o, int cus) { run<K>(s, o, cus); RunAll<K + 1>::go(s, o, cus); } };
+template <> struct RunAll<KIND_COUNT> { static void go(uint64_t*, float*, int) {} };
 
 int main()
 {
     int cus = 0;
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
     float* out; hipMalloc(&out, 64);
-    printf("{\"cus\": %d}\n", cus);
-    run<0>("v_fma_f32", out, cus);
-    run<1>("v_pk_fma_f32", out, cus);
-    run<2>("v_perm_b32", out, cus);
-    run<3>("v_max3_f32", out, cus);
+    uint64_t* stamps; hipMalloc(&stamps, 2 * 8 * (size_t)cus * 32);
+    printf("{\"cus\": %d, \"note\": \"cycles = s_memtime ticks (shader clock); clock = ticks / s_memrealtime (100 MHz)\"}\n", cus);
+    RunAll<0>::go(stamps, out, cus);
     return 0;
 }
