@@ -39,7 +39,11 @@
 namespace aob {
 
 static constexpr int kWave = 64;                  // threads per workgroup: one wavefront
-static constexpr uint32_t kInvalid = 0xffffffffu;
+// A lane's state is its `addr`: a node to visit (inner below leaf_base, a leaf from there on), or one of three values above every
+// node reference — no flag registers, and every section's vote is one compare of the address.
+static constexpr uint32_t kInvalid = 0xffffffffu;         // the stack's sentinel: nothing left to visit — the ray ends, unoccluded so far
+static constexpr uint32_t kEndHit = 0xfffffffeu;          // any hit: the ray ended on a triangle
+static constexpr uint32_t kIdle = 0xfffffffdu;            // the lane has no ray
 typedef float v2f __attribute__((ext_vector_type(2)));    // a register pair for v_pk_fma_f32
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 as_uint4(v4u v) { return make_uint4(v.x, v.y, v.z, v.w); }
@@ -264,15 +268,14 @@ void k_trace(TraceParams p)
     uint32_t q_head = 0, q_count = 0;                   // wave-uniform: the queue is a ring of 64 rays
 
     // ---- the ray a lane is tracing ----
-    bool active = false;
     f3 org, dir, invdir, oxinvdir;
     org = dir = invdir = oxinvdir = make_f3(0.f, 0.f, 0.f);
     float w = 0.0f, closest_t = 0.0f;
     uint3 rot = make_uint3(0u, 0u, 0u);        // QUANT 1: 16 for axes the ray travels down, else 0
     uint3 nsel = make_uint3(0u, 0u, 0u), fsel = make_uint3(0u, 0u, 0u);   // QUANT 2: v_perm_b32 selectors of the near / far plane
-    bool hit = false;
     uint32_t slot = 0;                         // the ray's surfel
-    uint32_t addr = kInvalid;
+    uint32_t addr = kIdle;
+    const uint32_t leaf_base = QUANT == 2 ? 0x80000000u : p.leaf_base;      // QUANT 2: a compile-time constant, the votes are sign tests
     // Any hit: the lane's stack top is kept as a BYTE offset into lds_stack (entry e of this lane lives at e * 256 + lane * 4): a
     // push or a pop is the LDS access itself and one add, no address arithmetic.  Closest hit keeps the entry index (its ranked
     // placement of up to three children computes entry numbers anyway; with byte offsets it spilt five more registers and
@@ -306,19 +309,20 @@ void k_trace(TraceParams p)
             // r is 0 or 1: the sample adds its weight to the weight sum and, if unoccluded, to the total
             // ((1.0f * w) * 255.0f == w * 255.0f exactly).  Unit weights: the weight sum is the sample count (epilogue).
             if (UNITW) {
-                if (!hit) atomicAdd(&miss_count[slot], 1u);
+                if (addr == kInvalid) atomicAdd(&miss_count[slot], 1u);
             } else {
                 const long long cW = ACCUM == AOB_ACCUMULATE_QUANTISED ? (long long)ftoi(w * 255.0f) : f2fix(w);
                 atomicAdd(&acc[slot][1], (acc_t)cW);
-                if (!hit) atomicAdd(&acc[slot][0], (acc_t)cW);
+                if (addr == kInvalid) atomicAdd(&acc[slot][0], (acc_t)cW);
             }
         } else {
-            const float r = (hit && closest_t < p.falloff) ? closest_t / p.falloff : 1.0f;
+            // (a hit moved closest_t below tmax)
+            const float r = (closest_t < p.tmax && closest_t < p.falloff) ? closest_t / p.falloff : 1.0f;
             const float rw = UNITW ? r * 1.0f : r * w;
             atomicAdd(&acc[slot][0], (acc_t)(ACCUM == AOB_ACCUMULATE_QUANTISED ? (long long)ftoi(rw * 255.0f) : f2fix(rw)));
             if (!UNITW) atomicAdd(&acc[slot][1], (acc_t)(ACCUM == AOB_ACCUMULATE_QUANTISED ? (long long)ftoi(w * 255.0f) : f2fix(w)));
         }
-        active = false;
+        addr = kIdle;
     };
 
     // ---- one visit of a quantised 4-ary node: four slab tests, the next node and the deferred children ----
@@ -381,7 +385,7 @@ void k_trace(TraceParams p)
     };
 
     for (;;) {
-        const uint64_t active_m = __ballot(active);
+        const uint64_t active_m = __ballot(addr != kIdle);
         const bool more = q_count != 0u || gen_next < gen_end;
         if (active_m == 0ull && !more) break;
         AOB_STAT(0, 1);
@@ -390,10 +394,10 @@ void k_trace(TraceParams p)
         if (more && (kWave - __popcll(active_m) >= p.refill_idle || active_m == 0ull)) {
             AOB_STAT(5, 1);
             for (int pass = 0; pass < 2; pass++) {
-                const uint64_t idle_m = __ballot(!active);
+                const uint64_t idle_m = __ballot(addr == kIdle);
                 if (q_count != 0u) {
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
-                    if (!active && rank < q_count) {
+                    if (addr == kIdle && rank < q_count) {
                         const uint32_t pos = (q_head + rank) & (kWave - 1u);
                         const uint4 e0 = queue[pos * 2], e1 = queue[pos * 2 + 1];
                         slot = e0.w;
@@ -423,10 +427,9 @@ void k_trace(TraceParams p)
                             oxinvdir = make_f3(oxinvdir.x * p.inv_tmax, oxinvdir.y * p.inv_tmax, oxinvdir.z * p.inv_tmax);
                         }
                         if (!ANYHIT) closest_t = p.tmax;            // any hit: the bound never moves off tmax, no register for it
-                        hit = false; spa = sp_first;
-                        active = true;
+                        spa = sp_first;
                         addr = 0;
-                        if (p.node_count == 0) finish();          // empty scene: every ray misses
+                        if (p.node_count == 0) { addr = kInvalid; finish(); }      // empty scene: every ray misses
                     }
                     const uint32_t taken = min((uint32_t)__popcll(idle_m), q_count);
                     AOB_STAT(6, taken);
@@ -480,23 +483,23 @@ void k_trace(TraceParams p)
                     const const_words nw = (const_words)ng;
                     const uint4 n0 = make_uint4(nw[0], nw[1], nw[2], nw[3]), n1 = make_uint4(nw[4], nw[5], nw[6], nw[7]),
                                 n2 = make_uint4(nw[8], nw[9], nw[10], nw[11]), n3 = make_uint4(nw[12], nw[13], nw[14], nw[15]);
-                    const bool here = active && addr == a0;
+                    const bool here = addr == a0;
                     if (here) {
                         visit4(n0, n1, n2, n3, false);
                         if (addr == kInvalid) finish();      // nothing left to visit: the ray ends here, before the leaf section sees it
                     }
                     // the next node: where the first lane of the group went, if enough of the others went with it
-                    const uint64_t on_m = __ballot(here && active && addr < p.leaf_base);
+                    const uint64_t on_m = __ballot(here && addr < leaf_base);
                     if ((uint32_t)__popcll(on_m) < kScalarMin) break;
                     a0 = (uint32_t)__builtin_amdgcn_readlane((int)addr, (int)__builtin_ctzll(on_m));
-                    if ((uint32_t)__popcll(__ballot(active && addr == a0)) < kScalarMin) break;
+                    if ((uint32_t)__popcll(__ballot(addr == a0)) < kScalarMin) break;
                 }
             }
         }
 
         // ---- leaf section: :162-182 (closest) / :323-339 (any hit); the triangle is inlined in the node ----
-        const bool at_leaf = active && addr >= p.leaf_base;
-        const bool inner = active && addr < p.leaf_base;
+        const bool at_leaf = addr >= leaf_base && addr < kIdle;
+        const bool inner = addr < leaf_base;
         const uint64_t inner_m = __ballot(inner);
         // (run it, too, when fewer than 16 lanes are left walking: the parked lanes are then worth more than a fuller leaf section —
         // 69.6 -> 68.6 ms on BASELINE configs[2]; thresholds 8 / 12 / 16 / 20 / 24: 69.6 / 69.0 / 68.6 / 68.7 / 69.7)
@@ -506,7 +509,7 @@ void k_trace(TraceParams p)
             if (at_leaf) {
                 // QUANT 2: the ref may name a PAIR of triangles, p and p + 1 (AOB_PAIR_FLAG): both are fetched in one go
                 const float bound = ANYHIT ? p.tmax : closest_t;
-                const uint32_t lref = addr - p.leaf_base;
+                const uint32_t lref = addr - leaf_base;
                 const bool pair = QUANT == 2 && (lref & 0x40000000u) != 0u;
                 const float4* np = QUANT ? p.leaf_tris + 3ull * (lref & 0x3fffffffu) : p.nodes + 4ull * addr;
                 float t;
@@ -537,8 +540,8 @@ void k_trace(TraceParams p)
                     t = fminf(t, t2);
                 }
                 const bool closer = t < bound;
-                if (closer) { if (!ANYHIT) closest_t = t; hit = true; }
-                addr = (ANYHIT && closer) ? kInvalid : pop();
+                if (!ANYHIT && closer) closest_t = t;
+                addr = (ANYHIT && closer) ? kEndHit : pop();
             }
         }
 
@@ -604,7 +607,7 @@ void k_trace(TraceParams p)
             }
           }
         }
-        if (active && addr == kInvalid) finish();     // the one place a ray ends
+        if (addr > kIdle) finish();     // kInvalid or kEndHit: the one place a ray ends
     }
 #if AOB_EXP_VALU || AOB_EXP_LOAD
     asm volatile("" :: "v"(exp_acc));

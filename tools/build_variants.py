@@ -16,7 +16,7 @@ CSRC = os.path.join(ROOT, "aobaker_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "_variants")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
-         "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-result", "-Wno-unused-value"]
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize", "-Wall", "-Wno-unused-result", "-Wno-unused-value"]
 
 
 def main():
