@@ -9,6 +9,7 @@ Product code only (no oracle).  LIB `-` is the in-tree library.
   anyhit   BASELINE configs[2]: 999 698-triangle terrain, 2048^2, 256 spp, cosine / any hit / float   k_trace<1,1,1,11,2,0>
   closest  the same terrain and rays with closest-hit falloff scoring (falloff 1.25, tmax clamped)      k_trace<1,0,1,10,2,0>
   cfg2     configs[1]: 69 938-triangle sphere, 1024^2, 64 spp, any hit
+  cfg5     configs[4]'s instanced scene (10 M triangles) at its own 8192^2 atlas, 16 of its 1024 spp, closest-hit falloff scoring
   cfg5s    configs[4]'s instanced scene (10 M triangles) at 2048^2 x 64 spp, closest-hit falloff scoring
 
   python tools/build_variants.py base= valu8=-DAOB_EXP_VALU=8 && python tools/time_trace.py tools/_variants/lib_*.so
@@ -48,6 +49,9 @@ def child(modes, reps, knobs):
         elif mode == "cfg2":
             flat, spp = FlatScene(scenes.sphere_scene(n=187, atlas=1024, seed=2, bpc=4)), 64
             o = cosine(64, 2)
+        elif mode == "cfg5":
+            flat, spp = FlatScene(scenes.instanced_scene(instances=100, rock_n=224, atlas=8192, seed=5, bpc=1)), 16
+            o = cosine(16, 5, use_any_hit=0, falloff_distance=1.25, clamp_tmax_to_falloff=1)
         elif mode == "cfg5s":
             flat, spp = FlatScene(scenes.instanced_scene(instances=100, rock_n=224, atlas=2048, seed=5, bpc=1)), 64
             o = cosine(64, 5, use_any_hit=0, falloff_distance=1.25, clamp_tmax_to_falloff=1)
