@@ -61,7 +61,7 @@ static int validate_options(const AobOptions* o)
     if (o->raster_layers == AOB_LAYERS_ALL && o->raster_mode == AOB_RASTER_CONSERVATIVE) { set_error("raster_layers ALL needs raster_mode REFERENCE"); return AOB_ERR_UNSUPPORTED; }
     if (o->morton_adaptive != 0 && o->morton_adaptive != 1) { set_error("morton_adaptive %d: must be 0 or 1", o->morton_adaptive); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->material_ranges != 0 && o->material_ranges != 1) { set_error("material_ranges %d: must be 0 or 1", o->material_ranges); return AOB_ERR_INVALID_ARGUMENT; }
-    if (o->bvh_builder != 0 && o->bvh_builder != 1) { set_error("bvh_builder %d: must be 0 (LBVH) or 1 (PLOC)", o->bvh_builder); return AOB_ERR_INVALID_ARGUMENT; }
+    if (o->bvh_builder < 0 || o->bvh_builder > 2) { set_error("bvh_builder %d: must be 0 (LBVH), 1 (PLOC) or 2 (PLOC clusters under a binned-SAH top)", o->bvh_builder); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->bvh_width != 0 && o->bvh_width != 2 && o->bvh_width != 4) { set_error("bvh_width %d: must be 0, 2 or 4", o->bvh_width); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->trace_refill_idle < 0 || o->trace_refill_idle > 64 || o->trace_leaf_wait < 0 || o->trace_leaf_wait > 64) { set_error("trace_refill_idle %d / trace_leaf_wait %d: must be 0 (default) or 1..64", o->trace_refill_idle, o->trace_leaf_wait); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->trace_parts < 0 || o->trace_parts > 64 || o->trace_part_min < 0 || o->trace_fine_div < 0) { set_error("trace_parts %d (0..64), trace_part_min %d, trace_fine_div %d: must not be negative", o->trace_parts, o->trace_part_min, o->trace_fine_div); return AOB_ERR_INVALID_ARGUMENT; }
@@ -290,6 +290,9 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
     plan.want(&b->node_height, n);
     plan.want(&b->ploc_sums, n / 1024 + 4);
     plan.want(&b->ploc_totals, 8);
+    plan.want(&b->sah_counts, 1024 + 8);
+    b->sah_list_capacity = n < 131072u ? n : 131072u;           // kSahTopClusters (bvh_build.hip)
+    plan.want(&b->sah_lists, 2 * 28 * b->sah_list_capacity);
     plan.want(&b->nodes, 2 * n);
     plan.want(&b->nodes4, 8 * n);
     plan.want(&b->leaf_tris, 3 * n);

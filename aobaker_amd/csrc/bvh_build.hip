@@ -513,11 +513,13 @@ __device__ __forceinline__ uint32_t ploc_nearest(const uint32_t* cl, uint32_t m,
 // back while the next round runs, instead of draining the stream after every round.
 __global__ __launch_bounds__(kBlock)
 void k_ploc_nn(const uint32_t* __restrict__ cl, const uint32_t* __restrict__ state, const Box* __restrict__ bounds, int radius, int forced,
-               uint32_t* __restrict__ nn)
+               uint32_t stop, uint32_t* __restrict__ nn)
 {
     const uint32_t m = state[0];
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < m) nn[i] = ploc_nearest(cl, m, bounds, radius, forced, i);
+    // (a list of `stop` clusters or fewer is left as it is — bvh_builder 2 builds the rest of the tree over it top-down — and a round
+    // launched on it because the host had not seen that length yet copies it: everybody its own neighbour, nobody merges)
+    if (i < m) nn[i] = m <= stop ? i : ploc_nearest(cl, m, bounds, radius, forced, i);
 }
 
 // alive: the cluster survives (possibly as the new merged node); merge: it is the lower half of a mutual pair
@@ -606,7 +608,7 @@ __device__ __forceinline__ void ploc_emit_tile(const uint32_t* cl, const uint32_
 // for the host.
 __global__ __launch_bounds__(kBlock)
 void k_ploc_emit(const uint32_t* __restrict__ cl, const uint32_t* __restrict__ nn, const uint32_t* __restrict__ state, const uint2* __restrict__ sums,
-                 uint32_t tiles, uint32_t* __restrict__ state_out,
+                 uint32_t tiles, uint32_t stop, uint32_t* __restrict__ state_out,
                  uint32_t n, uint32_t* __restrict__ nxt, uint32_t* __restrict__ child_left,
                  uint32_t* __restrict__ child_right, uint32_t* __restrict__ parent, Box* __restrict__ bounds, uint32_t* height)
 {
@@ -622,7 +624,7 @@ void k_ploc_emit(const uint32_t* __restrict__ cl, const uint32_t* __restrict__ n
     block_exclusive_scan2(all, &grand);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         state_out[0] = grand.x; state_out[1] = created + grand.y;
-        state_out[2] = state[2] | ((grand.x >= m || grand.y == 0) ? 1u : 0u);      // a round without progress (never observed)
+        state_out[2] = state[2] | ((m > stop && (grand.x >= m || grand.y == 0)) ? 1u : 0u);      // a round without progress (never observed)
     }
     uint2 total;
     ploc_emit_tile(cl, nn, m, blockIdx.x * kPlocTile + threadIdx.x * kPlocItems, off, created, n, nxt,
@@ -708,7 +710,10 @@ void k_ploc_tail(const uint32_t* __restrict__ cl_in, const uint32_t* __restrict_
 
 __global__ void k_set_root_parent(uint32_t* parent) { if (threadIdx.x == 0) parent[0] = 0xffffffffu; }
 
-static int build_ploc(AobBake* b, uint32_t n)
+static int build_sah_top(AobBake* b, uint32_t n, const uint32_t* cl, uint32_t* other, const uint32_t* state, uint32_t bound);
+
+// stop: the list length at which clustering ends (1: PLOC builds the whole tree; bvh_builder 2: kSahTopClusters)
+static int build_ploc(AobBake* b, uint32_t n, uint32_t stop)
 {
     hipStream_t s = b->stream;
     uint32_t* cl[2] = { b->prim_idx[0], (uint32_t*)b->codes[0] };      // both free once the sort is done
@@ -720,13 +725,13 @@ static int build_ploc(AobBake* b, uint32_t n)
     // a round is launched with the length read back after the round before last as its upper bound
     uint32_t known = n;                                                // the latest length the host has seen
     int cur = 0, iter = 0;
-    while (known > (uint32_t)kPlocTile) {
+    while (known > max((uint32_t)kPlocTile, stop)) {
         const int forced = iter >= 256;                                 // never observed; guarantees termination
         const uint32_t tiles = (known + kPlocTile - 1) / kPlocTile;
         const uint32_t* st = state[iter & 1]; uint32_t* st_out = state[(iter & 1) ^ 1];
-        hipLaunchKernelGGL(k_ploc_nn, dim3(blocks_for(known)), dim3(kBlock), 0, s, cl[cur], st, b->node_bounds, kPlocRadius, forced, nn);
+        hipLaunchKernelGGL(k_ploc_nn, dim3(blocks_for(known)), dim3(kBlock), 0, s, cl[cur], st, b->node_bounds, kPlocRadius, forced, stop, nn);
         hipLaunchKernelGGL(k_ploc_count, dim3(tiles), dim3(kBlock), 0, s, nn, st, b->ploc_sums);
-        hipLaunchKernelGGL(k_ploc_emit, dim3(tiles), dim3(kBlock), 0, s, cl[cur], nn, st, b->ploc_sums, tiles, st_out, n,
+        hipLaunchKernelGGL(k_ploc_emit, dim3(tiles), dim3(kBlock), 0, s, cl[cur], nn, st, b->ploc_sums, tiles, stop, st_out, n,
                            cl[cur ^ 1], b->child_left, b->child_right, b->parent, b->node_bounds, b->node_height);
         AOB_HIP(hipMemcpyAsync(host[iter & 1], st_out, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         AOB_HIP(hipEventRecord(b->ev_ploc[iter & 1], s));
@@ -742,10 +747,472 @@ static int build_ploc(AobBake* b, uint32_t n)
         AOB_HIP(hipEventSynchronize(b->ev_ploc[(iter - 1) & 1]));
         if (host[(iter - 1) & 1][2]) { set_error("PLOC made no progress"); return AOB_ERR_DEVICE; }
     }
+    if (stop > 1u) {
+        // bvh_builder 2: the clusters made so far (at most `stop` of them, or every leaf of a small scene) become the leaves of a
+        // top-down binned-SAH tree
+        AOB_TRY(build_sah_top(b, n, cl[cur], cl[cur ^ 1], state[iter & 1], min(known, max(stop, (uint32_t)kPlocTile))));
+        hipLaunchKernelGGL(k_set_root_parent, dim3(1), dim3(64), 0, s, b->parent);
+        return AOB_OK;
+    }
     // the list now holds at most one tile (the last round launched may have run on less): the rest in one launch
     hipLaunchKernelGGL(k_ploc_tail, dim3(1), dim3(kBlock), 0, s, cl[cur], state[iter & 1], n, iter, kPlocRadius,
                        b->child_left, b->child_right, b->parent, b->node_bounds, b->node_height, b->depth_dev);
     hipLaunchKernelGGL(k_set_root_parent, dim3(1), dim3(64), 0, s, b->parent);
+    return AOB_OK;
+}
+
+// ---- binned-SAH top (bvh_builder = 2) ------------------------------------------------------------
+// The reference stack's own lever for traversal cost is its SAH builder (RadeonRays/radeon_rays.h:286-294: bvh.builder = "sah").
+// Here: PLOC clusters the Morton-ordered triangles until at most kSahTopClusters clusters are left (a smaller scene: none at
+// all), and the tree above them is built TOP-DOWN by binned SAH — where an agglomerated tree differs most from a SAH tree
+// (1 M-triangle terrain: 14.24 instead of 15.00 node visits per ray; every triangle a cluster of its own would give 13.65,
+// profiles/r03/sah_top/).  The algorithm, stated once in oracle/aob_oracle.c (sah_top): per list range the box of the clusters'
+// centres, 16 bins per axis, the cheapest of the 3 x 15 planes, a STABLE partition; a node's id is the position its range was
+// cut at (unique; the root and the node cut at position 0 swap ids so that the root is node 0) — so ranges can be split in
+// any order: one workgroup per range while ranges are long, one thread per range (and all below it) once they are short.
+static constexpr int kSahTopClusters = 131072;
+static constexpr int kSahBins = 16;
+static constexpr int kSahSmall = 32;               // ranges of at most this many clusters are finished by one wavefront each
+// A range of the list that is to be cut: parent << 1 | side (0xffffffff: the root); depth << 2 | boxes known << 1 | the list it
+// lives in; its clusters' box and the box of their centres, handed down by the cut that made it (the bins of the parent on either
+// side of the plane), so that a range is read twice, not three times.
+struct SahRange { uint32_t begin, end, parent_side, depth_buf; float box[6], cbox[6]; };
+struct SahShort { uint32_t begin, end, parent_side, depth_buf; };       // at most kSahSmall clusters: finished by one wavefront
+
+__device__ __forceinline__ int sah_bin(float c, float cmin, float ext)
+{
+    int q = (int)((c - cmin) / ext * (float)kSahBins);
+    return q > kSahBins - 1 ? kSahBins - 1 : q;
+}
+__device__ __forceinline__ float box_area(const float* b)          // b: min[3], max[3]
+{
+    const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// The bins of one group (a workgroup or a wavefront) in LDS: per axis and bin the clusters' count, their box and the box of their
+// centres (ordered-uint encoded: LDS atomics).
+struct SahBins { uint32_t cnt[3][kSahBins]; uint32_t box[3][kSahBins][12]; };
+__device__ __forceinline__ void sah_bins_clear(SahBins* bins, uint32_t tid, uint32_t threads)
+{
+    for (uint32_t i = tid; i < 3u * kSahBins; i += threads) {
+        (&bins->cnt[0][0])[i] = 0u;
+        for (int q = 0; q < 12; q++) (&bins->box[0][0][0])[i * 12u + q] = (q % 6) < 3 ? 0xffffffffu : 0u;
+    }
+}
+// A thread walks a run of consecutive clusters and keeps, per axis, the box of the clusters it has seen since their bin last
+// changed (neighbours in the list mostly share a bin: it is in Morton order); a change of bin — and the end of the run — sends
+// the box to LDS with thirteen atomics.  (One atomic per cluster and value put up to 64 lanes on one LDS word; reducing across the
+// lanes first kept the LDS pipe busy with ds_bpermute instead.)
+struct SahRun { int bin; uint32_t cnt; float v[12]; };
+__device__ __forceinline__ void sah_run_flush(SahBins* bins, int ax, SahRun& r)
+{
+    if (r.cnt) {
+        atomicAdd(&bins->cnt[ax][r.bin], r.cnt);
+        for (int q = 0; q < 12; q++) { if ((q % 6) < 3) atomicMin(&bins->box[ax][r.bin][q], enc_float(r.v[q])); else atomicMax(&bins->box[ax][r.bin][q], enc_float(r.v[q])); }
+    }
+    r.cnt = 0;
+}
+__device__ __forceinline__ void sah_run_add(SahBins* bins, int ax, SahRun& r, const Box& bx, float cmin, float ext)
+{
+    float c[3];
+    for (int q = 0; q < 3; q++) c[q] = (bx.pmin[q] + bx.pmax[q]) * 0.5f;
+    const int b = sah_bin(c[ax], cmin, ext);
+    if (b != r.bin || r.cnt == 0u) {
+        sah_run_flush(bins, ax, r);
+        r.bin = b;
+        for (int q = 0; q < 3; q++) { r.v[q] = INFINITY; r.v[3 + q] = -INFINITY; r.v[6 + q] = INFINITY; r.v[9 + q] = -INFINITY; }
+    }
+    r.cnt++;
+    for (int q = 0; q < 3; q++) {
+        r.v[q] = fminf(r.v[q], bx.pmin[q]); r.v[3 + q] = fmaxf(r.v[3 + q], bx.pmax[q]);
+        r.v[6 + q] = fminf(r.v[6 + q], c[q]); r.v[9 + q] = fmaxf(r.v[9 + q], c[q]);
+    }
+}
+
+// The cut of a range from its bins, by one whole wavefront: lane 16 * axis + q holds bin q of the axis; unions of the bins up to q
+// and from q on by shuffles inside each group of 16 lanes; the plane behind bin q costs area(left) * count(left) + area(right) *
+// count(right); the cheapest wins, the lowest lane among equals (the first plane in axis, then bin order: the oracle's sweep).
+// Returns the axis (-1: no plane leaves clusters on both sides), and for either side count, box and box of the centres.
+struct SahCut { int axis, split; uint32_t nl; float lbox[12], rbox[12]; };
+__device__ __forceinline__ SahCut sah_select(const SahBins* bins, const float* ext)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const int ax = (int)(lane >> 4), q = (int)(lane & 15u);
+    const bool valid = lane < 48u && ext[ax < 3 ? ax : 0] > 0.0f;
+    uint32_t pc = valid ? bins->cnt[ax][q] : 0u;
+    float pb[12];
+    for (int k = 0; k < 12; k++) pb[k] = valid && pc ? dec_float(bins->box[ax][q][k]) : ((k % 6) < 3 ? INFINITY : -INFINITY);
+    uint32_t sc = pc; float sb[12];
+    for (int k = 0; k < 12; k++) sb[k] = pb[k];
+    for (int off = 1; off < 16; off <<= 1) {
+        const uint32_t oc = __shfl_up(pc, off, 16), oc2 = __shfl_down(sc, off, 16);
+        float ob[12], ob2[12];
+        for (int k = 0; k < 12; k++) { ob[k] = __shfl_up(pb[k], off, 16); ob2[k] = __shfl_down(sb[k], off, 16); }
+        if (q >= off) { pc += oc; for (int k = 0; k < 12; k++) pb[k] = (k % 6) < 3 ? fminf(pb[k], ob[k]) : fmaxf(pb[k], ob[k]); }
+        if (q + off < 16) { sc += oc2; for (int k = 0; k < 12; k++) sb[k] = (k % 6) < 3 ? fminf(sb[k], ob2[k]) : fmaxf(sb[k], ob2[k]); }
+    }
+    // the right side of the plane behind bin q: the bins from q + 1 on
+    const uint32_t rc = __shfl_down(sc, 1, 16);
+    float rb[12];
+    for (int k = 0; k < 12; k++) rb[k] = __shfl_down(sb[k], 1, 16);
+    float cost = INFINITY;
+    if (valid && q < kSahBins - 1 && pc != 0u && rc != 0u) cost = box_area(pb) * (float)pc + box_area(rb) * (float)rc;
+    float best = cost; uint32_t bl = lane;
+    for (int off = 32; off > 0; off >>= 1) {
+        const float oc = __shfl_xor(best, off); const uint32_t ol = __shfl_xor(bl, off);
+        if (oc < best || (oc == best && ol < bl)) { best = oc; bl = ol; }
+    }
+    SahCut c;
+    c.axis = best < INFINITY ? (int)(bl >> 4) : -1;
+    c.split = (int)(bl & 15u) + 1;
+    c.nl = __shfl(pc, (int)bl);
+    for (int k = 0; k < 12; k++) { c.lbox[k] = __shfl(pb[k], (int)bl); c.rbox[k] = __shfl(rb[k], (int)bl); }
+    return c;
+}
+
+// what a range that has been cut leaves behind: its node (id from the cut position), the link from its parent, its children —
+// single clusters at once, longer ranges as new work
+__device__ __forceinline__ void sah_emit(uint32_t begin, uint32_t end, uint32_t parent_side, uint32_t depth, uint32_t mid, const float* node_box,
+                                         const SahCut* cut, const uint32_t* list, uint32_t out_buf,
+                                         uint32_t n, uint32_t* root_k, uint32_t* child_left, uint32_t* child_right, uint32_t* parent, Box* bounds,
+                                         const uint32_t* height, uint32_t* depth_out,
+                                         SahRange* next, uint32_t* next_count, SahShort* small, uint32_t* small_count)
+{
+    const uint32_t k = mid - 1u;
+    const bool root = parent_side == 0xffffffffu;
+    if (root) *root_k = k;
+    const uint32_t id = root ? 0u : (k == 0u ? *root_k : k);
+    Box bx;
+    for (int q = 0; q < 3; q++) { bx.pmin[q] = node_box[q]; bx.pmax[q] = node_box[3 + q]; }
+    bounds[id] = bx;
+    if (!root) {
+        const uint32_t par = parent_side >> 1;
+        if (parent_side & 1u) child_right[par] = id; else child_left[par] = id;
+        parent[id] = par;
+    }
+    const uint32_t rb[2] = { begin, mid }, re[2] = { mid, end };
+    for (uint32_t side = 0; side < 2u; side++) {
+        const uint32_t cb = rb[side], ce = re[side];
+        if (ce - cb == 1u) {
+            const uint32_t c = list[cb];
+            if (side) child_right[id] = c; else child_left[id] = c;
+            parent[c] = id;
+            atomicMax(depth_out, depth + 1u + (c < n - 1u ? height[c] : 0u));       // a cluster is a PLOC subtree of that height (a leaf: 0)
+        } else if (ce - cb > (uint32_t)kSahSmall) {
+            SahRange ch; ch.begin = cb; ch.end = ce; ch.parent_side = id << 1 | side;
+            const bool known = cut && cut->axis >= 0;
+            ch.depth_buf = (depth + 1u) << 2 | (known ? 2u : 0u) | out_buf;
+            const float* sbx = known ? (side ? cut->rbox : cut->lbox) : node_box;
+            for (int q = 0; q < 6; q++) { ch.box[q] = sbx[q]; ch.cbox[q] = known ? sbx[6 + q] : 0.0f; }
+            next[atomicAdd(next_count, 1u)] = ch;
+        } else {
+            SahShort ch; ch.begin = cb; ch.end = ce; ch.parent_side = id << 1 | side; ch.depth_buf = (depth + 1u) << 2 | out_buf;
+            small[atomicAdd(small_count, 1u)] = ch;
+        }
+    }
+}
+
+// The clusters of a range travel with their boxes: list `buf` is ids[buf][i] + boxes[buf][i], contiguous per range, so that every
+// pass streams its range (gathering node_bounds[ids[i]] made the 131 072-cluster root range alone cost milliseconds).
+struct SahLists { uint32_t* ids[2]; Box* boxes[2]; };
+
+// one workgroup per range of more than kSahSmall clusters: bins in LDS, a stable partition into the other list
+static constexpr int kSahBlock = 1024;
+__global__ __launch_bounds__(kSahBlock)
+void k_sah_level(const SahRange* __restrict__ ranges, const uint32_t* __restrict__ count, SahLists lists,
+                 uint32_t n, uint32_t* root_k, uint32_t* __restrict__ child_left, uint32_t* __restrict__ child_right, uint32_t* __restrict__ parent,
+                 Box* __restrict__ bounds, const uint32_t* __restrict__ height, uint32_t* depth_out,
+                 SahRange* __restrict__ next, uint32_t* next_count, SahShort* __restrict__ small, uint32_t* small_count)
+{
+    constexpr int kWaves = kSahBlock / 64;
+    __shared__ uint32_t s_enc[12];                              // node box (6) and box of the centres (6), ordered-uint encoded
+    __shared__ SahBins s_bins;
+    __shared__ SahCut s_cut;
+    __shared__ uint32_t s_wave[kWaves];
+    if (blockIdx.x >= *count) return;
+    const SahRange r = ranges[blockIdx.x];
+    const uint32_t from = r.depth_buf & 1u, to = from ^ 1u;
+    const uint32_t* src = lists.ids[from]; const Box* src_box = lists.boxes[from];
+    uint32_t* dst = lists.ids[to]; Box* dst_box = lists.boxes[to];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t len = r.end - r.begin;
+    sah_bins_clear(&s_bins, tid, kSahBlock);
+    float node_box[6], cbox[6];
+    if (r.depth_buf & 2u) {
+        for (int q = 0; q < 6; q++) { node_box[q] = r.box[q]; cbox[q] = r.cbox[q]; }
+        __syncthreads();
+    } else {
+        // (the root, and the halves of a range no plane could cut) the clusters' box and the box of their centres
+        if (tid < 12u) s_enc[tid] = (tid % 6u) < 3u ? 0xffffffffu : 0u;
+        __syncthreads();
+        float v[12];
+        for (int q = 0; q < 12; q++) v[q] = (q % 6) < 3 ? INFINITY : -INFINITY;
+        for (uint32_t i = r.begin + tid; i < r.end; i += kSahBlock) {
+            const Box bx = src_box[i];
+            for (int q = 0; q < 3; q++) {
+                v[q] = fminf(v[q], bx.pmin[q]); v[3 + q] = fmaxf(v[3 + q], bx.pmax[q]);
+                const float c = (bx.pmin[q] + bx.pmax[q]) * 0.5f;
+                v[6 + q] = fminf(v[6 + q], c); v[9 + q] = fmaxf(v[9 + q], c);
+            }
+        }
+        for (int q = 0; q < 12; q++)
+            for (int off = 32; off > 0; off >>= 1) v[q] = (q % 6) < 3 ? fminf(v[q], __shfl_xor(v[q], off)) : fmaxf(v[q], __shfl_xor(v[q], off));
+        if (lane == 0u) for (int q = 0; q < 12; q++) { if ((q % 6) < 3) atomicMin(&s_enc[q], enc_float(v[q])); else atomicMax(&s_enc[q], enc_float(v[q])); }
+        __syncthreads();
+        for (int q = 0; q < 6; q++) { node_box[q] = dec_float(s_enc[q]); cbox[q] = dec_float(s_enc[6 + q]); }
+    }
+    float cmin[3], ext[3];
+    for (int q = 0; q < 3; q++) { cmin[q] = cbox[q]; ext[q] = cbox[3 + q] - cbox[q]; }
+    // the bins: every thread a run of consecutive clusters
+    {
+        const uint32_t chunk = (len + kSahBlock - 1u) / kSahBlock;
+        const uint32_t i0 = r.begin + tid * chunk, i1 = min(r.end, i0 + chunk);
+        SahRun run[3];
+        for (int ax = 0; ax < 3; ax++) { run[ax].bin = -1; run[ax].cnt = 0u; }
+        for (uint32_t i = i0; i < i1; i++) {
+            const Box bx = src_box[i];
+            for (int ax = 0; ax < 3; ax++) if (ext[ax] > 0.0f) sah_run_add(&s_bins, ax, run[ax], bx, cmin[ax], ext[ax]);
+        }
+        for (int ax = 0; ax < 3; ax++) sah_run_flush(&s_bins, ax, run[ax]);
+    }
+    __syncthreads();
+    if (wave == 0u) { const SahCut c = sah_select(&s_bins, ext); if (lane == 0u) s_cut = c; }
+    __syncthreads();
+    const int axis = s_cut.axis, split = s_cut.split;
+    const uint32_t nl = axis >= 0 ? s_cut.nl : len / 2u;        // no plane separates the centres: the list is cut in the middle
+    // stable partition into the other list, a tile of kSahBlock clusters at a time
+    uint32_t lbase = r.begin, rbase = r.begin + nl;
+    for (uint32_t t0 = r.begin; t0 < r.end; t0 += kSahBlock) {
+        const uint32_t i = t0 + tid;
+        const bool in = i < r.end;
+        uint32_t c = 0; bool goes_left = false; Box bx;
+        if (in) {
+            c = src[i]; bx = src_box[i];
+            if (axis < 0) goes_left = i - r.begin < nl;
+            else goes_left = sah_bin((bx.pmin[axis] + bx.pmax[axis]) * 0.5f, cmin[axis], ext[axis]) < split;
+        }
+        const uint64_t lm = __ballot(in && goes_left), rm = __ballot(in && !goes_left);
+        if (lane == 0u) s_wave[wave] = (uint32_t)__popcll(lm) | (uint32_t)__popcll(rm) << 16;
+        __syncthreads();
+        uint32_t lbefore = 0, rbefore = 0, ltotal = 0, rtotal = 0;
+        for (uint32_t w = 0; w < (uint32_t)kWaves; w++) {
+            const uint32_t v = s_wave[w];
+            if (w < wave) { lbefore += v & 0xffffu; rbefore += v >> 16; }
+            ltotal += v & 0xffffu; rtotal += v >> 16;
+        }
+        const uint64_t below = lane ? (~0ull >> (64u - lane)) : 0ull;
+        if (in) {
+            const uint32_t at = goes_left ? lbase + lbefore + (uint32_t)__popcll(lm & below) : rbase + rbefore + (uint32_t)__popcll(rm & below);
+            dst[at] = c; dst_box[at] = bx;
+        }
+        lbase += ltotal; rbase += rtotal;
+        __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0)
+        sah_emit(r.begin, r.end, r.parent_side, r.depth_buf >> 2, r.begin + nl, node_box, &s_cut, dst, to, n, root_k, child_left, child_right, parent, bounds,
+                 height, depth_out, next, next_count, small, small_count);
+}
+
+// one WAVEFRONT per range of at most kSahSmall (= 64) clusters: the range and everything below it, a lane per cluster, the clusters
+// and the stack of sub-ranges in LDS.  The same cut as above, without bins: lane 15 * axis + q takes the plane behind bin q and
+// walks the sub-range's clusters (broadcast reads), collecting what lies on either side of it.
+static constexpr int kSahWaveBlock = 256;
+__global__ __launch_bounds__(kSahWaveBlock)
+void k_sah_wave(const SahShort* __restrict__ ranges, const uint32_t* __restrict__ count, SahLists lists,
+                uint32_t n, uint32_t* root_k, uint32_t* __restrict__ child_left, uint32_t* __restrict__ child_right, uint32_t* __restrict__ parent,
+                Box* __restrict__ bounds, const uint32_t* __restrict__ height, uint32_t* depth_out)
+{
+    constexpr int kWaves = kSahWaveBlock / 64;
+    __shared__ Box s_box[kWaves][kSahSmall];
+    __shared__ uint32_t s_id[kWaves][kSahSmall], s_bin3[kWaves][kSahSmall];
+    __shared__ uint32_t s_todo[kWaves][kSahSmall][4];           // begin | end << 8, parent << 1 | side, depth, boxes known
+    __shared__ float s_tbox[kWaves][kSahSmall][12];             // ... and the sub-range's box and box of centres, if known
+    __shared__ float s_cut[kWaves][26];                         // the winning plane: count, left box + centres, right box + centres
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t t = blockIdx.x * kWaves + wave;
+    if (t >= *count) return;                                    // (wave-uniform; no workgroup barrier below)
+    const SahShort r0 = ranges[t];
+    const uint32_t from = r0.depth_buf & 1u;
+    const uint32_t total = r0.end - r0.begin;
+    Box* box = s_box[wave]; uint32_t* id = s_id[wave]; uint32_t* bin3 = s_bin3[wave];
+    if (lane < total) { box[lane] = lists.boxes[from][r0.begin + lane]; id[lane] = lists.ids[from][r0.begin + lane]; }
+    if (lane == 0) { s_todo[wave][0][0] = 0u | total << 8; s_todo[wave][0][1] = r0.parent_side; s_todo[wave][0][2] = r0.depth_buf >> 2; s_todo[wave][0][3] = 0u; }
+    int top = 1;
+    uint32_t my_root_k = 0xffffffffu;
+    uint32_t deepest = 0;                                       // (lane 0) one atomic per wavefront at the end: every leaf's own atomicMax on the one
+                                                                // word took 1.5 ms for the 160 000 clusters of the terrain
+    const uint32_t shared_root_k = r0.parent_side == 0xffffffffu ? 0u : *root_k;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    while (top) {
+        top--;
+        const uint32_t be = s_todo[wave][top][0], parent_side = s_todo[wave][top][1], depth = s_todo[wave][top][2], known = s_todo[wave][top][3];
+        const uint32_t b = be & 0xffu, e = be >> 8, cnt = e - b;
+        const bool in = lane >= b && lane < e;
+        float v[12];                                            // box min, box max, centres min, centres max (wave-uniform)
+        if (known) { for (int q = 0; q < 12; q++) v[q] = s_tbox[wave][top][q]; }
+        else {
+            for (int q = 0; q < 12; q++) v[q] = (q % 6) < 3 ? INFINITY : -INFINITY;
+            for (uint32_t i = b; i < e; i++) {
+                const Box bx = box[i];
+                for (int q = 0; q < 3; q++) {
+                    v[q] = fminf(v[q], bx.pmin[q]); v[3 + q] = fmaxf(v[3 + q], bx.pmax[q]);
+                    const float c = (bx.pmin[q] + bx.pmax[q]) * 0.5f;
+                    v[6 + q] = fminf(v[6 + q], c); v[9 + q] = fmaxf(v[9 + q], c);
+                }
+            }
+        }
+        float cmin[3], ext[3];
+        for (int q = 0; q < 3; q++) { cmin[q] = v[6 + q]; ext[q] = v[9 + q] - v[6 + q]; }
+        Box bx;
+        uint32_t me = 0, mybins = 0;
+        if (in) {
+            bx = box[lane]; me = id[lane];
+            for (int ax = 0; ax < 3; ax++) if (ext[ax] > 0.0f) mybins |= (uint32_t)sah_bin((bx.pmin[ax] + bx.pmax[ax]) * 0.5f, cmin[ax], ext[ax]) << (4 * ax);
+            bin3[lane] = mybins;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // lane 15 * ax + q: the plane behind bin q of axis ax
+        const int cax = (int)(lane / 15u), cq = (int)(lane % 15u);
+        float cost = INFINITY;
+        uint32_t lc = 0;
+        float lb[12], rb[12];
+        for (int q = 0; q < 12; q++) { lb[q] = rb[q] = (q % 6) < 3 ? INFINITY : -INFINITY; }
+        if (lane < 45u && ext[cax < 3 ? cax : 0] > 0.0f) {
+            for (uint32_t i = b; i < e; i++) {
+                const Box ib = box[i];
+                const bool left = (int)((bin3[i] >> (4 * cax)) & 15u) <= cq;
+                lc += left ? 1u : 0u;
+                for (int q = 0; q < 3; q++) {
+                    // (neutral elements on the side the cluster is not on: no indexing of registers by side)
+                    const float c = (ib.pmin[q] + ib.pmax[q]) * 0.5f;
+                    lb[q] = fminf(lb[q], left ? ib.pmin[q] : INFINITY); lb[3 + q] = fmaxf(lb[3 + q], left ? ib.pmax[q] : -INFINITY);
+                    lb[6 + q] = fminf(lb[6 + q], left ? c : INFINITY); lb[9 + q] = fmaxf(lb[9 + q], left ? c : -INFINITY);
+                    rb[q] = fminf(rb[q], left ? INFINITY : ib.pmin[q]); rb[3 + q] = fmaxf(rb[3 + q], left ? -INFINITY : ib.pmax[q]);
+                    rb[6 + q] = fminf(rb[6 + q], left ? INFINITY : c); rb[9 + q] = fmaxf(rb[9 + q], left ? -INFINITY : c);
+                }
+            }
+            const uint32_t rc = cnt - lc;
+            if (lc != 0u && rc != 0u) cost = box_area(lb) * (float)lc + box_area(rb) * (float)rc;
+        }
+        float best = cost; uint32_t bl = lane;
+        for (int off = 32; off > 0; off >>= 1) {
+            const float oc = __shfl_xor(best, off); const uint32_t ol = __shfl_xor(bl, off);
+            if (oc < best || (oc == best && ol < bl)) { best = oc; bl = ol; }
+        }
+        const int axis = best < INFINITY ? (int)(bl / 15u) : -1;
+        const int split = (int)(bl % 15u) + 1;
+        if (axis >= 0 && lane == bl) { s_cut[wave][0] = __uint_as_float(lc); for (int q = 0; q < 12; q++) { s_cut[wave][1 + q] = lb[q]; s_cut[wave][13 + q] = rb[q]; } }
+        // stable partition of the lanes b .. e-1
+        bool goes_left = in && lane - b < cnt / 2u;
+        if (axis >= 0) goes_left = in && (int)((mybins >> (4 * axis)) & 15u) < split;
+        const uint64_t lm = __ballot(goes_left), rm = __ballot(in && !goes_left);
+        const uint32_t nl = (uint32_t)__popcll(lm);
+        const uint64_t below = lane ? (~0ull >> (64u - lane)) : 0ull;
+        if (in) {
+            const uint32_t at = goes_left ? b + (uint32_t)__popcll(lm & below) : b + nl + (uint32_t)__popcll(rm & below);
+            box[at] = bx; id[at] = me;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t mid = b + nl;
+        // the node (lane 0 writes; every lane keeps the stack pointer)
+        const uint32_t k = r0.begin + mid - 1u;
+        const bool root = parent_side == 0xffffffffu;
+        if (root) my_root_k = k;
+        const uint32_t rk = my_root_k != 0xffffffffu ? my_root_k : shared_root_k;
+        const uint32_t nid = root ? 0u : (k == 0u ? rk : k);
+        if (lane == 0) {
+            if (root) *root_k = k;
+            Box nb;
+            for (int q = 0; q < 3; q++) { nb.pmin[q] = v[q]; nb.pmax[q] = v[3 + q]; }
+            bounds[nid] = nb;
+            if (!root) {
+                const uint32_t par = parent_side >> 1;
+                if (parent_side & 1u) child_right[par] = nid; else child_left[par] = nid;
+                parent[nid] = par;
+            }
+        }
+        const uint32_t rb2[2] = { b, mid }, re2[2] = { mid, e };
+        for (int side = 1; side >= 0; side--) {
+            if (re2[side] - rb2[side] == 1u) {
+                if (lane == 0) {
+                    const uint32_t c = id[rb2[side]];
+                    if (side) child_right[nid] = c; else child_left[nid] = c;
+                    parent[c] = nid;
+                    deepest = max(deepest, depth + 1u + (c < n - 1u ? height[c] : 0u));
+                }
+            } else {
+                if (lane == 0) { s_todo[wave][top][0] = rb2[side] | re2[side] << 8; s_todo[wave][top][1] = nid << 1 | (uint32_t)side; s_todo[wave][top][2] = depth + 1u; s_todo[wave][top][3] = axis >= 0 ? 1u : 0u; }
+                if (axis >= 0 && lane < 12u) s_tbox[wave][top][lane] = s_cut[wave][1 + 12 * side + lane];
+                top++;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) atomicMax(depth_out, deepest);
+}
+
+// the clusters' boxes next to their ids, and the first range
+__global__ __launch_bounds__(kBlock)
+void k_sah_begin(const uint32_t* __restrict__ cl, const uint32_t* __restrict__ state, const Box* __restrict__ bounds, SahLists lists,
+                 SahRange* level0, uint32_t* counts, SahShort* small, uint32_t* small_count)
+{
+    const uint32_t m = state[0];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < m) { const uint32_t c = cl[i]; lists.ids[0][i] = c; lists.boxes[0][i] = bounds[c]; }
+    if (i != 0) return;
+    if (m > (uint32_t)kSahSmall) {
+        SahRange r; r.begin = 0; r.end = m; r.parent_side = 0xffffffffu; r.depth_buf = 0u;
+        for (int q = 0; q < 6; q++) { r.box[q] = 0.0f; r.cbox[q] = 0.0f; }
+        level0[0] = r; counts[0] = 1u;
+    } else if (m > 1u) {
+        SahShort r; r.begin = 0; r.end = m; r.parent_side = 0xffffffffu; r.depth_buf = 0u;
+        small[0] = r; *small_count = 1u;
+    }
+}
+
+static constexpr int kSahMaxLevels = 1024;         // counters of the level-by-level pass (a level that finds no range ends it)
+static constexpr int kSahLevelBatch = 12;          // levels launched between two looks at the range counts
+
+static int build_sah_top(AobBake* b, uint32_t n, const uint32_t* cl, uint32_t* other, const uint32_t* state, uint32_t bound)
+{
+    hipStream_t s = b->stream;
+    // workspace free at this point: the level tables in refit_flags (n words), the short ranges in codes[1] (2 n words), the lists
+    // with their boxes in sah_lists (2 x bound x 28 B), counters of their own (sah_counts: [0 .. kSahMaxLevels] ranges per level,
+    // then short ranges, then the root's cut)
+    (void)other;
+    const uint32_t per_level = bound / (uint32_t)(kSahSmall + 1) + 1u;
+    SahRange* table[2] = { (SahRange*)b->refit_flags, (SahRange*)b->refit_flags + per_level };
+    SahShort* small = (SahShort*)b->codes[1];
+    uint32_t* counts = b->sah_counts;
+    uint32_t* small_count = counts + kSahMaxLevels + 1, * root_k = counts + kSahMaxLevels + 2;
+    SahLists lists;
+    const uint64_t cap = b->sah_list_capacity;
+    lists.boxes[0] = (Box*)b->sah_lists; lists.boxes[1] = lists.boxes[0] + cap;
+    lists.ids[0] = (uint32_t*)(lists.boxes[1] + cap); lists.ids[1] = lists.ids[0] + cap;
+    if (bound > cap) { set_error("SAH top: %u clusters, room for %llu", bound, (unsigned long long)cap); return AOB_ERR_DEVICE; }
+    AOB_HIP(hipMemsetAsync(counts, 0, sizeof(uint32_t) * (kSahMaxLevels + 4), s));
+    hipLaunchKernelGGL(k_sah_begin, dim3(blocks_for(bound)), dim3(kBlock), 0, s, cl, state, b->node_bounds, lists, table[0], counts, small, small_count);
+    // level by level, a batch of levels between two looks at the range counts (a level without ranges is an empty launch)
+    uint32_t* host = b->pinned + 12;
+    int level = 0;
+    for (;;) {
+        for (int k = 0; k < kSahLevelBatch && level < kSahMaxLevels; k++, level++)
+            hipLaunchKernelGGL(k_sah_level, dim3(per_level), dim3(kSahBlock), 0, s, table[level & 1], counts + level, lists, n, root_k, b->child_left, b->child_right,
+                               b->parent, b->node_bounds, b->node_height, b->depth_dev, table[(level & 1) ^ 1], counts + level + 1, small, small_count);
+        AOB_HIP(hipMemcpyAsync(host, counts + level, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        AOB_HIP(hipStreamSynchronize(s));
+        if (host[0] == 0u) break;
+        if (level >= kSahMaxLevels) { set_error("the SAH top needs more than %d levels", kSahMaxLevels); return AOB_ERR_BVH_TOO_DEEP; }
+    }
+    hipLaunchKernelGGL(k_sah_wave, dim3(bound / 2u / (kSahWaveBlock / 64) + 1u), dim3(kSahWaveBlock), 0, s, small, small_count, lists, n, root_k, b->child_left, b->child_right,
+                       b->parent, b->node_bounds, b->node_height, b->depth_dev);
     return AOB_OK;
 }
 
@@ -780,11 +1247,11 @@ int build_bvh(AobBake* b)
     size_t temp = b->sort_temp_bytes;
     AOB_HIP(rocprim::radix_sort_pairs(b->sort_temp, temp, b->codes[0], b->codes[1], b->prim_idx[0], b->prim_idx[1],
                                       (size_t)n, 0u, 63u, s));
-    if (n > 1 && b->opt.bvh_builder == 1) {
+    if (n > 1 && b->opt.bvh_builder >= 1) {
         AOB_HIP(hipMemsetAsync(b->depth_dev, 0, sizeof(uint32_t), s));
         hipLaunchKernelGGL(k_leaf_bounds, dim3(blocks_for(n)), dim3(kBlock), 0, s, b->prim_bounds, b->prim_idx[1],
                            (uint32_t)n, b->node_bounds);
-        AOB_TRY(build_ploc(b, (uint32_t)n));
+        AOB_TRY(build_ploc(b, (uint32_t)n, b->opt.bvh_builder == 2 ? (uint32_t)kSahTopClusters : 1u));
     } else if (n > 1) {
         AOB_HIP(hipMemsetAsync(b->refit_flags, 0, sizeof(uint32_t) * (n - 1), s));
         AOB_HIP(hipMemsetAsync(b->depth_dev, 0, sizeof(uint32_t), s));

@@ -397,6 +397,101 @@ static inline float merged_area(const Box* a, const Box* b)
     return fmaf(dz, dx, fmaf(dy, dz, dx * dy));
 }
 
+/* bvh_builder 2 (bvh_build.hip build_sah_top): the top of the tree, over the m clusters PLOC has made so far (`cl`, in list order;
+ * a cluster is a node id with its box in `bounds`), top-down by binned SAH — the reference stack's own lever for traversal cost
+ * (RadeonRays/radeon_rays.h:286-294: bvh.builder = "sah").  Every list range [b, e) of two or more clusters:
+ *   - the box of the clusters' centres c = (pmin + pmax) * 0.5; on every axis with a positive extent 16 bins,
+ *     bin = min(15, (int)((c - cmin) / extent * 16)), with the clusters' count and box per bin;
+ *   - the 3 x 15 planes between bins, in axis then bin order: cost = area(left) * count(left) + area(right) * count(right),
+ *     area = dx * dy + dy * dz + dz * dx; the first plane of the lowest cost that leaves clusters on both sides wins;
+ *   - the range is partitioned at that plane KEEPING THE LIST ORDER on both sides (no such plane: cut in the middle of the list);
+ *   - the node's id is a function of where its range was cut: with the left part [b, mid) the position k = mid - 1 is unique
+ *     among all nodes, and lies in 0 .. m-2 — the ids PLOC's own numbering (the k-th node made is n-2-k) has not used.  The root
+ *     must be node 0: the root takes id 0 and the one node cut at k = 0 takes the root's k instead.  No order of construction
+ *     enters: ranges can be split level by level, or each by a thread of its own. */
+#define ORC_SAH_TOP_CLUSTERS 131072
+#define ORC_SAH_BINS 16
+typedef struct { int64_t begin, end; uint32_t parent; int side; } TopRange;
+/* the cut of one range: returns mid (b < mid < e) and leaves the range's clusters partitioned in tmp[b, e); *node_box = their box */
+static int64_t sah_cut(const uint32_t* cl, uint32_t* tmp, int64_t b, int64_t e, const Box* bounds, Box* node_box)
+{
+    const int64_t cnt = e - b;
+    float cmin[3] = { INFINITY, INFINITY, INFINITY }, cmax[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (int k = 0; k < 3; k++) { node_box->pmin[k] = INFINITY; node_box->pmax[k] = -INFINITY; }
+    for (int64_t i = b; i < e; i++) {
+        box_union(node_box, node_box, &bounds[cl[i]]);
+        for (int k = 0; k < 3; k++) {
+            const float c = (bounds[cl[i]].pmin[k] + bounds[cl[i]].pmax[k]) * 0.5f;
+            cmin[k] = fminf(cmin[k], c); cmax[k] = fmaxf(cmax[k], c);
+        }
+    }
+    int best_axis = -1, best_split = 0; float best_cost = INFINITY;
+    for (int ax = 0; ax < 3; ax++) {
+        const float ext = cmax[ax] - cmin[ax];
+        if (!(ext > 0.0f)) continue;
+        Box bb[ORC_SAH_BINS]; uint32_t bc[ORC_SAH_BINS];
+        for (int q = 0; q < ORC_SAH_BINS; q++) { bc[q] = 0; for (int k = 0; k < 3; k++) { bb[q].pmin[k] = INFINITY; bb[q].pmax[k] = -INFINITY; } }
+        for (int64_t i = b; i < e; i++) {
+            const float c = (bounds[cl[i]].pmin[ax] + bounds[cl[i]].pmax[ax]) * 0.5f;
+            int q = (int)((c - cmin[ax]) / ext * (float)ORC_SAH_BINS); if (q > ORC_SAH_BINS - 1) q = ORC_SAH_BINS - 1;
+            bc[q]++; box_union(&bb[q], &bb[q], &bounds[cl[i]]);
+        }
+        float right_area[ORC_SAH_BINS]; uint32_t right_cnt[ORC_SAH_BINS];
+        Box acc; for (int k = 0; k < 3; k++) { acc.pmin[k] = INFINITY; acc.pmax[k] = -INFINITY; }
+        uint32_t c = 0;
+        for (int q = ORC_SAH_BINS - 1; q > 0; q--) {
+            c += bc[q]; if (bc[q]) box_union(&acc, &acc, &bb[q]);
+            const float dx = acc.pmax[0] - acc.pmin[0], dy = acc.pmax[1] - acc.pmin[1], dz = acc.pmax[2] - acc.pmin[2];
+            right_area[q] = c ? dx * dy + dy * dz + dz * dx : 0.0f; right_cnt[q] = c;
+        }
+        for (int k = 0; k < 3; k++) { acc.pmin[k] = INFINITY; acc.pmax[k] = -INFINITY; }
+        c = 0;
+        for (int q = 0; q < ORC_SAH_BINS - 1; q++) {
+            c += bc[q]; if (bc[q]) box_union(&acc, &acc, &bb[q]);
+            if (c == 0 || right_cnt[q + 1] == 0) continue;
+            const float dx = acc.pmax[0] - acc.pmin[0], dy = acc.pmax[1] - acc.pmin[1], dz = acc.pmax[2] - acc.pmin[2];
+            const float cost = (dx * dy + dy * dz + dz * dx) * (float)c + right_area[q + 1] * (float)right_cnt[q + 1];
+            if (cost < best_cost) { best_cost = cost; best_axis = ax; best_split = q + 1; }
+        }
+    }
+    if (best_axis < 0) { for (int64_t i = b; i < e; i++) tmp[i] = cl[i]; return b + cnt / 2; }
+    const float ext = cmax[best_axis] - cmin[best_axis];
+    int64_t at = b, mid = b;
+    for (int pass = 0; pass < 2; pass++) {          /* stable: the left clusters in list order, then the right ones */
+        for (int64_t i = b; i < e; i++) {
+            const float c = (bounds[cl[i]].pmin[best_axis] + bounds[cl[i]].pmax[best_axis]) * 0.5f;
+            int q = (int)((c - cmin[best_axis]) / ext * (float)ORC_SAH_BINS); if (q > ORC_SAH_BINS - 1) q = ORC_SAH_BINS - 1;
+            if ((q < best_split) == (pass == 0)) tmp[at++] = cl[i];
+        }
+        if (pass == 0) mid = at;
+    }
+    return mid;
+}
+static void sah_top(uint32_t* cl, uint32_t* tmp, int64_t m, Box* bounds, uint32_t* left, uint32_t* right, uint32_t* parent)
+{
+    TopRange* todo = (TopRange*)malloc(sizeof(TopRange) * (size_t)m);
+    int64_t top = 0;
+    int64_t root_k = -1;
+    todo[top].begin = 0; todo[top].end = m; todo[top].parent = 0xffffffffu; todo[top].side = 0; top++;
+    while (top) {
+        const TopRange t = todo[--top];
+        Box bx;
+        const int64_t mid = sah_cut(cl, tmp, t.begin, t.end, bounds, &bx);
+        for (int64_t i = t.begin; i < t.end; i++) cl[i] = tmp[i];
+        const int64_t k = mid - 1;
+        if (t.parent == 0xffffffffu) root_k = k;
+        const uint32_t id = t.parent == 0xffffffffu ? 0u : (k == 0 ? (uint32_t)root_k : (uint32_t)k);
+        bounds[id] = bx;
+        if (t.parent != 0xffffffffu) { if (t.side == 0) left[t.parent] = id; else right[t.parent] = id; parent[id] = t.parent; }
+        const int64_t rb[2] = { t.begin, mid }, re[2] = { mid, t.end };
+        for (int s2 = 1; s2 >= 0; s2--) {
+            if (re[s2] - rb[s2] == 1) { const uint32_t c = cl[rb[s2]]; if (s2 == 0) left[id] = c; else right[id] = c; parent[c] = id; }
+            else { todo[top].begin = rb[s2]; todo[top].end = re[s2]; todo[top].parent = id; todo[top].side = s2; top++; }
+        }
+    }
+    free(todo);
+}
+
 uint64_t orc_bvh_build(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes, uint32_t* depth_out)
 {
     return orc_bvh_build_ex(tris, n, nodes, depth_out, 0, 0);
@@ -463,7 +558,7 @@ uint64_t orc_bvh_build_ex(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes
     Box* bounds = (Box*)malloc(sizeof(Box) * node_count);
     parent[0] = 0xffffffffu;
     uint32_t max_depth = 0;
-    if (builder == 1) {
+    if (builder == 1 || builder == 2) {
         /* PLOC: the sequential statement of the library's parallel builder.  Clusters in Morton order look
          * `radius` places left and right for the neighbour with the smallest merged surface area (ties: the
          * lower position); mutual nearest neighbours merge; the list is compacted; repeat.  Node ids are final
@@ -473,7 +568,10 @@ uint64_t orc_bvh_build_ex(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes
         uint32_t* cl = (uint32_t*)malloc(4 * n); uint32_t* nxt = (uint32_t*)malloc(4 * n); uint32_t* nn = (uint32_t*)malloc(4 * n);
         for (int64_t p = 0; p < N; p++) cl[p] = (uint32_t)(N - 1 + p);
         int64_t m = N; uint32_t created = 0; int iter = 0;
-        while (m > 1) {
+        /* builder 2: clustering stops once the list is short enough for the top of the tree to be built over the clusters
+         * top-down, by binned SAH (below) — where a SAH tree differs most from an agglomerated one */
+        const int64_t stop = builder == 2 ? ORC_SAH_TOP_CLUSTERS : 1;
+        while (m > stop) {
             const int forced = iter >= 256;
             for (int64_t i = 0; i < m; i++) {
                 if (forced) { nn[i] = (uint32_t)(((i ^ 1) < m) ? (i ^ 1) : i); continue; }
@@ -503,6 +601,7 @@ uint64_t orc_bvh_build_ex(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes
             uint32_t* t = cl; cl = nxt; nxt = t;
             m = pos; created += mk; iter++;
         }
+        if (m > 1) sah_top(cl, nxt, m, bounds, left, right, parent);
         parent[0] = 0xffffffffu;
         for (int64_t p = 0; p < N; p++) {
             uint32_t dpt = 0;

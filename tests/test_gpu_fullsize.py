@@ -49,7 +49,7 @@ def test_config2_sphere_complete_bake(engine, orc):
     assert 0.2 < g.ao()[g.ao() > 0].mean() < 1.0
 
 
-@pytest.mark.parametrize("builder", [1, 0])
+@pytest.mark.parametrize("builder", [1, 0, 2])
 def test_config3_bvh_and_surfels_bit_exact(engine, orc, terrain, builder):
     flat = FlatScene(terrain)
     opt = cosine_options(orc, 4, bvh_builder=builder)

@@ -54,7 +54,7 @@ def random_options(rng):
     o.falloff_distance = float(rng.uniform(0.1, 2.0)); o.clamp_tmax_to_falloff = int(rng.integers(0, 2)); o.material_ranges = int(rng.integers(0, 2))
     o.ray_tmax = float(rng.choice([1e6, 0.7, 3.0])); o.ray_bias = float(rng.choice([0.001, 0.0, 0.01]))
     o.bvh_width, o.bvh_quantised = [(4, 1), (4, 1), (2, 1), (2, 0)][int(rng.integers(0, 4))]
-    o.bvh_builder = int(rng.integers(0, 2)); o.morton_adaptive = int(rng.integers(0, 2))
+    o.bvh_builder = int(rng.integers(0, 3)); o.morton_adaptive = int(rng.integers(0, 2))
     o.raster_mode = int(rng.integers(0, 2))       # drawn last: the cases keep the options they had before it existed
     o.raster_layers = int(rng.integers(0, 2))
     o.ray_chunk_size = int(rng.choice([0xFFFFFF, 4096, 640, 64]))      # the compat sampler's chunk-local table index wraps

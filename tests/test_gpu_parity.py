@@ -39,10 +39,12 @@ SCENES = {
 
 
 @pytest.mark.parametrize("adaptive", [0, 1])
-@pytest.mark.parametrize("builder", [0, 1])
+@pytest.mark.parametrize("builder", [0, 1, 2])
 @pytest.mark.parametrize("name", ["cube", "two_section", "sphere", "terrain", "floor_wall", "plane"])
 def test_bvh_nodes_bit_exact(engine, orc, name, builder, adaptive):
-    """builder 0: LBVH (build_hlbvh.cl); builder 1: PLOC; adaptive: the Morton bit order.  Topology, boxes, leaf order, depth."""
+    """builder 0: LBVH (build_hlbvh.cl); builder 1: PLOC; builder 2: binned SAH top-down over PLOC's clusters (these scenes have
+    fewer triangles than clustering stops at: the whole tree is the SAH tree); adaptive: the Morton bit order.  Topology, boxes,
+    leaf order, depth."""
     flat = FlatScene(SCENES[name]())
     ref_nodes, ref_depth = orc.bvh_build(orc.scene_triangles(flat.desc), builder, adaptive)
     with Baker(flat, make_options(orc, bvh_builder=builder, morton_adaptive=adaptive)) as b:
@@ -562,12 +564,13 @@ def test_instanced_scene_with_transforms(engine, orc, mode):
 
 @pytest.mark.parametrize("mode", [2, 3, 0])
 @pytest.mark.parametrize("name", ["terrain", "sphere", "cube_inward"])
-def test_ploc_builder_end_to_end(engine, orc, name, mode):
-    """bvh_builder = 1 through every derived structure and the trace, against the oracle's PLOC twin."""
+@pytest.mark.parametrize("builder", [1, 2])
+def test_ploc_builder_end_to_end(engine, orc, name, mode, builder):
+    """bvh_builder = 1 (and 2: the SAH top) through every derived structure and the trace, against the oracle's twin."""
     flat = FlatScene(SCENES[name]())
-    opt = make_options(orc, sample_count=16, bvh_builder=1, **MODES[mode])
+    opt = make_options(orc, sample_count=16, bvh_builder=builder, **MODES[mode])
     m = flat.material_array[0]
-    nodes, _ = orc.bvh_build(orc.scene_triangles(flat.desc), 1)
+    nodes, _ = orc.bvh_build(orc.scene_triangles(flat.desc), builder)
     surfels, sidx = orc.rasterize(flat.desc, 0, opt)
     hemi = orc.compat_table(opt) if opt.sampler == capi.SAMPLER_REFERENCE_COMPAT else None
     ref, st1 = orc.trace(nodes, surfels, sidx, opt, m.width, m.height, hemi, threads=8)

@@ -68,6 +68,11 @@ def child(modes, reps, knobs):
                 ms.append(b.last_trace_ms())
             n = b.surfel_count(0)
             crc = zlib.crc32(np.ascontiguousarray(b.results(0)).tobytes())
+            import time as _time
+            build_ms = []
+            for _ in range(3):                                   # the build's wall time, three times (the stream drained before and after)
+                b.sync(); t0 = _time.perf_counter(); b.build_bvh(); b.sync(); build_ms.append((_time.perf_counter() - t0) * 1e3)
+            st = b.stats()
             stats = None
             if hasattr(b.lib, "aob_debug_trace_stats"):          # a diagnostic build (-DAOB_TRACE_STATS=1): the loop counters of ONE trace
                 import ctypes
@@ -87,7 +92,8 @@ def child(modes, reps, knobs):
                                     "inner_sections_with_a_deep_stack": round(stats["deep_stack_visits"] / max(1, stats["inner_sections"]), 4)}
         best = min(ms[1:])
         print(json.dumps({"lib": os.path.relpath(lib, ROOT) if lib != "-" else "in-tree", "mode": mode, "knobs": knobs, "trace_ms": round(best, 3),
-                          "all_ms": [round(x, 3) for x in ms], "grays_per_s": round(n * spp / best / 1e6, 3), "results_crc32": crc, **({"loop_counters": stats} if stats else {})}), flush=True)
+                          "all_ms": [round(x, 3) for x in ms], "grays_per_s": round(n * spp / best / 1e6, 3), "results_crc32": crc,
+                          "bvh_build_wall_ms": round(min(build_ms), 3), "bvh_depth": st.bvh_depth, **({"loop_counters": stats} if stats else {})}), flush=True)
     BakeEngine.Dispose()
 
 
