@@ -96,6 +96,7 @@ struct AobBake {
     uint32_t* sah_counts = nullptr;       // bvh_builder 2: ranges per level, short ranges, the root's cut (bvh_build.hip build_sah_top)
     uint8_t*  sah_lists = nullptr;        // ... and its two cluster lists, ids + boxes (2 x 28 B per cluster)
     uint64_t  sah_list_capacity = 0;
+    uint8_t*  sah_big = nullptr;          // ... and its long ranges: tables, the slices' bins, the cuts
     AobBvhNode* nodes = nullptr;
     float4*   nodes4 = nullptr;         // 8 x float4 per 4-ary node (AobBvh4Node), indexed by BVH2 inner index
     float4*   leaf_tris = nullptr;      // 3 x float4 per triangle in Morton order (AobLeafTri)

@@ -290,7 +290,8 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
     plan.want(&b->node_height, n);
     plan.want(&b->ploc_sums, n / 1024 + 4);
     plan.want(&b->ploc_totals, 8);
-    plan.want(&b->sah_counts, 1024 + 8);
+    plan.want(&b->sah_counts, 1024 + 16 + 64 + 8);
+    plan.want(&b->sah_big, 1u << 20);
     b->sah_list_capacity = n < 131072u ? n : 131072u;           // kSahTopClusters (bvh_build.hip)
     plan.want(&b->sah_lists, 2 * 28 * b->sah_list_capacity);
     plan.want(&b->nodes, 2 * n);

@@ -773,6 +773,8 @@ static int build_ploc(AobBake* b, uint32_t n, uint32_t stop)
 static constexpr int kSahTopClusters = 131072;
 static constexpr int kSahBins = 16;
 static constexpr int kSahSmall = 32;               // ranges of at most this many clusters are finished by one wavefront each
+static constexpr int kSahBig = 8192;               // ranges of more than this many are cut by kSahSlices workgroups together
+static constexpr int kSahSlices = 16;
 // A range of the list that is to be cut: parent << 1 | side (0xffffffff: the root); depth << 2 | boxes known << 1 | the list it
 // lives in; its clusters' box and the box of their centres, handed down by the cut that made it (the bins of the parent on either
 // side of the plane), so that a range is read twice, not three times.
@@ -877,7 +879,8 @@ __device__ __forceinline__ void sah_emit(uint32_t begin, uint32_t end, uint32_t 
                                          const SahCut* cut, const uint32_t* list, uint32_t out_buf,
                                          uint32_t n, uint32_t* root_k, uint32_t* child_left, uint32_t* child_right, uint32_t* parent, Box* bounds,
                                          const uint32_t* height, uint32_t* depth_out,
-                                         SahRange* next, uint32_t* next_count, SahShort* small, uint32_t* small_count)
+                                         SahRange* next, uint32_t* next_count, SahShort* small, uint32_t* small_count,
+                                         SahRange* big = nullptr, uint32_t* big_count = nullptr, bool emit_single = true)
 {
     const uint32_t k = mid - 1u;
     const bool root = parent_side == 0xffffffffu;
@@ -895,6 +898,7 @@ __device__ __forceinline__ void sah_emit(uint32_t begin, uint32_t end, uint32_t 
     for (uint32_t side = 0; side < 2u; side++) {
         const uint32_t cb = rb[side], ce = re[side];
         if (ce - cb == 1u) {
+            if (!emit_single) continue;                                             // (k_big_move links it when it moves it)
             const uint32_t c = list[cb];
             if (side) child_right[id] = c; else child_left[id] = c;
             parent[c] = id;
@@ -905,7 +909,8 @@ __device__ __forceinline__ void sah_emit(uint32_t begin, uint32_t end, uint32_t 
             ch.depth_buf = (depth + 1u) << 2 | (known ? 2u : 0u) | out_buf;
             const float* sbx = known ? (side ? cut->rbox : cut->lbox) : node_box;
             for (int q = 0; q < 6; q++) { ch.box[q] = sbx[q]; ch.cbox[q] = known ? sbx[6 + q] : 0.0f; }
-            next[atomicAdd(next_count, 1u)] = ch;
+            if (big && known && ce - cb > (uint32_t)kSahBig) big[atomicAdd(big_count, 1u)] = ch;
+            else next[atomicAdd(next_count, 1u)] = ch;
         } else {
             SahShort ch; ch.begin = cb; ch.end = ce; ch.parent_side = id << 1 | side; ch.depth_buf = (depth + 1u) << 2 | out_buf;
             small[atomicAdd(small_count, 1u)] = ch;
@@ -1158,19 +1163,202 @@ void k_sah_wave(const SahShort* __restrict__ ranges, const uint32_t* __restrict_
     if (lane == 0) atomicMax(depth_out, deepest);
 }
 
-// the clusters' boxes next to their ids, and the first range
-__global__ __launch_bounds__(kBlock)
-void k_sah_begin(const uint32_t* __restrict__ cl, const uint32_t* __restrict__ state, const Box* __restrict__ bounds, SahLists lists,
-                 SahRange* level0, uint32_t* counts, SahShort* small, uint32_t* small_count)
+// ---- ranges of more than kSahBig clusters: kSahSlices workgroups each ----
+// One workgroup walking 100 000 clusters three times is most of a millisecond; the longest ranges — the first few levels — are
+// cut by kSahSlices workgroups each: every workgroup bins its slice (k_big_bins), one wavefront per range adds the slices' bins
+// up, picks the plane, makes the node and tells every slice where its left and right clusters go (k_big_cut), the workgroups move
+// them (k_big_move).  Same bins, same plane, same order of the clusters as one workgroup would have made.
+struct SahBigCut { int axis, split; uint32_t node, depth, nl, lbase[kSahSlices], rbase[kSahSlices]; float cmin[3], ext[3]; };
+
+__device__ __forceinline__ void sah_slice(const SahRange& r, uint32_t g, uint32_t& s0, uint32_t& s1)
 {
+    const uint32_t len = r.end - r.begin, per = (len + kSahSlices - 1u) / kSahSlices;
+    s0 = min(r.end, r.begin + g * per); s1 = min(r.end, s0 + per);
+}
+
+__global__ __launch_bounds__(kBlock)
+void k_big_bins(const SahRange* __restrict__ ranges, const uint32_t* __restrict__ count, SahLists lists, SahBins* __restrict__ gbins)
+{
+    __shared__ SahBins s_bins;
+    const uint32_t ri = blockIdx.x / kSahSlices, g = blockIdx.x % kSahSlices;
+    if (ri >= *count) return;
+    const SahRange r = ranges[ri];
+    const Box* src_box = lists.boxes[r.depth_buf & 1u];
+    uint32_t s0, s1;
+    sah_slice(r, g, s0, s1);
+    const uint32_t tid = threadIdx.x;
+    sah_bins_clear(&s_bins, tid, kBlock);
+    __syncthreads();
+    float cmin[3], ext[3];
+    for (int q = 0; q < 3; q++) { cmin[q] = r.cbox[q]; ext[q] = r.cbox[3 + q] - r.cbox[q]; }
+    const uint32_t chunk = (s1 - s0 + kBlock - 1u) / kBlock;
+    const uint32_t i0 = s0 + tid * chunk, i1 = min(s1, i0 + chunk);
+    SahRun run[3];
+    for (int ax = 0; ax < 3; ax++) { run[ax].bin = -1; run[ax].cnt = 0u; }
+    for (uint32_t i = i0; i < i1; i++) {
+        const Box bx = src_box[i];
+        for (int ax = 0; ax < 3; ax++) if (ext[ax] > 0.0f) sah_run_add(&s_bins, ax, run[ax], bx, cmin[ax], ext[ax]);
+    }
+    for (int ax = 0; ax < 3; ax++) sah_run_flush(&s_bins, ax, run[ax]);
+    __syncthreads();
+    uint32_t* out = (uint32_t*)&gbins[(uint64_t)ri * kSahSlices + g];
+    for (uint32_t i = tid; i < sizeof(SahBins) / 4u; i += kBlock) out[i] = ((const uint32_t*)&s_bins)[i];
+}
+
+__global__ __launch_bounds__(64)
+void k_big_cut(const SahRange* __restrict__ ranges, const uint32_t* __restrict__ count, const SahBins* __restrict__ gbins, SahBigCut* __restrict__ cuts,
+               uint32_t n, uint32_t* root_k, uint32_t* __restrict__ child_left, uint32_t* __restrict__ child_right, uint32_t* __restrict__ parent,
+               Box* __restrict__ bounds, const uint32_t* __restrict__ height, uint32_t* depth_out,
+               SahRange* __restrict__ big_next, uint32_t* big_next_count, SahRange* __restrict__ next, uint32_t* next_count,
+               SahShort* __restrict__ small, uint32_t* small_count)
+{
+    __shared__ SahBins s_bins;
+    const uint32_t ri = blockIdx.x, lane = threadIdx.x;
+    if (ri >= *count) return;
+    const SahRange r = ranges[ri];
+    // the slices' bins, added up (sums, minima and maxima of ordered-uint codes: any order)
+    for (uint32_t i = lane; i < 3u * kSahBins; i += 64u) {
+        uint32_t c = 0;
+        for (uint32_t g = 0; g < (uint32_t)kSahSlices; g++) c += (&gbins[(uint64_t)ri * kSahSlices + g].cnt[0][0])[i];
+        (&s_bins.cnt[0][0])[i] = c;
+    }
+    for (uint32_t i = lane; i < 3u * kSahBins * 12u; i += 64u) {
+        const bool is_min = (i % 6u) < 3u;
+        uint32_t v = is_min ? 0xffffffffu : 0u;
+        for (uint32_t g = 0; g < (uint32_t)kSahSlices; g++) { const uint32_t x = (&gbins[(uint64_t)ri * kSahSlices + g].box[0][0][0])[i]; v = is_min ? min(v, x) : max(v, x); }
+        (&s_bins.box[0][0][0])[i] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    float ext[3];
+    for (int q = 0; q < 3; q++) ext[q] = r.cbox[3 + q] - r.cbox[q];
+    const SahCut c = sah_select(&s_bins, ext);
+    SahBigCut* out = &cuts[ri];
+    const uint32_t depth = r.depth_buf >> 2;
+    if (c.axis < 0) {
+        // no plane separates the centres: the range goes to the one-workgroup pass as it is (it cuts the list in the middle)
+        if (lane == 0) { out->axis = -1; next[atomicAdd(next_count, 1u)] = r; }
+        return;
+    }
+    // where every slice's left and right clusters go
+    uint32_t mine = 0;
+    if (lane < (uint32_t)kSahSlices) for (int q = 0; q < c.split; q++) mine += gbins[(uint64_t)ri * kSahSlices + lane].cnt[c.axis][q];
+    uint32_t before = mine;
+    for (int off = 1; off < kSahSlices; off <<= 1) { const uint32_t o = __shfl_up(before, off); if ((int)lane >= off) before += o; }
+    before -= mine;
+    uint32_t s0, s1;
+    sah_slice(r, min(lane, (uint32_t)kSahSlices - 1u), s0, s1);
+    if (lane < (uint32_t)kSahSlices) { out->lbase[lane] = r.begin + before; out->rbase[lane] = r.begin + c.nl + (s0 - r.begin) - before; }
+    if (lane == 0) {
+        const uint32_t mid = r.begin + c.nl;
+        const uint32_t k = mid - 1u;
+        const bool root = r.parent_side == 0xffffffffu;
+        if (root) *root_k = k;
+        out->axis = c.axis; out->split = c.split; out->nl = c.nl; out->depth = depth;
+        out->node = root ? 0u : (k == 0u ? *root_k : k);
+        for (int q = 0; q < 3; q++) { out->cmin[q] = r.cbox[q]; out->ext[q] = ext[q]; }
+        sah_emit(r.begin, r.end, r.parent_side, depth, mid, r.box, &c, nullptr, (r.depth_buf & 1u) ^ 1u, n, root_k, child_left, child_right, parent, bounds,
+                 height, depth_out, next, next_count, small, small_count, big_next, big_next_count, false);
+    }
+}
+
+__global__ __launch_bounds__(kBlock)
+void k_big_move(const SahRange* __restrict__ ranges, const uint32_t* __restrict__ count, const SahBigCut* __restrict__ cuts, SahLists lists,
+                uint32_t n, uint32_t* __restrict__ child_left, uint32_t* __restrict__ child_right, uint32_t* __restrict__ parent,
+                const uint32_t* __restrict__ height, uint32_t* depth_out)
+{
+    constexpr int kWaves = kBlock / 64;
+    __shared__ uint32_t s_wave[kWaves];
+    const uint32_t ri = blockIdx.x / kSahSlices, g = blockIdx.x % kSahSlices;
+    if (ri >= *count) return;
+    const SahBigCut cut = cuts[ri];
+    if (cut.axis < 0) return;
+    const SahRange r = ranges[ri];
+    const uint32_t from = r.depth_buf & 1u, to = from ^ 1u;
+    const uint32_t* src = lists.ids[from]; const Box* src_box = lists.boxes[from];
+    uint32_t* dst = lists.ids[to]; Box* dst_box = lists.boxes[to];
+    uint32_t s0, s1;
+    sah_slice(r, g, s0, s1);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t nr = (r.end - r.begin) - cut.nl;
+    uint32_t lbase = cut.lbase[g], rbase = cut.rbase[g];
+    for (uint32_t t0 = s0; t0 < s1; t0 += kBlock) {
+        const uint32_t i = t0 + tid;
+        const bool in = i < s1;
+        uint32_t c = 0; bool goes_left = false; Box bx;
+        if (in) {
+            c = src[i]; bx = src_box[i];
+            goes_left = sah_bin((bx.pmin[cut.axis] + bx.pmax[cut.axis]) * 0.5f, cut.cmin[cut.axis], cut.ext[cut.axis]) < cut.split;
+        }
+        const uint64_t lm = __ballot(in && goes_left), rm = __ballot(in && !goes_left);
+        if (lane == 0u) s_wave[wave] = (uint32_t)__popcll(lm) | (uint32_t)__popcll(rm) << 16;
+        __syncthreads();
+        uint32_t lbefore = 0, rbefore = 0, ltotal = 0, rtotal = 0;
+        for (uint32_t w = 0; w < (uint32_t)kWaves; w++) {
+            const uint32_t v = s_wave[w];
+            if (w < wave) { lbefore += v & 0xffffu; rbefore += v >> 16; }
+            ltotal += v & 0xffffu; rtotal += v >> 16;
+        }
+        const uint64_t below = lane ? (~0ull >> (64u - lane)) : 0ull;
+        if (in) {
+            const uint32_t at = goes_left ? lbase + lbefore + (uint32_t)__popcll(lm & below) : rbase + rbefore + (uint32_t)__popcll(rm & below);
+            dst[at] = c; dst_box[at] = bx;
+            // a side of one cluster: its link (sah_emit left it to the thread that knows which cluster it is)
+            if ((goes_left && cut.nl == 1u) || (!goes_left && nr == 1u)) {
+                if (goes_left) child_left[cut.node] = c; else child_right[cut.node] = c;
+                parent[c] = cut.node;
+                atomicMax(depth_out, cut.depth + 1u + (c < n - 1u ? height[c] : 0u));
+            }
+        }
+        lbase += ltotal; rbase += rtotal;
+        __syncthreads();
+    }
+}
+
+// the clusters' boxes next to their ids; per workgroup their box and the box of their centres (for the first range)
+__global__ __launch_bounds__(kBlock)
+void k_sah_begin(const uint32_t* __restrict__ cl, const uint32_t* __restrict__ state, const Box* __restrict__ bounds, SahLists lists, float* __restrict__ partial)
+{
+    __shared__ float s_red[kBlock / 64][12];
     const uint32_t m = state[0];
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < m) { const uint32_t c = cl[i]; lists.ids[0][i] = c; lists.boxes[0][i] = bounds[c]; }
-    if (i != 0) return;
+    float v[12];
+    for (int q = 0; q < 12; q++) v[q] = (q % 6) < 3 ? INFINITY : -INFINITY;
+    if (i < m) {
+        const uint32_t c = cl[i]; const Box bx = bounds[c];
+        lists.ids[0][i] = c; lists.boxes[0][i] = bx;
+        for (int q = 0; q < 3; q++) { v[q] = bx.pmin[q]; v[3 + q] = bx.pmax[q]; v[6 + q] = v[9 + q] = (bx.pmin[q] + bx.pmax[q]) * 0.5f; }
+    }
+    for (int q = 0; q < 12; q++)
+        for (int off = 32; off > 0; off >>= 1) v[q] = (q % 6) < 3 ? fminf(v[q], __shfl_xor(v[q], off)) : fmaxf(v[q], __shfl_xor(v[q], off));
+    if ((threadIdx.x & 63u) == 0u) for (int q = 0; q < 12; q++) s_red[threadIdx.x >> 6][q] = v[q];
+    __syncthreads();
+    if (threadIdx.x < 12u) {
+        const int q = (int)threadIdx.x;
+        float x = s_red[0][q];
+        for (int w = 1; w < kBlock / 64; w++) x = (q % 6) < 3 ? fminf(x, s_red[w][q]) : fmaxf(x, s_red[w][q]);
+        partial[12u * blockIdx.x + q] = x;
+    }
+}
+// ... and the first range: to the workgroups-per-range pass, the workgroup-per-range pass or the wavefront-per-range pass by length
+__global__ __launch_bounds__(64)
+void k_sah_root(const uint32_t* __restrict__ state, const float* __restrict__ partial, uint32_t blocks, SahRange* big0, uint32_t* big_count,
+                SahRange* level0, uint32_t* counts, SahShort* small, uint32_t* small_count)
+{
+    const uint32_t m = state[0], lane = threadIdx.x;
+    const uint32_t used = min(blocks, (m + kBlock - 1u) / kBlock);
+    float v[12];
+    for (int q = 0; q < 12; q++) v[q] = (q % 6) < 3 ? INFINITY : -INFINITY;
+    for (uint32_t bk = lane; bk < used; bk += 64u)
+        for (int q = 0; q < 12; q++) v[q] = (q % 6) < 3 ? fminf(v[q], partial[12u * bk + q]) : fmaxf(v[q], partial[12u * bk + q]);
+    for (int q = 0; q < 12; q++)
+        for (int off = 32; off > 0; off >>= 1) v[q] = (q % 6) < 3 ? fminf(v[q], __shfl_xor(v[q], off)) : fmaxf(v[q], __shfl_xor(v[q], off));
+    if (lane != 0) return;
     if (m > (uint32_t)kSahSmall) {
-        SahRange r; r.begin = 0; r.end = m; r.parent_side = 0xffffffffu; r.depth_buf = 0u;
-        for (int q = 0; q < 6; q++) { r.box[q] = 0.0f; r.cbox[q] = 0.0f; }
-        level0[0] = r; counts[0] = 1u;
+        SahRange r; r.begin = 0; r.end = m; r.parent_side = 0xffffffffu; r.depth_buf = 2u;
+        for (int q = 0; q < 6; q++) { r.box[q] = v[q]; r.cbox[q] = v[6 + q]; }
+        if (m > (uint32_t)kSahBig) { big0[0] = r; big_count[0] = 1u; }
+        else { level0[0] = r; counts[0] = 1u; }
     } else if (m > 1u) {
         SahShort r; r.begin = 0; r.end = m; r.parent_side = 0xffffffffu; r.depth_buf = 0u;
         small[0] = r; *small_count = 1u;
@@ -1179,28 +1367,55 @@ void k_sah_begin(const uint32_t* __restrict__ cl, const uint32_t* __restrict__ s
 
 static constexpr int kSahMaxLevels = 1024;         // counters of the level-by-level pass (a level that finds no range ends it)
 static constexpr int kSahLevelBatch = 12;          // levels launched between two looks at the range counts
+static constexpr int kSahBigLevels = 64;
+static constexpr int kSahBigBatch = 5;
 
 static int build_sah_top(AobBake* b, uint32_t n, const uint32_t* cl, uint32_t* other, const uint32_t* state, uint32_t bound)
 {
     hipStream_t s = b->stream;
     // workspace free at this point: the level tables in refit_flags (n words), the short ranges in codes[1] (2 n words), the lists
-    // with their boxes in sah_lists (2 x bound x 28 B), counters of their own (sah_counts: [0 .. kSahMaxLevels] ranges per level,
-    // then short ranges, then the root's cut)
+    // with their boxes in sah_lists (2 x bound x 28 B), the long ranges' tables, bins and cuts in sah_big, counters of their own
+    // (sah_counts: [0 .. kSahMaxLevels] ranges per level, short ranges, the root's cut, then the long ranges per level)
     (void)other;
     const uint32_t per_level = bound / (uint32_t)(kSahSmall + 1) + 1u;
     SahRange* table[2] = { (SahRange*)b->refit_flags, (SahRange*)b->refit_flags + per_level };
     SahShort* small = (SahShort*)b->codes[1];
     uint32_t* counts = b->sah_counts;
     uint32_t* small_count = counts + kSahMaxLevels + 1, * root_k = counts + kSahMaxLevels + 2;
+    uint32_t* big_counts = counts + kSahMaxLevels + 16;
+    constexpr uint32_t kMaxBig = kSahTopClusters / kSahBig + 1;           // long ranges at one level
+    SahRange* bigtab[2] = { (SahRange*)b->sah_big, (SahRange*)b->sah_big + kMaxBig };
+    SahBigCut* cuts = (SahBigCut*)(bigtab[1] + kMaxBig);
+    SahBins* gbins = (SahBins*)(cuts + kMaxBig);
+    float* partial = (float*)(gbins + kMaxBig * kSahSlices);              // 12 floats per workgroup of k_sah_begin
     SahLists lists;
     const uint64_t cap = b->sah_list_capacity;
     lists.boxes[0] = (Box*)b->sah_lists; lists.boxes[1] = lists.boxes[0] + cap;
     lists.ids[0] = (uint32_t*)(lists.boxes[1] + cap); lists.ids[1] = lists.ids[0] + cap;
     if (bound > cap) { set_error("SAH top: %u clusters, room for %llu", bound, (unsigned long long)cap); return AOB_ERR_DEVICE; }
-    AOB_HIP(hipMemsetAsync(counts, 0, sizeof(uint32_t) * (kSahMaxLevels + 4), s));
-    hipLaunchKernelGGL(k_sah_begin, dim3(blocks_for(bound)), dim3(kBlock), 0, s, cl, state, b->node_bounds, lists, table[0], counts, small, small_count);
-    // level by level, a batch of levels between two looks at the range counts (a level without ranges is an empty launch)
+    AOB_HIP(hipMemsetAsync(counts, 0, sizeof(uint32_t) * (kSahMaxLevels + 16 + kSahBigLevels + 2), s));
+    hipLaunchKernelGGL(k_sah_begin, dim3(blocks_for(bound)), dim3(kBlock), 0, s, cl, state, b->node_bounds, lists, partial);
+    hipLaunchKernelGGL(k_sah_root, dim3(1), dim3(64), 0, s, state, partial, blocks_for(bound), bigtab[0], big_counts, table[0], counts, small, small_count);
     uint32_t* host = b->pinned + 12;
+    // the long ranges, level by level (their shorter children collect in table[0])
+    if (bound > (uint32_t)kSahBig) {
+        int level = 0;
+        for (;;) {
+            for (int k = 0; k < kSahBigBatch && level < kSahBigLevels; k++, level++) {
+                const SahRange* cur = bigtab[level & 1]; const uint32_t* cnt = big_counts + level;
+                hipLaunchKernelGGL(k_big_bins, dim3(kMaxBig * kSahSlices), dim3(kBlock), 0, s, cur, cnt, lists, gbins);
+                hipLaunchKernelGGL(k_big_cut, dim3(kMaxBig), dim3(64), 0, s, cur, cnt, gbins, cuts, n, root_k, b->child_left, b->child_right, b->parent, b->node_bounds,
+                                   b->node_height, b->depth_dev, bigtab[(level & 1) ^ 1], big_counts + level + 1, table[0], counts, small, small_count);
+                hipLaunchKernelGGL(k_big_move, dim3(kMaxBig * kSahSlices), dim3(kBlock), 0, s, cur, cnt, cuts, lists, n, b->child_left, b->child_right, b->parent,
+                                   b->node_height, b->depth_dev);
+            }
+            AOB_HIP(hipMemcpyAsync(host, big_counts + level, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            AOB_HIP(hipStreamSynchronize(s));
+            if (host[0] == 0u) break;
+            if (level >= kSahBigLevels) { set_error("the SAH top needs more than %d levels of long ranges", kSahBigLevels); return AOB_ERR_BVH_TOO_DEEP; }
+        }
+    }
+    // the others level by level, a batch of levels between two looks at the range counts (a level without ranges is an empty launch)
     int level = 0;
     for (;;) {
         for (int k = 0; k < kSahLevelBatch && level < kSahMaxLevels; k++, level++)

@@ -103,7 +103,11 @@ def supervise(commands, deadline_s, poll_s=0.2, grace_s=5.0):
         codes = [p.poll() for p in procs]
         bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
         if bad:
-            reason = f"rank {bad[0]} exited with code {codes[bad[0]]}"
+            # (a moment for the peers that die of the same cause — a closed connection — so that the report names them all)
+            time.sleep(min(0.5, poll_s * 2))
+            codes = [p.poll() for p in procs]
+            bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+            reason = "; ".join(f"rank {r} exited with code {codes[r]}" for r in bad)
             break
         if all(c == 0 for c in codes):
             break
