@@ -12,7 +12,7 @@ import importlib.util
 import os
 import sys
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # ---- enums (include/aobaker.h) ------------------------------------------------
 AOB_OK = 0
@@ -63,6 +63,7 @@ class AobOptions(C.Structure):
         ("trace_part_min", C.c_int32),
         ("trace_fine_div", C.c_int32),
         ("trace_bands", C.c_int32),
+        ("trace_scalar_min", C.c_int32),
     ]
 
 

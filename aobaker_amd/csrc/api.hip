@@ -65,6 +65,7 @@ static int validate_options(const AobOptions* o)
     if (o->bvh_width != 0 && o->bvh_width != 2 && o->bvh_width != 4) { set_error("bvh_width %d: must be 0, 2 or 4", o->bvh_width); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->trace_refill_idle < 0 || o->trace_refill_idle > 64 || o->trace_leaf_wait < 0 || o->trace_leaf_wait > 64) { set_error("trace_refill_idle %d / trace_leaf_wait %d: must be 0 (default) or 1..64", o->trace_refill_idle, o->trace_leaf_wait); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->trace_parts < 0 || o->trace_parts > 64 || o->trace_part_min < 0 || o->trace_fine_div < 0) { set_error("trace_parts %d (0..64), trace_part_min %d, trace_fine_div %d: must not be negative", o->trace_parts, o->trace_part_min, o->trace_fine_div); return AOB_ERR_INVALID_ARGUMENT; }
+    if (o->trace_scalar_min < 0 || o->trace_scalar_min > 64) { set_error("trace_scalar_min %d: must be 0 (default) or 1..64", o->trace_scalar_min); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->trace_bands < 0 || o->trace_bands > 2) { set_error("trace_bands %d: must be 0 (default), 1 or 2", o->trace_bands); return AOB_ERR_INVALID_ARGUMENT; }
     if (!(o->falloff_distance > 0.0f)) { set_error("falloff_distance must be positive"); return AOB_ERR_INVALID_ARGUMENT; }
     return AOB_OK;
@@ -167,17 +168,18 @@ void aob_default_options(AobOptions* o)
     // measured fastest on MI355X (profiles/): lane-per-ray walk of the 64-byte quantised 4-ary nodes
     o->bvh_width = 4;
     o->bvh_quantised = 1;
-    o->bvh_builder = 1;           // PLOC: +1.3 ms build, -11 % trace on the 1 M-triangle terrain
+    o->bvh_builder = 1;           // PLOC (2, the SAH top, pays from a few hundred million rays per bake on: include/aobaker.h)
     o->morton_adaptive = 1;
     o->raster_mode = AOB_RASTER_REFERENCE;
     o->raster_layers = AOB_LAYERS_LAST;
     // schedule of k_trace: the measured optima on BASELINE configs[2]
     o->trace_refill_idle = 0;     // by scoring mode: 42 where a ray is a miss counter (COSINE sampler, any hit), else 24 (trace.hip)
-    o->trace_leaf_wait = 16;
+    o->trace_leaf_wait = 0;       // by scoring mode: 24 with any-hit scoring, 16 with closest-hit scoring (trace.hip)
     o->trace_parts = 4;
     o->trace_part_min = 16;
     o->trace_fine_div = 8;
     o->trace_bands = 1;
+    o->trace_scalar_min = 24;
 }
 
 int aob_init(const AobDeviceConfig* config)

@@ -766,7 +766,7 @@ static int build_ploc(AobBake* b, uint32_t n, uint32_t stop)
 // Here: PLOC clusters the Morton-ordered triangles until at most kSahTopClusters clusters are left (a smaller scene: none at
 // all), and the tree above them is built TOP-DOWN by binned SAH — where an agglomerated tree differs most from a SAH tree
 // (1 M-triangle terrain: 14.24 instead of 15.00 node visits per ray; every triangle a cluster of its own would give 13.65,
-// profiles/r03/sah_top/).  The algorithm, stated once in oracle/aob_oracle.c (sah_top): per list range the box of the clusters'
+// profiles/r03/sah_top/).  The algorithm (DESIGN.md §3.2 states it once, for this file and for its CPU twin): per list range the box of the clusters'
 // centres, 16 bins per axis, the cheapest of the 3 x 15 planes, a STABLE partition; a node's id is the position its range was
 // cut at (unique; the root and the node cut at position 0 swap ids so that the root is node 0) — so ranges can be split in
 // any order: one workgroup per range while ranges are long, one thread per range (and all below it) once they are short.

@@ -572,10 +572,13 @@ void k_trace(TraceParams p)
             // ---- 4-ary node: four slab tests per visit, children ranked only when the order matters ----
             // buffer loads: a 32-bit byte offset off an SGPR resource (one v_lshlrev) instead of a 64-bit address per lane
             const uint32_t noff = addr << 6;
-            const uint4 c0 = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(nodes_rsrc, noff, 0, 0)),
-                        c1 = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(nodes_rsrc, noff + 16u, 0, 0)),
-                        c2 = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(nodes_rsrc, noff + 32u, 0, 0)),
-                        c3 = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(nodes_rsrc, noff + 48u, 0, 0));
+#ifndef AOB_EXP_AUX
+#define AOB_EXP_AUX 0
+#endif
+            const uint4 c0 = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(nodes_rsrc, noff, 0, AOB_EXP_AUX)),
+                        c1 = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(nodes_rsrc, noff + 16u, 0, AOB_EXP_AUX)),
+                        c2 = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(nodes_rsrc, noff + 32u, 0, AOB_EXP_AUX)),
+                        c3 = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(nodes_rsrc, noff + 48u, 0, AOB_EXP_AUX));
 #if AOB_EXP_LOAD
             for (int k = 0; k < AOB_EXP_LOAD; k++) exp_acc ^= __builtin_amdgcn_raw_buffer_load_b32(nodes_rsrc, noff + 12u + 16u * (uint32_t)k, 0, 0);
 #endif
@@ -764,8 +767,11 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
         // when 42 lanes wait for a refill (fresh rays of one sample start together and share the top of the tree: configs[2]
         // 76.2 -> 74.1 ms, configs[1] +5 %); closest-hit and weighted scoring keep 24 (configs[4] loses 4.5 % at 42)
         p.refill_idle = knob(o.trace_refill_idle, (o.sampler == AOB_SAMPLER_COSINE && o.use_any_hit) ? 42 : 24);
-        p.leaf_wait = knob(o.trace_leaf_wait, 16);
-        p.scalar_min = (uint32_t)max(8, p.refill_idle - 2);      // (slack 0 / 2 / 4 / 6 / 10: the same within 0.3 %)
+        // (the leaf section: 16 parked lanes, 24 with any-hit scoring — 12 / 16 / 20 / 24 / 28 -> 59.5 / 58.3 / 57.9 / 57.7 / 57.7 ms on
+        // BASELINE configs[2]; the scalar steps: since the vector-memory path is what binds the walk (profiles/r03/roofs/) a step pays
+        // for 24 lanes on one node — 16 / 24 / 32 / 36 / 40 -> 56.9 / 56.6 / 56.9 / 57.2 / 57.7 ms — where round 2's kernel wanted 40)
+        p.leaf_wait = knob(o.trace_leaf_wait, o.use_any_hit ? 24 : 16);
+        p.scalar_min = (uint32_t)min(knob(o.trace_scalar_min, 24), max(1, p.refill_idle));
         cosine_grid(o.sample_count, p.grid);
         // one launch per section: two sections of a material may cover the same texel, and
         // their contributions are added in section order (BakeEngine.cpp:473,659)

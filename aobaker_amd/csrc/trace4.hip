@@ -286,12 +286,6 @@ static void launch_hit4(int anyhit, int accum, dim3 grid, hipStream_t s, const T
     else launch_acc4<SAMPLER, 0>(accum, grid, s, p);
 }
 
-static int env_int4(const char* name, int fallback)
-{
-    const char* v = getenv(name);
-    return v && *v ? atoi(v) : fallback;
-}
-
 int trace4_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
 {
     DeviceMaterial& m = b->materials[material];
@@ -315,8 +309,9 @@ int trace4_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
     }
     if (!o.use_any_hit && o.clamp_tmax_to_falloff && p.falloff < p.tmax) p.tmax = p.falloff;
     p.bias = o.ray_bias;
-    p.refill_idle = max(1, env_int4("AOB_TRACE4_REFILL_IDLE", 4));
-    p.leaf_wait = max(1, env_int4("AOB_TRACE4_LEAF_WAIT", 4));
+    // (the schedule in rays: a quad of lanes walks one ray — AobOptions' thresholds are in lanes)
+    p.refill_idle = b->opt.trace_refill_idle > 0 ? max(1, b->opt.trace_refill_idle / 4) : 4;
+    p.leaf_wait = b->opt.trace_leaf_wait > 0 ? max(1, b->opt.trace_leaf_wait / 4) : 4;
     cosine_grid(o.sample_count, p.grid);
     for (size_t si = 0; si + 1 < m.section_offsets.size(); si++) {
         uint64_t sb = m.section_offsets[si] > begin ? m.section_offsets[si] : begin;

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AOB_ABI_VERSION 3
+#define AOB_ABI_VERSION 4
 
 typedef enum AobStatus {
     AOB_OK = 0,
@@ -95,7 +95,11 @@ typedef struct AobOptions {
                                      box, rounded outward (AobBvh2QNode)                            */
     int32_t  bvh_builder;         /* 0: LBVH, the reference stack's GPU builder (kernels/CL/build_hlbvh.cl);
                                      1: PLOC (locally-ordered agglomerative clustering over the same Morton
-                                     order) — same node layouts, cheaper trees, ~1.5 ms more build time   */
+                                     order) — same node layouts, cheaper trees, ~0.5 ms more build time — the default;
+                                     2: PLOC until 131 072 clusters are left, the tree above them top-down by binned SAH
+                                     (the reference stack's "sah" builder, RadeonRays/radeon_rays.h:286-294): 5 % fewer
+                                     node visits per ray on the 1 M-triangle terrain for 0.6 ms more build — worth it
+                                     from a few hundred million rays per bake on (any-hit bakes)          */
     int32_t  bleed_mode;          /* AOB_BLEED_*: how uncovered texels borrow a neighbour's value     */
     int32_t  material_ranges;     /* 1: honour AobMaterialDesc::ao_max_range; default 0 (the reference ignores it) */
     int32_t  morton_adaptive;     /* default 1: the Morton bits both builders sort by are dealt to the axes in the order a
@@ -104,17 +108,20 @@ typedef struct AobOptions {
                                      node visits per ray on the 1 M-triangle terrain                                  */
     int32_t  raster_mode;         /* AOB_RASTER_*; default REFERENCE                                  */
     int32_t  raster_layers;       /* AOB_LAYERS_*; default LAST                                       */
-    /* Schedule of the fused trace kernel (trace.hip).  These six move work between wavefronts and never change a result
+    /* Schedule of the fused trace kernel (trace.hip).  These seven move work between wavefronts and never change a result
      * cell (tests/test_gpu_parity.py::test_trace_schedule_knobs_do_not_change_results).  aob_default_options writes the
      * values measured fastest on MI355X for BASELINE configs[2]; 0 in any of them also means "that default". */
     int32_t  trace_refill_idle;   /* lanes of a wavefront without a ray that trigger the refill section: 1..64; default 0 = by
                                      scoring mode: 42 with the COSINE sampler and any-hit scoring, 24 otherwise            */
-    int32_t  trace_leaf_wait;     /* lanes parked at a leaf that trigger the leaf section: 1..64, default 16               */
+    int32_t  trace_leaf_wait;     /* lanes parked at a leaf that trigger the leaf section: 1..64; default 0 = by scoring mode:
+                                     24 with any-hit scoring, 16 with closest-hit scoring                                  */
     int32_t  trace_parts;         /* sample parts a tile's rays are cut into (units of one work queue), default 4          */
     int32_t  trace_part_min;      /* a part holds at least this many samples, default 16                                   */
     int32_t  trace_fine_div;      /* the last 1/trace_fine_div of every queue is cut into half-length units, default 8     */
     int32_t  trace_bands;         /* 1 (default): on a fully covered atlas, 8x8-tile blocks inside bands of 8 tile rows;
                                      2: plain chunks of 2048 tiles                                                          */
+    int32_t  trace_scalar_min;    /* any-hit walk of the quantised 4-ary nodes: lanes that must stand on ONE node for it to be
+                                     visited from scalar registers (after a refill): 1..64, default 24                      */
 } AobOptions;
 
 /* ---- scene description ----------------------------------------------------
