@@ -60,7 +60,9 @@ def parse_args():
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--bvh-width", type=int, default=0, help="0 = library default (4), 2 = BVH2 nodes, 4 = 4-ary nodes")
     ap.add_argument("--bvh-quantised", type=int, default=-1, help="-1 = library default (1); 1 = 15-bit quantised boxes, lane per ray; 0 = fp32 boxes")
-    ap.add_argument("--bvh-builder", type=int, default=-1, help="-1 = library default; 0 = LBVH, 1 = PLOC")
+    ap.add_argument("--bvh-builder", type=int, default=2,
+                    help="2 (the benchmark's choice: PLOC clusters under a binned-SAH top — it pays from a few hundred million rays per bake on), "
+                         "1 = PLOC (the library's default), 0 = LBVH, -1 = the library's default")
     ap.add_argument("--no-balance", action="store_true", help="N>1: keep the equal strips (no re-cut during warm-up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpp-host", action="store_true")
@@ -373,7 +375,7 @@ def main():
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"terrain {flat.triangle_count()} tris, {W}x{H} atlas, {args.spp} spp, "
-                                   f"cosine sampler, any-hit, float accumulate, {'PLOC' if opts.bvh_builder else 'LBVH'} bvh_width {opts.bvh_width or 2}"
+                                   f"cosine sampler, any-hit, float accumulate, {('LBVH', 'PLOC', 'PLOC + binned-SAH top (bvh_builder 2)')[opts.bvh_builder]} bvh_width {opts.bvh_width or 2}"
                                    f"{' quantised' if opts.bvh_quantised else ''} — "
                                    + ("BASELINE configs[2]" if world == 1 else
                                       ("BASELINE configs[3]: one fixed atlas in N strips of texel rows" if strong else "configs[2] scaled: N x 2048^2 texels")),
@@ -473,17 +475,22 @@ def roofline_record(opts, args, W, H, world, visits, my_rays, kernel_ms):
     b_ray_build = inner_bytes * n_inner + 48.0 * n_leaf + 64.0 + 8.0 / args.spp
     achieved = my_rays * b_ray / (kernel_ms * 1e-3) / 1e9
     rec, why = counter_record(opts, args, W, H, world)
-    traffic = hbm_frac = valu_frac = lane_occ = None
+    traffic = hbm_frac = None
+    roof = None
     if rec:
         traffic = rec["hbm_side_bytes_per_launch"]
         hbm_frac = round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-        valu_frac = rec.get("valu_issue_frac")
-        lane_occ = rec.get("valu_lane_occupancy")
-    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roof = rec.get("roof")
+    return {"bound": (roof or {}).get("bound", "vmem"), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "frac_note": "algorithmic node bytes / HBM peak (SURVEY §8(d)); > 1 means the fetches are cache-served — what binds is VALU "
-                         "issue (valu_issue_frac) beside the CU's vector-memory path (vmem_wave_instr_per_ray; DESIGN.md §3.1 (d))",
-            "hbm_counter_frac": hbm_frac, "valu_issue_frac": valu_frac, "valu_lane_occupancy": lane_occ,
+            "frac_note": "achieved / peak / frac: SURVEY §8(d)'s algorithmic node bytes against HBM peak — > 1 means the fetches are cache-served "
+                         "(hbm_counter_frac is what the memory-side counters saw).  HBM is not what binds k_trace: `bound` and `roof` name the "
+                         "roof that the slope measurements on this kernel point to (DESIGN.md §3.1, profiles/r03/roofs/)",
+            "hbm_counter_frac": hbm_frac,
+            # the binding roof, from the committed measurements of THIS kernel source (profiles/k_trace_counters.json): which unit,
+            # how busy the counters say it is, and what one more instruction of either kind per inner visit costs
+            "roof": roof,
+            "valu_lane_occupancy": (rec or {}).get("valu_lane_occupancy"),
             "valu_wave_instr_per_ray": (rec or {}).get("valu_wave_instr_per_ray"), "vmem_wave_instr_per_ray": (rec or {}).get("vmem_wave_instr_per_ray"),
             "counters": (rec or {}).get("provenance") or why,
             "kernel": "k_trace", "kernel_ms": round(kernel_ms, 3), "kernel_source_sha256_16": kernel_source_hash(),
@@ -560,6 +567,8 @@ def cpu_baseline(flat, opts, W, H, seconds):
         break
     visits = (st.inner_visits / max(1, st.rays), st.leaf_visits / max(1, st.rays))
     return ({"value": st.rays / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+             "compiler": "gcc -O2 -mavx2 -mfma -ffp-contract=off (oracle/Makefile: x86-64-v3 instead of -march=native because the library is built in "
+                         "one container and runs on another host; SURVEY §8(d) names -O3 -march=native)",
              "sample": f"a fixed pseudo-random 1/{one_in} of the texels of the same atlas ({len(sub)} surfels, {st.rays} rays, "
                        f"{dt:.1f} s); trace stage only, same BVH/sampler/rays as the GPU",
              "extrapolated_full_trace_s": len(surfels) * opts.sample_count / (st.rays / dt)}, visits)

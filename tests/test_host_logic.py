@@ -117,13 +117,17 @@ def test_bench_helpers_and_committed_counters():
     import bench
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     opts = capi.default_options()
+    opts.bvh_builder = 2                                           # the benchmark's builder (bench.py --bvh-builder)
     args = types.SimpleNamespace(spp=256, grid=708)
     rec, why = bench.counter_record(opts, args, 2048, 2048, 1)
     path = os.path.join(root, "profiles", "k_trace_counters.json")
     if os.path.exists(path):
         committed = json.load(open(path))
         if committed["source_sha256_16"] == bench.kernel_source_hash():
-            assert rec is not None and 1e9 < rec["hbm_side_bytes_per_launch"] < 1e12 and 0 < rec["valu_issue_frac"] <= 1.0
+            assert rec is not None and 1e9 < rec["hbm_side_bytes_per_launch"] < 1e12
+            roof = rec["roof"]                                     # the binding roof comes with the measurements that name it
+            assert roof["bound"] in ("vmem", "valu") and 0 < roof["frac"] <= 1.05
+            assert roof["marginal_cost_per_vmem_instr"]["mean"] > 0 and roof["marginal_cost_per_valu_instr"]["mean"] > 0
         else:
             assert rec is None and "kernel source" in why        # a stale record is refused, not reported
     else:

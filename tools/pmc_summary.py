@@ -29,6 +29,16 @@ def main():
                 out["vgpr_count"] = int(row["VGPR_Count"])
                 out["scratch_size"] = int(row["Scratch_Size"])
         out["launches"][os.path.relpath(path, root)] = len(dispatches)
+    # the kernel's duration in the counter passes (kernel-trace of the same runs): the clock the counters ran at = cycles / this
+    ms = []
+    for path in sorted(glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True)):
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                if kernel in row["Kernel_Name"]:
+                    ms.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6)
+    if ms:
+        out["kernel_ms"] = sum(ms) / len(ms)
+        out["kernel_ms_per_pass"] = [round(x, 3) for x in ms]
     print(json.dumps(out, indent=1))
 
 
