@@ -72,6 +72,7 @@ struct DeviceMaterial {
 
 struct AobBake {
     AobOptions opt;
+    int device = 0;                     // the HIP device every buffer of the handle lives on; entry points select it (api.hip check_bake)
     hipStream_t stream = nullptr;
     uint8_t*  arena = nullptr;          // ONE device allocation: every buffer sized at creation is a slice of it (api.hip)
     size_t    arena_bytes = 0;

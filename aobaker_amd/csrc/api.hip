@@ -4,6 +4,7 @@
 #include "aob_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -18,6 +19,9 @@ static thread_local char g_error[512] = "";
 // per host thread, like HIP's current device: a multi-GPU host runs one thread per device (aobaker_amd/host/MultiGpu.cpp)
 static thread_local bool g_initialised = false;
 static thread_local int g_device = 0;
+// the device of the most recent aob_init on ANY thread (-1: none, or shut down): what a thread that has not called aob_init
+// itself creates handles on — a host that initialises once on its main thread and bakes from a worker keeps working
+static std::atomic<int> g_process_device{-1};
 
 void set_error(const char* fmt, ...)
 {
@@ -121,6 +125,8 @@ static void free_bake(AobBake* b)
 static int check_bake(AobBake* b, int32_t material, bool need_material)
 {
     if (!b) { set_error("bake handle is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
+    // a handle lives on the device it was created on, whatever the calling thread's current device is (cheap, idempotent)
+    AOB_HIP(hipSetDevice(b->device));
     if (need_material && (material < 0 || (size_t)material >= b->materials.size())) {
         set_error("material %d out of range (%zu)", material, b->materials.size());
         return AOB_ERR_INVALID_ARGUMENT;
@@ -140,6 +146,16 @@ static int ensure_depth(AobBake* b)
 } // namespace aob
 
 using namespace aob;
+
+// cells += other's cells, word by word, as an RCCL sum-reduce of the same buffers adds them
+template <bool AS_FLOAT>
+__global__ __launch_bounds__(256)
+void k_add_results(uint32_t* __restrict__ cells, const uint32_t* __restrict__ other, uint64_t words)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= words) return;
+    cells[i] = AS_FLOAT ? __float_as_uint(__uint_as_float(cells[i]) + __uint_as_float(other[i])) : cells[i] + other[i];
+}
 
 extern "C" {
 
@@ -199,17 +215,19 @@ int aob_init(const AobDeviceConfig* config)
     }
     g_device = dev;
     g_initialised = true;
+    g_process_device.store(dev);
     return AOB_OK;
 }
 
 // aob_init acquires nothing (every stream, event and buffer belongs to an AobBake handle), so there is nothing to release
-void aob_shutdown(void) { g_initialised = false; }
+void aob_shutdown(void) { g_initialised = false; g_process_device.store(-1); }
 
 int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBake** out)
 {
     if (!out) { set_error("out is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
     *out = nullptr;
-    if (!g_initialised) { set_error("aob_init has not been called"); return AOB_ERR_NOT_INITIALISED; }
+    const int device = g_initialised ? g_device : g_process_device.load();
+    if (device < 0) { set_error("aob_init has not been called"); return AOB_ERR_NOT_INITIALISED; }
     if (!scene) { set_error("scene is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
     AOB_TRY(validate_options(options));
     if ((scene->mesh_count && !scene->meshes) || (scene->material_count && !scene->materials)) {
@@ -231,10 +249,11 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
         }
     }
 
-    AOB_HIP(hipSetDevice(g_device));
+    AOB_HIP(hipSetDevice(device));
     AobBake* b = new (std::nothrow) AobBake();
     if (!b) { set_error("out of host memory"); return AOB_ERR_OUT_OF_MEMORY; }
     b->opt = *options;
+    b->device = device;
     int rc = AOB_OK;
     auto fail = [&](int code) { free_bake(b); return code; };
 #define AOB_C(expr) do { rc = (expr); if (rc != AOB_OK) return fail(rc); } while (0)
@@ -245,7 +264,7 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
     for (auto& e : b->ev_trace) AOB_CH(hipEventCreate(&e));
     for (auto& e : b->ev_ploc) AOB_CH(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     AOB_CH(hipHostMalloc((void**)&b->pinned, 64));
-    AOB_CH(hipDeviceGetAttribute(&b->cu_count, hipDeviceAttributeMultiprocessorCount, g_device));
+    AOB_CH(hipDeviceGetAttribute(&b->cu_count, hipDeviceAttributeMultiprocessorCount, device));
     AOB_CH(hipEventRecord(b->ev[0], b->stream));
 
     // ---- plan: what every stage needs, sized once ----
@@ -394,6 +413,7 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
 void aob_bake_destroy(AobBake* bake)
 {
     if (!bake) return;
+    hipSetDevice(bake->device);
     if (bake->stream) hipStreamSynchronize(bake->stream);
     free_bake(bake);
 }
@@ -447,6 +467,20 @@ int aob_bake_clear_results(AobBake* b, int32_t material)
     AOB_TRY(check_bake(b, material, true));
     DeviceMaterial& m = b->materials[material];
     AOB_HIP(hipMemsetAsync(m.results, 0, sizeof(AobResult) * (uint64_t)m.width * m.height, b->stream));
+    return AOB_OK;
+}
+
+int aob_bake_add_results(AobBake* b, int32_t material, const void* other_cells, uint64_t cell_count)
+{
+    AOB_TRY(check_bake(b, material, true));
+    DeviceMaterial& m = b->materials[material];
+    const uint64_t cells = (uint64_t)m.width * m.height;
+    if (!other_cells || cell_count != cells) { set_error("aob_bake_add_results: %llu cells given, the material has %llu", (unsigned long long)cell_count, (unsigned long long)cells); return AOB_ERR_INVALID_ARGUMENT; }
+    const uint64_t words = 2 * cells;
+    const dim3 grid((uint32_t)((words + 255) / 256));
+    if (b->opt.accumulate == AOB_ACCUMULATE_QUANTISED) hipLaunchKernelGGL(k_add_results<false>, grid, dim3(256), 0, b->stream, (uint32_t*)m.results, (const uint32_t*)other_cells, words);
+    else hipLaunchKernelGGL(k_add_results<true>, grid, dim3(256), 0, b->stream, (uint32_t*)m.results, (const uint32_t*)other_cells, words);
+    AOB_HIP(hipGetLastError());
     return AOB_OK;
 }
 

@@ -424,9 +424,13 @@ void k_emit_nodes4q(uint32_t count4, const float4* __restrict__ nodes4, const fl
         const float4 lo = nodes4[8ull * i + j], hi = nodes4[8ull * i + 4 + j];
         uint32_t ref = __float_as_uint(lo.w);
         // an empty slot is an INVERTED box — min plane 0x7fff, max plane 0 on every axis: its near distance exceeds its far
-        // distance for every ray, so the walk needs no test of the ref (trace.hip)
-        uint4 o = make_uint4(0x8000ffffu, 0x8000ffffu, 0x8000ffffu, ref);
+        // distance for every ray, so the walk needs no test of the ref (trace.hip).  Where arithmetic cannot tell the two
+        // planes apart (a scene without extent; an extent below the rounding of the ray's distance to it) the slot may pass
+        // all the same, so its ref is one that is harmless to follow: leaf triangle 0, a triangle of the scene — testing it
+        // once more changes no ray's answer.
+        uint4 o = make_uint4(0x8000ffffu, 0x8000ffffu, 0x8000ffffu, 0x80000000u);
         if (ref != 0xffffffffu) {
+            o.w = ref;
             if (ref < 0x80000000u) o.w = packed_index[ref];
             o.x = 0x80008000u | quant_down(lo.x, frame[0], frame[3]) | quant_up(hi.x, frame[0], frame[3]) << 16;
             o.y = 0x80008000u | quant_down(lo.y, frame[1], frame[4]) | quant_up(hi.y, frame[1], frame[4]) << 16;

@@ -423,13 +423,22 @@ static int ensure_surfel_capacity(AobBake* b, DeviceMaterial& m, uint64_t need)
             return e == hipErrorOutOfMemory ? AOB_ERR_OUT_OF_MEMORY : AOB_ERR_DEVICE;
         }
     }
-    if (m.surfel_count) {
-        AOB_HIP(hipMemcpyAsync(ns, m.surfels, sizeof(AobSurfel) * m.surfel_count, hipMemcpyDeviceToDevice, b->stream));
-        AOB_HIP(hipMemcpyAsync(ni, m.section_index, sizeof(uint32_t) * m.surfel_count, hipMemcpyDeviceToDevice, b->stream));
-        AOB_HIP(hipMemcpyAsync(nf, m.frames, sizeof(float4) * 4 * m.surfel_count, hipMemcpyDeviceToDevice, b->stream));
-        AOB_HIP(hipStreamSynchronize(b->stream));
+    {
+        // the sections rasterised so far move over; the old buffers may still be read by work in flight, so the stream drains
+        // before they are released.  A failure here frees the new buffers like a failed allocation does.
+        hipError_t e = hipSuccess;
+        if (m.surfel_count) {
+            e = hipMemcpyAsync(ns, m.surfels, sizeof(AobSurfel) * m.surfel_count, hipMemcpyDeviceToDevice, b->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(ni, m.section_index, sizeof(uint32_t) * m.surfel_count, hipMemcpyDeviceToDevice, b->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(nf, m.frames, sizeof(float4) * 4 * m.surfel_count, hipMemcpyDeviceToDevice, b->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+        if (e != hipSuccess) {
+            hipFree(ns); hipFree(ni); hipFree(nf); hipFree(np);
+            set_error("moving the surfel buffers failed: %s", hipGetErrorString(e));
+            return AOB_ERR_DEVICE;
+        }
     }
-    AOB_HIP(hipStreamSynchronize(b->stream));
     release_device(b, m.surfels); release_device(b, m.section_index); release_device(b, m.frames); release_device(b, m.perm);   // (slices of the arena stay)
     m.surfels = ns; m.section_index = ni; m.frames = nf; m.perm = np; m.surfel_capacity = cap;
     return AOB_OK;

@@ -335,7 +335,10 @@ int AobMultiGpuBake::Step(AobMultiStepStats* stats)
 				if (reduce)
 				{
 					// sections of one material overlap and the list was cut by surfel count: cells of different ranks may
-					// coincide — sum them (x + 0 is exact for the cells only one rank touched)
+					// coincide — sum them (x + 0 is exact for the cells only one rank touched).  QUANTISED sums are integers:
+					// the atlas is the single-device bake's, byte for byte.  FLOAT cells are floats rounded once from each
+					// rank's exact sums, so a cell two ranks both touched is the sum of two rounded floats: equal to the
+					// single-device cell within 1 ulp per extra rank (aobaker_multi.h states it; --check-single reports it).
 					e = ncclReduce(mine, mine, cells * 2, d.opt.accumulate == AOB_ACCUMULATE_QUANTISED ? ncclInt32 : ncclFloat32, ncclSum, 0,
 					               d.comms[(size_t)r], stream);
 				}
@@ -359,8 +362,14 @@ int AobMultiGpuBake::Step(AobMultiStepStats* stats)
 			else if (n > 1 && r == 0)
 			{
 				// ranks sharing a device (rehearsal): the strips are already in this device's memory
-				if (reduce) { d.errors[0] = "overlapping sections with the REFERENCE_COMPAT sampler need one device per rank (RCCL reduce)"; return AOB_ERR_UNSUPPORTED; }
-				for (int p = 1; p < n; p++)
+				if (reduce)
+				{
+					// the sum-reduce on one device: the peers' whole cell arrays are added to rank 0's in rank order, on rank 0's
+					// stream (every rank's trace was waited for in phase 1)
+					for (int p = 1; p < n; p++)
+						if (aob_bake_add_results(d.bakes[0], (int32_t)i, d.results[(size_t)p][i], cells) != AOB_OK) { d.errors[0] = aob_last_error(); return AOB_ERR_DEVICE; }
+				}
+				else for (int p = 1; p < n; p++)
 					if (first[(size_t)p] <= last[(size_t)p])
 					{
 						const hipError_t e = hipMemcpyAsync(mine + first[(size_t)p] * sizeof(AobResult), d.results[(size_t)p][i] + first[(size_t)p] * sizeof(AobResult),

@@ -231,6 +231,9 @@ class FlatScene:
         self.desc.mesh_count = len(meshes)
         self.desc.materials = C.cast(self.material_array, C.POINTER(capi.AobMaterialDesc))
         self.desc.material_count = len(mats)
+        # `FlatScene(scene).desc` is a common way to pass a scene on: the descriptor itself keeps what it points into alive
+        # (the vertex / index arrays and, through the scene, the textures the material descriptors write to)
+        self.desc._keepalive = (self._keep, self.mesh_array, self.material_array, scene)
 
     def triangle_count(self):
         return sum(int(self.mesh_array[i].index_count) // 3 for i in range(self.desc.mesh_count))

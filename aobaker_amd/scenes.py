@@ -188,6 +188,23 @@ def sphere_scene(n=187, atlas=1024, seed=2, **kw):
     return _scene_with([sphere_mesh(n, seed)], atlas, **kw)
 
 
+def config2_scene(atlas=1024, seed=2, bpc=4):
+    """BASELINE configs[1]'s mesh: returns (scene, mesh name).  The Stanford bunny is not in the image (no network), so the
+    stand-in is the 69 938-triangle displaced sphere; AOB_CFG2_OBJ=/path/to/mesh.obj bakes that file instead (imported as
+    BakeObject::LoadFromFile imports it, assets.load_obj, every material on an atlas x atlas texture) — for whoever has the
+    bunny, or any UV-mapped mesh of that size.  The name goes into the records made from the scene."""
+    import os
+    path = os.environ.get("AOB_CFG2_OBJ")
+    if not path:
+        return sphere_scene(n=187, atlas=atlas, seed=seed, bpc=bpc), "displaced sphere n=187 (bunny stand-in)"
+    from .assets import load_obj
+    sc = Scene()
+    load_obj(path, sc, atlas=(atlas, atlas), channelCount=1, bytesPerChannel=bpc)
+    if sc.GetMaterialCount() == 0:
+        raise ValueError(f"AOB_CFG2_OBJ={path}: the file has no faces")
+    return sc, os.path.basename(path)
+
+
 def two_section_scene(atlas=32, **kw):
     """Two sections of ONE material whose charts overlap in UV space: the reference bakes each
     section separately and both accumulate into the same result cells (BakeEngine.cpp:473,659)."""

@@ -241,8 +241,9 @@ typedef struct AobBvh2QNode { uint32_t w[8]; } AobBvh2QNode;
 typedef struct AobQuantFrame { float origin[3]; float scale[3]; } AobQuantFrame;
 /* 64 B 4-ary node with quantised child boxes (same grid and rounding as AobBvh2QNode): child j is
  * w[4j..4j+2] = x, y, z words and w[4j+3] = ref_j (as in AobBvh4Node); an empty slot has
- * ref = AOB_INVALID_ADDR and the words 0x8000ffff — an inverted box (min plane 0x7fff, max plane 0) that no ray enters, so the
- * walk does not test the ref.  A word is (0x8000 | min) | (0x8000 | max) << 16: bit 15 of each
+ * the words 0x8000ffff — an inverted box (min plane 0x7fff, max plane 0) that no ray enters, so the walk does not test the
+ * ref — and ref = AOB_LEAF_FLAG | 0: should rounding ever let such a box pass (a scene without extent), the walk tests
+ * triangle 0 once more, which changes no answer.  A word is (0x8000 | min) | (0x8000 | max) << 16: bit 15 of each
  * half is set so that the bytes {0x3f, half>>8, half&0xff, 0x00} are the IEEE float 1 + q/32768 — one
  * v_perm_b32 per plane in the traversal; decode q = half & 0x7fff.  The array is packed (no records for the
  * collapsed-away levels): inner refs index this array, not AobBvh4Node[].  Walked one lane per ray
@@ -259,11 +260,14 @@ typedef struct AobResult { uint32_t total_bits, weight_bits; } AobResult;
 
 /* Replaces BakeEngine::Init (BakeEngine.cpp:118-213): checks that the device is a gfx950 and makes it the device every
  * later aob_bake_create of the calling THREAD allocates on (one host thread per GPU: each thread calls aob_init with
- * its own device).  It acquires nothing: streams, events and buffers belong to the AobBake handles (the reference's
+ * its own device); a thread that never called aob_init creates its handles on the device of the most recent aob_init of
+ * any thread.  A handle stays on the device it was created on: every aob_bake_* entry point selects that device for the
+ * calling thread (hipSetDevice), so a handle may be driven from any thread — one call at a time.  It acquires nothing: streams, events and buffers belong to the AobBake handles (the reference's
  * Init allocates ~3 GB of fixed buffers here, BakeEngine.cpp:163-212; this library sizes them per scene). */
 int aob_init(const AobDeviceConfig* config);
 /* Replaces BakeEngine::Dispose (BakeEngine.cpp:215-279).  Since aob_init acquires nothing there is nothing to release
- * beyond the calling thread's device selection; handles still alive stay valid until aob_bake_destroy. */
+ * beyond the device selection (the calling thread's, and the process-wide one threads without their own fall back to);
+ * handles still alive stay valid until aob_bake_destroy. */
 void aob_shutdown(void);
 /* Fills `out` with the reference's constants (BakeEngine.cpp:13-18). */
 void aob_default_options(AobOptions* out);
@@ -347,6 +351,11 @@ int aob_bake_shard_bounds(AobBake* bake, int32_t material, uint32_t parts, uint6
  * collective issued by the caller) and of its resolved image. */
 int aob_bake_results_device_ptr(AobBake* bake, int32_t material, void** ptr, uint64_t* bytes);
 int aob_bake_image_device_ptr(AobBake* bake, int32_t material, void** ptr, uint64_t* bytes);
+/* cells += other_cells (cell_count = W*H AobResult records in the SAME device's memory, e.g. another handle's buffer from
+ * aob_bake_results_device_ptr), enqueued on the bake's stream: int32 sums in QUANTISED mode, float sums in FLOAT mode —
+ * what ncclReduce(ncclSum) does between devices, for hosts whose ranks share one device (aobaker_multi.h rehearsals).
+ * QUANTISED sums are exact; FLOAT sums of cells that two parts both touched are the sum of two rounded floats. */
+int aob_bake_add_results(AobBake* bake, int32_t material, const void* other_cells, uint64_t cell_count);
 /* The HIP stream the stages are enqueued on (a hipStream_t as void*). */
 int aob_bake_stream(AobBake* bake, void** stream);
 /* Timing of the most recent aob_bake_trace launch, measured with HIP events

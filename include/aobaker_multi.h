@@ -38,7 +38,11 @@ public:
 	// strip, gather to device 0, resolve + bleed there.  Strips: tile-row (8 texel) aligned windows of texel rows for the
 	// COSINE sampler; for REFERENCE_COMPAT (whose hemisphere-table index is a surfel's number in its section's list,
 	// BakeEngine.cpp:598-628) every device rasterises the whole atlas and traces an equal range of the surfel list
-	// (aob_bake_shard_bounds), so that N devices write exactly the cells one device would.
+	// (aob_bake_shard_bounds), so that N devices write exactly the cells one device would.  Where sections of one material
+	// overlap in the atlas, ranges of different devices may share cells; those are summed on device 0 (ncclReduce, or
+	// aob_bake_add_results between ranks that share a device): exact in QUANTISED mode — the atlas is the single-device
+	// bake's byte for byte — and, in FLOAT mode, the sum of each device's once-rounded float, i.e. within 1 ulp per extra
+	// device of the single-device cell (well inside the 1e-4 AO tolerance), for the shared cells only.
 	int Step(AobMultiStepStats* stats = nullptr);
 	// Device 0's resolved images -> the AobMaterialDesc::data pointers given at creation (BakeEngine.cpp:705-709).
 	int Download();

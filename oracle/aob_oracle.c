@@ -378,7 +378,8 @@ static inline int lbvh_delta(const MortonKey* keys, int64_t n, int64_t i1, int64
     if (left < 0 || right >= n) return -1;
     uint64_t lc = keys[left].code, rc = keys[right].code;
     if (lc != rc) return __builtin_clzll(lc ^ rc);
-    return 64 + __builtin_clz((uint32_t)left ^ (uint32_t)right);
+    const uint32_t x = (uint32_t)left ^ (uint32_t)right;
+    return 64 + (x ? __builtin_clz(x) : 32);          /* OpenCL's clz(0) is 32 (i1 == i2: the search probes its own position) */
 }
 
 typedef struct { float pmin[3], pmax[3]; } Box;
@@ -1097,9 +1098,12 @@ uint64_t orc_bvh4q_build(const AobBvh4Node* nodes4, uint64_t count4, const AobQu
             const float* lo = nodes4[i].lo[j]; const float* hi = nodes4[i].hi[j];
             uint32_t ref; memcpy(&ref, &lo[3], 4);
             uint32_t* w = &o->w[4 * j];
-            w[0] = w[1] = w[2] = 0x8000ffffu; w[3] = ref;       /* an empty slot: the inverted box (min plane 0x7fff, max plane 0) no ray enters */
+            /* an empty slot: the inverted box (min plane 0x7fff, max plane 0) no ray enters — and, for the scenes whose planes
+             * arithmetic cannot tell apart (no extent at all, or less than the rounding of a ray's distance to it), a ref that
+             * is harmless to follow: leaf triangle 0 (one more test of a triangle of the scene changes no answer) */
+            w[0] = w[1] = w[2] = 0x8000ffffu; w[3] = AOB_LEAF_FLAG;
             if (ref == AOB_INVALID_ADDR) continue;
-            if (!(ref & AOB_LEAF_FLAG)) w[3] = packed[ref];
+            w[3] = (ref & AOB_LEAF_FLAG) ? ref : packed[ref];
             for (int k = 0; k < 3; k++)
                 w[k] = 0x80008000u | quant_down(lo[k], fr->origin[k], fr->scale[k]) | quant_up(hi[k], fr->origin[k], fr->scale[k]) << 16;
         }
@@ -1167,8 +1171,7 @@ static inline int traverse4q(const AobBvh4QNode* nq, uint64_t count4, const AobQ
                 if (any_hit) t0 = t0 != t0 ? 0.0f : fminf(fmaxf(t0, 0.0f), 1.0f);
                 else { t0 = fmaxf(t0, 0.0f); t1 = fminf(t1, closest_t); }
                 ref[j] = c[3];
-                chit[j] = t0 <= t1;                      /* an empty slot's inverted box fails this by itself */
-                if (chit[j] && ref[j] == AOB_INVALID_ADDR) { *error = AOB_ERR_INVALID_ARGUMENT; *t_out = t_max; return 0; }   /* (never: asserted) */
+                chit[j] = t0 <= t1;                      /* an empty slot's inverted box fails this by itself (or leads to triangle 0) */
                 key[j] = chit[j] ? t0 : INFINITY;
                 nhit += chit[j];
             }
@@ -1669,6 +1672,57 @@ void orc_occluded_rays(const AobBvhNode* nodes, uint64_t node_count, const OrcRa
         int hit = traverse(nodes, node_count, f3_make(r->o[0], r->o[1], r->o[2]), f3_make(r->d[0], r->d[1], r->d[2]),
                            r->o[3], 1, &t, &st, &error, NULL);
         hits[i] = hit ? 1 : -1;
+    }
+}
+
+/* The deferred-entry count the reference's walk reaches for every active ray (closest hit, or any hit): the kernel keeps
+ * 15 entries + the sentinel per work item in LDS and, when a 16th is pushed, moves the 15 to its global stack
+ * (intersect_bvh2_lds.cl:144-153; brought back at :186-196), whose STACK_SIZE 32 words per ray hold two such moves —
+ * so a ray of depth >= 16 exercises the spill and one of depth > 45 would overrun the reference's own stack.  The walk
+ * is traverse()'s; only the high-water mark is kept.  Inactive rays get 0. */
+void orc_reference_stack_depths(const AobBvhNode* nodes, uint64_t node_count, const OrcRay* rays, uint64_t n, int32_t any_hit,
+                                uint32_t* depth_out)
+{
+    for (uint64_t i = 0; i < n; i++) {
+        const OrcRay* r = &rays[i];
+        depth_out[i] = 0;
+        if (r->extra[1] == 0 || node_count == 0) continue;
+        const f3 o = f3_make(r->o[0], r->o[1], r->o[2]), d = f3_make(r->d[0], r->d[1], r->d[2]);
+        const f3 invdir = safe_invdir(d);
+        const f3 oxinvdir = f3_make(-o.x * invdir.x, -o.y * invdir.y, -o.z * invdir.z);
+        float closest_t = r->o[3];
+        uint32_t stack[ORC_STACK];
+        int sp = 0, high = 0;
+        stack[sp++] = AOB_INVALID_ADDR;
+        uint32_t addr = 0;
+        while (addr != AOB_INVALID_ADDR) {
+            const AobBvhNode* nd = &nodes[addr];
+            if (nd->addr_left != AOB_INVALID_ADDR) {
+                float s0x, s0y, s1x, s1y;
+                intersect_bbox(nd->lmin_or_v0, nd->lmax_or_v1, invdir, oxinvdir, closest_t, &s0x, &s0y);
+                intersect_bbox(nd->rmin_or_v2, nd->rmax, invdir, oxinvdir, closest_t, &s1x, &s1y);
+                const int c0 = s0x <= s0y, c1 = s1x <= s1y;
+                const int c1first = c1 && (s0x > s1x);
+                if (c0 || c1) {
+                    uint32_t deferred;
+                    if (c1first || !c0) { addr = nd->addr_right; deferred = nd->addr_left; }
+                    else { addr = nd->addr_left; deferred = nd->addr_right; }
+                    if (c0 && c1) {
+                        if (sp >= ORC_STACK) break;
+                        stack[sp++] = deferred;
+                        if (sp - 1 > high) high = sp - 1;
+                    }
+                    continue;
+                }
+            } else {
+                const float t = intersect_triangle(o, d, f3_make(nd->lmin_or_v0[0], nd->lmin_or_v0[1], nd->lmin_or_v0[2]),
+                                                   f3_make(nd->lmax_or_v1[0], nd->lmax_or_v1[1], nd->lmax_or_v1[2]),
+                                                   f3_make(nd->rmin_or_v2[0], nd->rmin_or_v2[1], nd->rmin_or_v2[2]), closest_t);
+                if (t < closest_t) { closest_t = t; if (any_hit) break; }
+            }
+            addr = stack[--sp];
+        }
+        depth_out[i] = (uint32_t)high;
     }
 }
 

@@ -159,6 +159,9 @@ uint64_t orc_generate_rays(const AobSurfel* surfels, const uint32_t* section_ind
 void orc_intersect_rays(const AobBvhNode* nodes, uint64_t node_count, const OrcRay* rays, uint64_t n, int32_t use_mask,
                         OrcIntersection* hits);
 void orc_occluded_rays(const AobBvhNode* nodes, uint64_t node_count, const OrcRay* rays, uint64_t n, int32_t* hits);
+/* high-water mark of deferred entries per ray in that walk (>= 16: the kernel's LDS stack spilt, :144-153) */
+void orc_reference_stack_depths(const AobBvhNode* nodes, uint64_t node_count, const OrcRay* rays, uint64_t n, int32_t any_hit,
+                                uint32_t* depth_out);
 /* ProcessIntersectionsComputeShader.hlsl:52-92 from Intersection records (accumulates into results like orc_trace). */
 void orc_process_intersections(const AobSurfel* surfels, uint64_t begin, uint64_t end, const OrcRay* rays,
                                const OrcIntersection* hits, const AobOptions* opt, float falloff,

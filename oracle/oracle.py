@@ -35,7 +35,8 @@ def load():
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = os.path.join(_HERE, "liboracle.so")
+    # AOB_ORACLE_LIBRARY: another build of the same source (the sanitizer build, tests/test_oracle_sanitizers.py)
+    path = os.environ.get("AOB_ORACLE_LIBRARY") or os.path.join(_HERE, "liboracle.so")
     if not os.path.exists(path):
         build()
     lib = C.CDLL(path)
@@ -72,6 +73,7 @@ def load():
         "orc_generate_rays": (u64, [vp, vp, u64, u64, P(capi.AobOptions), vp, i32, f32, i32, vp]),
         "orc_intersect_rays": (None, [vp, u64, vp, u64, i32, vp]),
         "orc_occluded_rays": (None, [vp, u64, vp, u64, vp]),
+        "orc_reference_stack_depths": (None, [vp, u64, vp, u64, i32, vp]),
         "orc_process_intersections": (None, [vp, u64, u64, vp, vp, P(capi.AobOptions), f32, i32, i32, vp]),
         "orc_morton_codes": (None, [vp, u64, C.c_int, vp, vp, vp]),
         "orc_two_level_intersect": (C.c_int, [vp, u64, vp, vp, vp, vp, u64, i32, vp, P(OrcTraceStats), P(OrcTraceStats)]),
@@ -332,6 +334,14 @@ def occluded_rays(nodes, rays, fill=None):
     hits = np.zeros(max(1, len(rays)), dtype=np.int32) if fill is None else fill.copy()
     load().orc_occluded_rays(nodes.ctypes.data if len(nodes) else None, len(nodes), rays.ctypes.data, len(rays), hits.ctypes.data)
     return hits[:len(rays)]
+
+
+def reference_stack_depths(nodes, rays, any_hit=False):
+    """Deferred entries each ray holds at most in the reference's walk (>= 16 spills its LDS stack, intersect_bvh2_lds.cl:144-153)."""
+    nodes, rays = np.ascontiguousarray(nodes), np.ascontiguousarray(rays)
+    out = np.zeros(max(1, len(rays)), dtype=np.uint32)
+    load().orc_reference_stack_depths(nodes.ctypes.data if len(nodes) else None, len(nodes), rays.ctypes.data, len(rays), int(bool(any_hit)), out.ctypes.data)
+    return out[:len(rays)]
 
 
 def process_intersections(surfels, rays, hits, opt, width, height, falloff=None, results=None):

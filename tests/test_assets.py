@@ -190,3 +190,20 @@ def test_obj_import_tolerates_real_world_files(tool, tmp_path):
     assert subprocess.run([tool, "obj2aobs", str(tmp_path / "nope.obj"), str(out), "8", "8", "1", "1"], capture_output=True).returncode == 1
     with pytest.raises(FileNotFoundError):
         assets.load_obj(str(tmp_path / "nope.obj"), Scene())
+
+
+def test_config2_scene_honours_the_obj_override(tmp_path, monkeypatch):
+    """scenes.config2_scene: the bunny stand-in by default; AOB_CFG2_OBJ=/path/to.obj bakes that mesh instead and names it
+    (tests/test_gpu_fullsize.py::test_config2_complete_bake and tools/run_shapes.py cfg2 both go through it)."""
+    from aobaker_amd import scenes
+    from aobaker_amd.scene import FlatScene
+    monkeypatch.delenv("AOB_CFG2_OBJ", raising=False)
+    sc, name = scenes.config2_scene(atlas=64, bpc=4)
+    assert "stand-in" in name and FlatScene(sc).triangle_count() == 69938
+    path = tmp_path / "quad.obj"
+    path.write_text("v 0 0 0\nv 1 0 0\nv 1 0 1\nv 0 0 1\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nf 1/1 2/2 3/3 4/4\n")
+    monkeypatch.setenv("AOB_CFG2_OBJ", str(path))
+    sc, name = scenes.config2_scene(atlas=64, bpc=4)
+    assert name == "quad.obj" and FlatScene(sc).triangle_count() == 2
+    tex = sc.GetMaterial(0).GetAOTexture()
+    assert (tex.GetWidth(), tex.GetHeight(), tex.GetBytesPerChannel()) == (64, 64, 4)

@@ -102,6 +102,7 @@ def run_mgpu(args, timeout=900):
     ("0,0,0", 1, "terrain"),             # three ranks on the one device: strips of rows, cost re-cuts, gather, resolve on rank 0
     ("0,0,0,0,0,0,0,0", 1, "two_section"),   # eight ranks, overlapping sections of one material, some strips empty
     ("0,0", 0, "cube"),                  # the reference's own sampler: the surfel list is sharded, not the rows
+    ("0,0,0", 0, "two_section"),         # ... with overlapping sections: ranges of different ranks share cells, summed on rank 0
 ])
 def test_cpp_multi_gpu_host_matches_single_device(engine, tmp_path, devices, sampler, scene_name):
     """aobaker_amd/host/MultiGpu.cpp through tools/aobake_mgpu: N ranks (threads) bake strips, rank 0 gathers and resolves;
@@ -170,3 +171,24 @@ def test_config5_instanced_scene_at_size(engine, orc):
     assert 0.2 < ao.mean() < 0.9 and rst.hits > 0
     print(f"configs[4] on one GPU at 64 spp: depth {st.bvh_depth}, {n} surfels, trace {ms:.1f} ms, {n * 64 / ms / 1e6:.2f} Grays/s, "
           f"oracle visits/ray inner {rst.inner_visits / rst.rays:.2f} leaf {rst.leaf_visits / rst.rays:.2f}")
+    del got
+    # ... and the configuration's own sample count: all 1024 spp of every texel (~6 x 10^10 closest-hit rays, one GPU), the
+    # oracle on a pseudo-random 1/32768 of the texels with all 1024 rays each
+    opt_full = cosine_options(orc, 1024, use_any_hit=0, falloff_distance=1.25, clamp_tmax_to_falloff=1, seed=5)
+    with Baker(flat, opt_full) as b:
+        b.build_bvh(); b.rasterize(0)
+        assert b.surfel_count(0) == n
+        b.trace(0)
+        full = b.results(0)
+        ms_full = b.last_trace_ms()
+    keep = pseudo_random_subset(surfels, 32768)
+    sub = np.ascontiguousarray(surfels[keep])
+    assert 1000 < len(sub) < 3000
+    ref, _ = orc.trace(ref_nodes, sub, None, opt_full, 8192, 8192, threads=CORES)
+    cells = sub["texel_y"].astype(np.int64) * 8192 + sub["texel_x"]
+    assert np.array_equal(full["total_bits"][cells], ref["total_bits"][cells])
+    assert np.array_equal(full["weight_bits"][cells], ref["weight_bits"][cells])
+    all_cells = surfels["texel_y"].astype(np.int64) * 8192 + surfels["texel_x"]
+    w = full["weight_bits"].view(np.float32)[all_cells]
+    assert ((w == 1024.0) | (w == 0.0)).all() and (w == 1024.0).mean() > 0.999     # unit weights: a texel with a tangent frame cast its 1024 rays
+    print(f"configs[4] on one GPU at its 1024 spp: trace {ms_full:.0f} ms, {n * 1024 / ms_full / 1e6:.2f} Grays/s")

@@ -65,15 +65,29 @@ def random_options(rng):
         o.trace_refill_idle = int(rng.choice([0, 1, 7, 24, 42, 64])); o.trace_leaf_wait = int(rng.choice([0, 1, 5, 16, 40, 64]))
         o.trace_parts = int(rng.choice([0, 1, 3, 8])); o.trace_part_min = int(rng.choice([0, 1, 4, 16])); o.trace_fine_div = int(rng.choice([0, 1, 3, 8]))
         o.trace_bands = int(rng.integers(0, 3))
+        o.trace_scalar_min = int(rng.choice([0, 1, 8, 24, 64]))
     return o
 
 
-def bake_and_compare(engine, orc, seeds):
+def flattened_scene(rng, bpc, axes):
+    """random_scene with every object squashed onto the origin along `axes` (scale 0, no rotation, no offset there): a scene
+    box without extent on those axes — a quantisation frame whose scale is 0 there, and with all three a scene that is one
+    point (every triangle degenerate, every empty child slot indistinguishable from a box: bvh_build.hip k_emit_nodes4q)."""
+    sc = random_scene(rng, bpc)
+    for obj in sc.BakeObjects:
+        obj.Rotation = np.zeros(3, dtype=np.float32)
+        for a in axes:
+            obj.Scale[a] = 0.0
+            obj.Position[a] = 0.0
+    return sc
+
+
+def bake_and_compare(engine, orc, seeds, make_scene=random_scene):
     for seed in seeds:
         rng = np.random.default_rng(seed)
         o = random_options(rng)
         bpc = 1 if o.accumulate == capi.ACCUMULATE_QUANTISED else 4
-        gpu_scene, cpu_scene = random_scene(np.random.default_rng(seed), bpc), random_scene(np.random.default_rng(seed), bpc)
+        gpu_scene, cpu_scene = make_scene(np.random.default_rng(seed), bpc), make_scene(np.random.default_rng(seed), bpc)
         engine.Options = o
         engine.Bake(gpu_scene)
         orc.bake(FlatScene(cpu_scene).desc, o, threads=8)
@@ -85,6 +99,12 @@ def bake_and_compare(engine, orc, seeds):
 @pytest.mark.parametrize("block", range(8))
 def test_random_scenes_and_options(engine, orc, block):
     bake_and_compare(engine, orc, range(1000 + 50 * block, 1000 + 50 * (block + 1)))
+
+
+@pytest.mark.parametrize("axes", [(1,), (0, 2), (0, 1, 2)])
+def test_random_scenes_without_extent(engine, orc, axes):
+    """Flat, line-like and point-like scenes (the scene box has no extent on one, two or all three axes), random options."""
+    bake_and_compare(engine, orc, range(3000, 3040), lambda rng, bpc: flattened_scene(rng, bpc, axes))
 
 
 if __name__ == "__main__":

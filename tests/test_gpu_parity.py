@@ -81,11 +81,13 @@ def test_bvh4_nodes_bit_exact(engine, orc, name):
     refs = w[:, :, 3]
     refs4 = got4["lo"][:, :, 3].view(np.uint32)
     inner = (refs4 != capi.INVALID_ADDR) & (refs4 < 0x80000000)
-    assert np.array_equal(refs[inner], packed[refs4[inner]]) and np.array_equal(refs[~inner], refs4[~inner])
+    used = refs4 != capi.INVALID_ADDR
+    leaf = used & ~inner
+    assert np.array_equal(refs[inner], packed[refs4[inner]]) and np.array_equal(refs[leaf], refs4[leaf])
     # a plane is stored as 0x8000 | q (the bytes of the float 1 + q/32768); the decoded boxes contain the fp32 boxes
-    used = refs != capi.INVALID_ADDR
     assert ((w[:, :, :3][used] & 0x80008000) == 0x80008000).all()
-    assert (w[:, :, :3][~used] == 0x8000ffff).all()          # empty slots: the inverted box no ray enters
+    assert (w[:, :, :3][~used] == 0x8000ffff).all()          # empty slots: the inverted box no ray enters ...
+    assert (refs[~used] == 0x80000000).all()                 # ... and a ref that is harmless to follow (leaf triangle 0)
     f64 = frame.astype(np.float64)
     lo = (f64[:3] + (w[:, :, :3] & 0x7fff).astype(np.float64) * f64[3:]).astype(np.float32)
     hi = (f64[:3] + ((w[:, :, :3] >> 16) & 0x7fff).astype(np.float64) * f64[3:]).astype(np.float32)
@@ -446,6 +448,40 @@ def test_hostile_coordinates(engine, orc, bad, structure):
     assert np.array_equal(gpu.GetMaterial(0).GetAOTexture().GetData(), cpu.GetMaterial(0).GetAOTexture().GetData())
 
 
+@pytest.mark.parametrize("structure", [(4, 1, 2), (4, 1, 1), (2, 1, 1), (2, 0, 0), (4, 0, 1)])
+@pytest.mark.parametrize("shape", ["point", "line", "flat_no_bias", "flat_stack"])
+@pytest.mark.parametrize("mode", [0, 2, 3])
+def test_scenes_without_extent(engine, orc, mode, shape, structure):
+    """Scene boxes with no extent: every vertex at one point (all triangles degenerate, the quantisation frame's scale 0 on
+    all three axes — the empty child slots of the quantised 4-ary nodes cannot be told from boxes and lead to leaf triangle
+    0, bvh_build.hip k_emit_nodes4q), on one line, in one plane with ray_bias 0, and two coincident planes that do occlude
+    each other's rays at bias 0.  Texel charts and normals are those of a quad, so rays ARE cast; the walk ends and the
+    texture is the oracle's."""
+    from aobaker_amd.scene import BakeObject, MaterialObject, RenderMesh, Scene, Section, make_vertices
+    uv = np.float32([[0.05, 0.05], [0.95, 0.05], [0.95, 0.95], [0.05, 0.95]])
+    nrm = np.tile(np.float32([0, 1, 0]), (4, 1))
+    quad = np.float32([[0, 0, 0], [1, 0, 0], [1, 0, 1], [0, 0, 1]])
+    p = {"point": np.tile(np.float32([0.3, 0.4, 0.5]), (4, 1)),
+         "line": quad * np.float32([1, 0, 0]) + np.float32([0, 0.25, 0.5]),
+         "flat_no_bias": quad + np.float32([0, 0.125, 0]),
+         "flat_stack": quad}[shape]
+    idx = np.uint32([0, 1, 2, 0, 2, 3] * (3 if shape == "flat_stack" else 1))
+
+    def mk(bpc):
+        sc = Scene(); m = sc.AddMaterial(MaterialObject("A", 24, 24, 1, bpc))
+        o = sc.AddObject(BakeObject("O")); o.AddSection(Section("s", RenderMesh(make_vertices(p, nrm, uv), idx), m))
+        return sc
+    opt = make_options(orc, sample_count=16, ray_bias=0.0, **MODES[mode])
+    opt.bvh_width, opt.bvh_quantised, opt.bvh_builder = structure
+    bpc = 1 if opt.accumulate == capi.ACCUMULATE_QUANTISED else 4
+    gpu, cpu = mk(bpc), mk(bpc)
+    engine.Options = opt
+    engine.Bake(gpu)
+    st = orc.bake(FlatScene(cpu).desc, opt, threads=4)
+    assert st.rays > 0 and engine.LastStats.ray_count == st.rays
+    assert np.array_equal(gpu.GetMaterial(0).GetAOTexture().GetData(), cpu.GetMaterial(0).GetAOTexture().GetData())
+
+
 @pytest.mark.parametrize("spp", [128, 200])
 @pytest.mark.parametrize("mode", [0, 2, 4])
 def test_fine_units_at_the_end_of_the_queues(engine, orc, mode, spp):
@@ -495,6 +531,32 @@ def test_invalid_arguments_are_reported(engine, orc):
             b.trace(0)                      # BVH not built yet
         with pytest.raises(capi.AobError):
             b.rasterize(3)                  # no such material
+
+
+def test_handles_work_from_threads_that_never_called_init(engine, orc):
+    """aob_init on the main thread, aob_bake_create and every stage from a worker thread: the worker creates its handle on
+    the process's device (the most recent aob_init of any thread), and a handle made on one thread is driven from another —
+    each entry point selects the handle's device itself (api.hip check_bake).  Same cells as the main thread's bake."""
+    import threading
+    flat = FlatScene(SCENES["sphere"]())
+    opt = make_options(orc, sample_count=16, **MODES[2])
+    with Baker(flat, opt) as main_handle:
+        main_handle.build_bvh(); main_handle.rasterize(0); main_handle.trace(0)
+        want = main_handle.results(0).copy()
+        out = {}
+
+        def worker():
+            try:
+                with Baker(flat, opt) as b:                  # created on a thread without an aob_init of its own
+                    b.build_bvh(); b.rasterize(0); b.trace(0)
+                    out["own"] = b.results(0).copy()
+                main_handle.clear_results(0); main_handle.trace(0)      # a handle of another thread
+                out["foreign"] = main_handle.results(0).copy()
+            except Exception as e:                           # noqa: BLE001 - reported by the assert below
+                out["error"] = repr(e)
+        t = threading.Thread(target=worker); t.start(); t.join()
+    assert "error" not in out, out.get("error")
+    assert bits(out["own"]).tobytes() == bits(want).tobytes() and bits(out["foreign"]).tobytes() == bits(want).tobytes()
 
 
 @pytest.mark.parametrize("name,parts", [("terrain", 3), ("cube", 2), ("sphere", 5), ("two_section", 2)])

@@ -58,11 +58,12 @@ def filled(dtype, n, byte=0x5A):
     return np.frombuffer(bytes([byte]) * (dtype.itemsize * max(1, n)), dtype=dtype).copy()
 
 
-@pytest.mark.parametrize("builder", [0, 1])
+@pytest.mark.parametrize("builder", [0, 1, 2])
 @pytest.mark.parametrize("name", ["cube", "cube_inward", "sphere", "terrain", "floor_wall"])
 def test_reference_kernels_intersect_main_matches_oracle(engine, orc, name, builder):
-    """intersect_main (exact-division build) on the library's node array: shape id, primitive id, barycentrics and t of
-    every ray equal the oracle's traverse() — bit for bit."""
+    """intersect_main (exact-division build) on the library's node array — the reference's LBVH (0), PLOC (1) and PLOC
+    under the binned-SAH top (2, what bench.py bakes with): shape id, primitive id, barycentrics and t of every ray equal
+    the oracle's traverse() — bit for bit."""
     flat = FlatScene(SCENES[name]())
     opts = make_options(orc, sample_count=16, sampler=capi.SAMPLER_COSINE, seed=5, bvh_builder=builder, bvh_width=2, bvh_quantised=0)
     nodes, surfels = library_tree_and_surfels(flat, opts)
@@ -138,6 +139,67 @@ def test_reference_kernels_cells_match_the_library(engine, orc, name, mode):
     assert bits(cells["bvh4_quantised"]).tobytes() == bits(want).tobytes()
 
 
+def _large_terrain():
+    return scenes.terrain_scene(grid=230, atlas=128, seed=4)          # 2 * 229^2 = 104 882 triangles
+
+
+@pytest.mark.parametrize("builder", [0, 2])
+def test_reference_kernels_on_a_100k_triangle_tree(engine, orc, builder):
+    """The same two checks where the tree is no toy: 104 882 triangles (the build's kernels run hundreds of workgroups,
+    builder 2's top is cut by the multi-workgroup and the one-workgroup kernels), 4 rays per texel of a 128^2 atlas.
+    intersect_main on the library's nodes == the oracle's walk of the oracle's own tree, record for record; and the cells
+    scored from the reference kernel's records == the cells k_trace accumulates on the quantised 4-ary form of that tree."""
+    flat = FlatScene(_large_terrain())
+    m = flat.material_array[0]
+    kw = dict(sample_count=4, sampler=capi.SAMPLER_COSINE, seed=8, bvh_builder=builder, use_any_hit=0, falloff_distance=0.3,
+              accumulate=capi.ACCUMULATE_FLOAT)
+    opts2 = make_options(orc, bvh_width=2, bvh_quantised=0, **kw)
+    nodes, surfels = library_tree_and_surfels(flat, opts2)
+    tris = orc.scene_triangles(flat.desc)
+    assert len(tris) >= 100_000
+    ref_nodes, _ = orc.bvh_build(tris, builder, 1)
+    assert bits(nodes).tobytes() == bits(ref_nodes).tobytes()
+    rays = orc.generate_rays(surfels, None, opts2, m.width)
+    fill = filled(orc.INTERSECTION, len(rays))
+    with rk.Module("intersect_bvh2_lds_exact.co") as mod:
+        got = rk.intersect(mod, nodes, rays, fill)
+    want = orc.intersect_rays(ref_nodes, rays, fill=fill)
+    assert (want["shape_id"] != -1).mean() > 0.05
+    assert np.array_equal(got["shape_id"], want["shape_id"]) and np.array_equal(got["prim_id"], want["prim_id"])
+    assert bits(got["uvwt"]).tobytes() == bits(want["uvwt"]).tobytes()
+    cells = orc.process_intersections(surfels, rays, got, opts2, m.width, m.height)
+    with Baker(flat, make_options(orc, bvh_width=4, bvh_quantised=1, **kw)) as b:
+        b.build_bvh(); b.rasterize(0); b.trace(0)
+        lib_cells = b.results(0)
+    assert bits(lib_cells).tobytes() == bits(cells).tobytes()
+
+
+@pytest.mark.parametrize("builder", [0, 1, 2])
+def test_reference_kernels_lds_stack_spills_to_its_global_stack(engine, orc, builder):
+    """intersect_main keeps 15 deferred nodes per work item in LDS and moves them to its global stack when a 16th comes
+    (intersect_bvh2_lds.cl:144-153), bringing them back when the LDS part runs empty (:186-196).  The hairball — 6 000
+    long thin triangles through one point — makes rays defer 16 and more nodes on every tree the library builds (the
+    oracle counts the high-water mark of each ray), and stays below the 45 the reference's 32-word stack can hold: the
+    records still equal the oracle's, and occluded_main's early-out (:228-363, the same spill code) changes no answer."""
+    from test_gpu_parity import _hairball_scene
+    flat = FlatScene(_hairball_scene(4, n=6000))
+    opts = make_options(orc, sample_count=16, sampler=capi.SAMPLER_COSINE, seed=5, bvh_builder=builder, bvh_width=2, bvh_quantised=0)
+    nodes, surfels = library_tree_and_surfels(flat, opts)
+    rays = orc.generate_rays(surfels, None, opts, flat.material_array[0].width)
+    depth = orc.reference_stack_depths(nodes, rays)
+    assert (depth >= 16).sum() >= 32 and depth.max() <= 45, (int((depth >= 16).sum()), int(depth.max()))
+    fill = filled(orc.INTERSECTION, len(rays))
+    with rk.Module("intersect_bvh2_lds_exact.co") as mod:
+        got = rk.intersect(mod, nodes, rays, fill)
+        occ = rk.occluded(mod, nodes, rays, filled(np.dtype(np.int32), len(rays)))
+    want = orc.intersect_rays(nodes, rays, fill=fill)
+    deep = depth >= 16
+    assert (want["shape_id"][deep] != -1).any()
+    assert np.array_equal(got["shape_id"], want["shape_id"]) and np.array_equal(got["prim_id"], want["prim_id"])
+    assert bits(got["uvwt"]).tobytes() == bits(want["uvwt"]).tobytes()
+    assert np.array_equal(occ, orc.occluded_rays(nodes, rays, fill=filled(np.dtype(np.int32), len(rays))))
+
+
 def test_reference_kernels_default_build_within_tolerance(engine, orc):
     """The kernels as RadeonRays builds them by default (native_recip, OpenCL's 2.5-ulp division): same hits, t within
     1e-4 (BASELINE.json's tolerance) of the exact-division build the oracle restates."""
@@ -205,14 +267,22 @@ def test_reference_kernels_ray_mask_is_hidden_from_self(engine, orc, name):
         assert unmasked_hits > 0           # the mask had something to hide
 
 
-def ramp_scene(g):
+def ramp_scene(g, jitter=0.0, seed=7):
     """A g x g vertex grid whose height is c * (i + j): the two triangles of a cell get boxes one step apart in y, cells are
     apart in x and z, so all 2 (g-1)^2 primitives have DISTINCT 30-bit Morton codes (g <= 512) — the case in which the
-    reference's 30-bit order and the build's 63-bit order must agree primitive for primitive."""
+    reference's 30-bit order and the build's 63-bit order must agree primitive for primitive.  jitter: every vertex moved
+    by up to that fraction of a cell in x and z (a quarter of it in y), seeded — an irregular mesh that still has that
+    property at g = 160, jitter = 0.2 (checked in the test, never assumed)."""
     t = np.linspace(0.0, 1.0, g)
     x, z = np.meshgrid(t, t, indexing="xy")
     i, j = np.meshgrid(np.arange(g), np.arange(g), indexing="xy")
     y = 0.25 * (i + j) / (2.0 * (g - 1))
+    if jitter:
+        rng = np.random.default_rng(seed)
+        h = jitter / (g - 1)
+        x = x + rng.uniform(-h, h, x.shape)
+        z = z + rng.uniform(-h, h, z.shape)
+        y = y + rng.uniform(-h, h, y.shape) * 0.25
     p = np.stack([x, y, z], axis=-1).reshape(-1, 3).astype(np.float32)
     n = np.tile(np.array([0, 1, 0], dtype=np.float32), (g * g, 1))
     uv = np.stack([x, z], axis=-1).reshape(-1, 2).astype(np.float32)
@@ -223,11 +293,11 @@ HLBVH_SCENES = {
     "cube": lambda: scenes.cube_scene(32),                                  # 12 triangles, 6 codes: the index fallback
     "ramp12": lambda: ramp_scene(12),                                       # 242 triangles: one 256-work-item workgroup
     "ramp40": lambda: ramp_scene(40),                                       # 3 042 triangles, 48 workgroups
-    "terrain_small": lambda: scenes.terrain_scene(grid=20, atlas=32),       # real terrains collide in 30 bits: skipped if so
+    "jitter160": lambda: ramp_scene(160, jitter=0.2),                       # 50 562 triangles, 198 workgroups, irregular
 }
 
 
-@pytest.mark.parametrize("name", ["cube", "ramp12", "ramp40", "terrain_small"])
+@pytest.mark.parametrize("name", ["cube", "ramp12", "ramp40", "jitter160"])
 def test_reference_kernels_hlbvh_build_matches_library_and_oracle(engine, orc, name):
     """build_hlbvh.cl on the GPU — calculate_morton_code_main, (host sort), emit_hierarchy_main, refit_bounds_main —
     against `bvh_builder = 0, morton_adaptive = 0` of the library and the oracle.  The reference sorts 30-bit codes, the
@@ -243,8 +313,10 @@ def test_reference_kernels_hlbvh_build_matches_library_and_oracle(engine, orc, n
         # Two triangles of one quad have the same box, hence the same code at any width: both sides order them by index and
         # split them by index (build_hlbvh.cl:131-150).  What must not happen is two primitives that share the 30-bit code
         # but not the 63-bit one: the reference would split them by index, the build by the finer bits.
-        if len(np.unique(codes30)) != len(np.unique(codes63)):
-            pytest.skip(f"{name}: {len(np.unique(codes63)) - len(np.unique(codes30))} 63-bit codes collide in their top 30 bits")
+        # The scenes here are made so that this cannot happen; a change that breaks that must fail, not skip.
+        assert len(np.unique(codes30)) == len(np.unique(codes63)), f"{name}: 63-bit codes collide in their top 30 bits"
+        if name != "cube":
+            assert len(np.unique(codes30)) == n
         order = np.argsort(codes30, kind="stable")
         one_group = n <= 256            # the code object's max_flat_workgroup_size (OpenCL default)
         # refit_bounds_main has no fence between a child's box store and its sibling's read of it (build_hlbvh.cl:283-312):

@@ -11,6 +11,7 @@ set -u
 R=$PWD
 O=${1:-gpurun_out/profile}
 mkdir -p $O $O/calib $O/roofs
+python3 tools/source_hash.py > $O/source_hash.json
 timeout -k 10 600 python -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1; rc=$?; echo "pytest rc=$rc" >> $O/pytest.log; tail -4 $O/pytest.log
 [ $rc -eq 0 ] || exit 1
 timeout -k 10 400 python tools/run_shapes.py > $O/shapes.jsonl 2> $O/shapes.err; echo "shapes rc=$?"

@@ -63,11 +63,12 @@ def main():
         return o
 
     if "cfg2" in which:
-        flat = FlatScene(scenes.sphere_scene(n=187, atlas=1024, seed=2, bpc=4))
+        sc2, mesh_name = scenes.config2_scene(atlas=1024, seed=2, bpc=4)        # AOB_CFG2_OBJ=/path/to.obj: that mesh instead of the stand-in
+        flat = FlatScene(sc2)
         with Baker(flat, cosine(64, 2)) as b:
             rec = timed_steps(b, 5)
             st = b.stats()
-        emit(shape="cfg2", workload="configs[1]: 69 938-triangle displaced sphere (bunny stand-in), 1024^2, 64 spp, cosine, any-hit, float",
+        emit(shape="cfg2", workload=f"configs[1]: {st.triangle_count}-triangle mesh, 1024^2, 64 spp, cosine, any-hit, float", mesh=mesh_name,
              triangles=st.triangle_count, rays=st.ray_count, grays_per_s=round(st.ray_count / rec["step_ms"] / 1e6, 3), **rec)
     if "reference" in which:
         sc = scenes.terrain_scene(grid=708, atlas=2048, seed=3, bpc=1)
