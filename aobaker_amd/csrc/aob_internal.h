@@ -50,7 +50,9 @@ struct DeviceMaterial {
     uint8_t* host_data = nullptr;
     uint32_t* cover = nullptr;            // W*H: winning triangle index + 1, per section pass
     uint32_t* prev_layer = nullptr;       // W*H, AOB_LAYERS_ALL only: triangle index + 1 of the texel's fragment in the layer before
-    uint32_t* block_sums = nullptr;       // scan partials
+    uint32_t* block_sums = nullptr;       // scan partials (+ the total, + the overlap flag)
+    uint8_t*  seen = nullptr;             // W*H: 1 where a section rasterised so far put a surfel (overlap detection)
+    bool      sections_overlap = false;   // some texel has surfels of two sections (or two layers): their launches stay apart
     uint32_t  scan_blocks = 0;
     AobSurfel* surfels = nullptr;         // concatenated, row-major per section
     uint32_t* section_index = nullptr;    // surfel -> index inside its section's list

@@ -345,7 +345,8 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
         const uint64_t cells = (uint64_t)d.width * d.height;
         d.scan_blocks = (uint32_t)((cells + 2047) / 2048);
         plan.want(&d.cover, cells);
-        plan.want(&d.block_sums, (uint64_t)d.scan_blocks + 1);
+        plan.want(&d.block_sums, (uint64_t)d.scan_blocks + 2);
+        plan.want(&d.seen, cells);
         plan.want(&d.results, cells);
         plan.want(&d.image, cells * d.channels * d.bytes_per_channel);
         plan.want(&d.surfels, cells);

@@ -175,12 +175,21 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* t
 }
 
 __global__ __launch_bounds__(kBlock)
-void k_scan_count(const uint32_t* __restrict__ cover, uint64_t cells, uint32_t* __restrict__ block_sums)
+void k_scan_count(const uint32_t* __restrict__ cover, uint64_t cells, uint32_t* __restrict__ block_sums,
+                  uint8_t* __restrict__ seen, uint32_t* __restrict__ overlap)
 {
     uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
     uint32_t c = 0;
+    bool again = false;
 #pragma unroll
-    for (int k = 0; k < kScanItems; k++) if (base + k < cells) c += cover[base + k] != 0u;
+    for (int k = 0; k < kScanItems; k++)
+        if (base + k < cells && cover[base + k] != 0u) {
+            c++;
+            // a texel an earlier section (or layer) of this rasterisation covered too: the sections overlap (trace.hip
+            // keeps their launches apart then)
+            if (seen[base + k]) again = true; else seen[base + k] = 1;
+        }
+    if (again) *overlap = 1u;
     uint32_t total;
     block_exclusive_scan(c, &total);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
@@ -455,6 +464,7 @@ int rasterize_material(AobBake* b, int32_t material, int32_t row_begin, int32_t 
     m.section_offsets.push_back(0);
     m.tile_prefix_valid = false;          // tile_row_prefix_host is written by the first section that has surfels
     AOB_HIP(hipMemsetAsync(m.results, 0, sizeof(AobResult) * cells, s));
+    m.sections_overlap = false;
     // Everything after the coverage pass works on the strip of texel rows alone: the strip starts on a tile row, so it is an
     // atlas of its own — W x window_rows texels at cover + row_begin * W — and a rank of the N-GPU run does not walk the
     // other ranks' rows.
@@ -462,6 +472,8 @@ int rasterize_material(AobBake* b, int32_t material, int32_t row_begin, int32_t 
     const uint64_t cell0 = (uint64_t)row_begin * m.width, cells_w = (uint64_t)hw * m.width;
     uint32_t* const cover_w = m.cover + cell0;
     const uint32_t nblocks = max(1u, (uint32_t)((cells_w + kScanTile - 1) / kScanTile));     // (an empty strip still runs the scans, on nothing)
+    AOB_HIP(hipMemsetAsync(m.seen + cell0, 0, cells_w, s));
+    AOB_HIP(hipMemsetAsync(m.block_sums + nblocks + 1, 0, sizeof(uint32_t), s));
     const bool conservative = b->opt.raster_mode == AOB_RASTER_CONSERVATIVE;
     const bool peel = b->opt.raster_layers == AOB_LAYERS_ALL;
     if (peel && !m.prev_layer) AOB_HIP(hipMalloc((void**)&m.prev_layer, sizeof(uint32_t) * cells));
@@ -485,12 +497,14 @@ int rasterize_material(AobBake* b, int32_t material, int32_t row_begin, int32_t 
                 hipLaunchKernelGGL((k_cover<false, false>), dim3(grid), dim3(kBlock), 0, s, mesh.uvs, mesh.indices, mesh.triangle_count,
                                    m.width, m.height, row_begin, row_end, m.cover, (const uint32_t*)nullptr);
         }
-        hipLaunchKernelGGL(k_scan_count, dim3(nblocks), dim3(kBlock), 0, s, cover_w, cells_w, m.block_sums);
+        hipLaunchKernelGGL(k_scan_count, dim3(nblocks), dim3(kBlock), 0, s, cover_w, cells_w, m.block_sums, m.seen + cell0, m.block_sums + nblocks + 1);
         hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(kBlock), 0, s, m.block_sums, nblocks);
-        // the section's surfel count decides the launch geometry of everything downstream
-        AOB_HIP(hipMemcpyAsync(b->pinned, m.block_sums + nblocks, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        // the section's surfel count decides the launch geometry of everything downstream (with it: whether any texel so far has
+        // surfels of two sections)
+        AOB_HIP(hipMemcpyAsync(&b->pinned[2], m.block_sums + nblocks, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));     // ([1] is the tree depth's)
         AOB_HIP(hipStreamSynchronize(s));
-        const uint64_t count = b->pinned[0];
+        const uint64_t count = b->pinned[2];
+        m.sections_overlap = b->pinned[3] != 0u;
         if (peel && layer > 0 && count == 0) break;                    // the peel is through (the first layer stands for the section even when empty)
         AOB_TRY(ensure_surfel_capacity(b, m, m.surfel_count + count));
         if (count) {

@@ -773,11 +773,16 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
         p.leaf_wait = knob(o.trace_leaf_wait, o.use_any_hit ? 24 : 16);
         p.scalar_min = (uint32_t)min(knob(o.trace_scalar_min, 24), max(1, p.refill_idle));
         cosine_grid(o.sample_count, p.grid);
-        // one launch per section: two sections of a material may cover the same texel, and
-        // their contributions are added in section order (BakeEngine.cpp:473,659)
-        for (size_t si = 0; si + 1 < m.section_offsets.size(); si++) {
-            uint64_t sb = m.section_offsets[si] > begin ? m.section_offsets[si] : begin;
-            uint64_t se = m.section_offsets[si + 1] < end ? m.section_offsets[si + 1] : end;
+        // One launch per section where two sections of the material cover a common texel: their contributions are added in
+        // section order (BakeEngine.cpp:473,659), and a launch owns the cells it writes.  Where no texel is shared (the rasteriser
+        // checks: sections_overlap) and no ray asks which section it came from (no visibility flags), the sections are one
+        // list of surfels to the kernel and go in ONE launch — the 101 charts of BASELINE configs[4] are 101 launches of ~1.1
+        // units per resident wavefront otherwise, each ending in a tail as long as itself.
+        const bool fused = m.section_offsets.size() > 2 && !m.sections_overlap && !b->any_mesh_flags;
+        const size_t launches = fused ? 1 : m.section_offsets.size() - 1;
+        for (size_t si = 0; si < launches; si++) {
+            uint64_t sb = fused ? begin : (m.section_offsets[si] > begin ? m.section_offsets[si] : begin);
+            uint64_t se = fused ? end : (m.section_offsets[si + 1] < end ? m.section_offsets[si + 1] : end);
             if (sb >= se) continue;
             p.begin = sb; p.end = se;
             p.ntiles = (uint32_t)((se - sb + kWave - 1) / kWave);
