@@ -416,7 +416,7 @@ def cpp_host_leg(scene, world, args):
             path = os.path.join(tmp, "scene.aobs")
             scenefile.write_scene(scene, path)
             cmd = [exe, "--scene", path, "--gpus", str(world), "--steps", str(max(1, min(args.steps, 5))), "--warmup", str(max(2, min(args.warmup, 3))),
-                   "--spp", str(args.spp), "--sampler", "1", "--accumulate", "1", "--seed", "3", "--any-hit", "1", "--normal-fp16", "0"]
+                   "--spp", str(args.spp), "--sampler", "1", "--accumulate", "1", "--seed", "3", "--any-hit", "1", "--normal-fp16", "0", "--builder", str(args.bvh_builder)]
             if args.no_balance:
                 cmd.append("--no-balance")
             out = subprocess.run(cmd, capture_output=True, text=True, timeout=180)

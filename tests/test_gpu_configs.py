@@ -120,6 +120,19 @@ def test_cpp_multi_gpu_host_matches_single_device(engine, tmp_path, devices, sam
     assert rec["rows"][0][0] == 0 and all(a[1] == b[0] for a, b in zip(rec["rows"], rec["rows"][1:]))
 
 
+def test_cpp_multi_gpu_host_names_a_device_that_is_not_there(engine, tmp_path):
+    """A device ordinal the box does not have (what the first run on a node with fewer GPUs than asked for would meet): the host
+    says which, and exits non-zero, before any thread or communicator exists — no hang, no fault."""
+    import torch
+    path = tmp_path / "scene.aobs"
+    scenefile.write_scene(scenes.cube_scene(32), str(path))
+    missing = torch.cuda.device_count()
+    out = subprocess.run([MGPU, "--scene", str(path), "--devices", f"0,{missing}", "--steps", "1", "--warmup", "0", "--spp", "4"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0
+    assert f"device {missing} is not on this box" in out.stderr, out.stderr[-500:]
+
+
 def test_cpp_multi_gpu_host_config4_shape(engine, tmp_path):
     """configs[3] through the C++ host: 4096^2 x 256 spp in 8 strips (8 ranks rehearsed on one device), image identical to the
     single-device bake; the re-cut strips are uneven (the terrain's border rows are cheaper), the ranks' times level."""

@@ -2,7 +2,7 @@
 // (aobaker_amd/host/MultiGpu.cpp), timed the way bench.py times its steps, one JSON line on stdout.
 //
 //   aobake_mgpu --scene file.aobs --gpus N [--devices 0,1,...] [--steps K] [--warmup W] [--spp S] [--sampler 0|1]
-//               [--accumulate 0|1] [--seed X] [--any-hit 0|1] [--normal-fp16 M] [--falloff F] [--no-balance] [--check-single]
+//               [--accumulate 0|1] [--seed X] [--any-hit 0|1] [--normal-fp16 M] [--falloff F] [--builder 0|1|2] [--no-balance] [--check-single]
 //               [--out prefix]
 //
 // --devices may name a device more than once: ranks that share a GPU rehearse the N-rank orchestration on one card (their
@@ -55,6 +55,7 @@ int main(int argc, char** argv)
 		else if (a == "--any-hit") opt.use_any_hit = std::atoi(next());
 		else if (a == "--normal-fp16") opt.normal_fp16 = std::atoi(next());
 		else if (a == "--falloff") opt.falloff_distance = (float)std::atof(next());
+		else if (a == "--builder") opt.bvh_builder = std::atoi(next());
 		else if (a == "--no-balance") balance = false;
 		else if (a == "--check-single") check_single = true;
 		else if (a == "--out") out = next();

@@ -86,7 +86,7 @@ def main():
         BakeEngine.Options = None
     if "ranks" in which:
         flat = FlatScene(scenes.terrain_scene(grid=708, atlas=4096, seed=3, bpc=4))
-        with Baker(flat, cosine(256, 3)) as b:
+        with Baker(flat, cosine(256, 3, bvh_builder=2)) as b:          # as bench.py bakes it
             for world in (1, 2, 4, 8):
                 bounds = aod.equal_rows(4096, world)
                 for rank in sorted({0, world // 2, world - 1}):
