@@ -195,7 +195,7 @@ void aob_default_options(AobOptions* o)
     o->trace_part_min = 16;
     o->trace_fine_div = 8;
     o->trace_bands = 1;
-    o->trace_scalar_min = 24;
+    o->trace_scalar_min = 0;       // by sampler (trace.hip)
 }
 
 int aob_init(const AobDeviceConfig* config)

@@ -771,7 +771,10 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
         // BASELINE configs[2]; the scalar steps: since the vector-memory path is what binds the walk (profiles/r03/roofs/) a step pays
         // for 24 lanes on one node — 16 / 24 / 32 / 36 / 40 -> 56.9 / 56.6 / 56.9 / 57.2 / 57.7 ms — where round 2's kernel wanted 40)
         p.leaf_wait = knob(o.trace_leaf_wait, o.use_any_hit ? 24 : 16);
-        p.scalar_min = (uint32_t)min(knob(o.trace_scalar_min, 24), max(1, p.refill_idle));
+        // (the table sampler's rays of one refill point everywhere — a sample index means a different direction for every surfel — and
+        // part ways a level or two below the root: there a step pays from 8 lanes, 2 / 4 / 6 / 8 / 12 / 24 -> 49.1 / 48.2 / 47.9 / 47.8 /
+        // 48.0 / 49.6 ms on the reference's own constants; profiles/r03/roofs/knobs_other_workloads.jsonl)
+        p.scalar_min = (uint32_t)min(knob(o.trace_scalar_min, o.sampler == AOB_SAMPLER_COSINE ? 24 : 8), max(1, p.refill_idle));
         cosine_grid(o.sample_count, p.grid);
         // One launch per section where two sections of the material cover a common texel: their contributions are added in
         // section order (BakeEngine.cpp:473,659), and a launch owns the cells it writes.  Where no texel is shared (the rasteriser

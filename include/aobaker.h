@@ -121,7 +121,8 @@ typedef struct AobOptions {
     int32_t  trace_bands;         /* 1 (default): on a fully covered atlas, 8x8-tile blocks inside bands of 8 tile rows;
                                      2: plain chunks of 2048 tiles                                                          */
     int32_t  trace_scalar_min;    /* any-hit walk of the quantised 4-ary nodes: lanes that must stand on ONE node for it to be
-                                     visited from scalar registers (after a refill): 1..64, default 24                      */
+                                     visited from scalar registers (after a refill): 1..64; 0 (default) = by sampler: 24
+                                     with the COSINE sampler, 8 with the table sampler (its rays part ways sooner)          */
 } AobOptions;
 
 /* ---- scene description ----------------------------------------------------

@@ -491,5 +491,5 @@ def default_options():
     o.bvh_builder = 1
     o.morton_adaptive = 1
     # the schedule of the library's trace kernel (no meaning for the oracle; stated so that the two defaults compare equal)
-    o.trace_refill_idle, o.trace_leaf_wait, o.trace_parts, o.trace_part_min, o.trace_fine_div, o.trace_bands, o.trace_scalar_min = 0, 0, 4, 16, 8, 1, 24
+    o.trace_refill_idle, o.trace_leaf_wait, o.trace_parts, o.trace_part_min, o.trace_fine_div, o.trace_bands, o.trace_scalar_min = 0, 0, 4, 16, 8, 1, 0
     return o

@@ -8,6 +8,7 @@ Product code only (no oracle).  LIB `-` is the in-tree library.
 
   anyhit   BASELINE configs[2]: 999 698-triangle terrain, 2048^2, 256 spp, cosine / any hit / float   k_trace<1,1,1,11,2,0>
   closest  the same terrain and rays with closest-hit falloff scoring (falloff 1.25, tmax clamped)      k_trace<1,0,1,10,2,0>
+  refmode  the reference's own constants on the same terrain: 100 spp, table sampler, int32 sums, any hit           k_trace<0,1,0,10,2,0>
   cfg2     configs[1]: 69 938-triangle sphere, 1024^2, 64 spp, any hit
   cfg5     configs[4]'s instanced scene (10 M triangles) at its own 8192^2 atlas, 16 of its 1024 spp, closest-hit falloff scoring
   cfg5s    configs[4]'s instanced scene (10 M triangles) at 2048^2 x 64 spp, closest-hit falloff scoring
@@ -46,6 +47,13 @@ def child(modes, reps, knobs):
             terrain = terrain or FlatScene(scenes.terrain_scene(grid=708, atlas=2048, seed=3, bpc=4))
             flat, spp = terrain, 256
             o = cosine(256, 3) if mode == "anyhit" else cosine(256, 3, use_any_hit=0, falloff_distance=1.25, clamp_tmax_to_falloff=1)
+        elif mode == "refmode":
+            # the reference's own constants (BakeEngine.cpp:13-18): 100 spp, MSVC-rand table, int32 quantised sums, any hit, R8
+            terrain1 = FlatScene(scenes.terrain_scene(grid=708, atlas=2048, seed=3, bpc=1))
+            flat, spp = terrain1, 100
+            o = capi.default_options()
+            for k, v in knobs.items():
+                setattr(o, k, v)
         elif mode == "cfg2":
             flat, spp = FlatScene(scenes.sphere_scene(n=187, atlas=1024, seed=2, bpc=4)), 64
             o = cosine(64, 2)
