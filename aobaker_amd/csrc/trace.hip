@@ -766,7 +766,10 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
         // Measured (profiles/r02/trace_knob_sweep.jsonl, shapes.jsonl): with unit weights and any-hit scoring the walk is fastest
         // when 42 lanes wait for a refill (fresh rays of one sample start together and share the top of the tree: configs[2]
         // 76.2 -> 74.1 ms, configs[1] +5 %); closest-hit and weighted scoring keep 24 (configs[4] loses 4.5 % at 42)
-        p.refill_idle = knob(o.trace_refill_idle, (o.sampler == AOB_SAMPLER_COSINE && o.use_any_hit) ? 42 : 24);
+        // (round 3, with a material's sections in one launch: closest-hit scoring — no scalar steps, so nothing to gain from rays that
+        // start together — is best at 16: 4 / 8 / 12 / 16 / 20 / 24 / 32 / 42 -> 187.6 / 180.7 / 179.4 / 180.0 / 182.2 / 184.3 / 196.5 / 193.0 ms on
+        // configs[4]'s scene at 16 spp, 116.9 / 108.8 / 104.8 / 104.1 / 104.8 / 106.1 / 115.4 / 110.2 on the terrain; profiles/r03/roofs/closest_hit_refill.jsonl)
+        p.refill_idle = knob(o.trace_refill_idle, o.use_any_hit ? (o.sampler == AOB_SAMPLER_COSINE ? 42 : 24) : 16);
         // (the leaf section: 16 parked lanes, 24 with any-hit scoring — 12 / 16 / 20 / 24 / 28 -> 59.5 / 58.3 / 57.9 / 57.7 / 57.7 ms on
         // BASELINE configs[2]; the scalar steps: since the vector-memory path is what binds the walk (profiles/r03/roofs/) a step pays
         // for 24 lanes on one node — 16 / 24 / 32 / 36 / 40 -> 56.9 / 56.6 / 56.9 / 57.2 / 57.7 ms — where round 2's kernel wanted 40)
