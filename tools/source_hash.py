@@ -54,10 +54,11 @@ def manifest(directory):
             out[os.path.relpath(path, os.path.join(ROOT, directory))] = {"commit": None, "note": "not committed yet: the working tree's sources", **{"kernel_source_sha": working_tree()["kernel_source_sha"]}}
             continue
         if commit not in cache:
-            cache[commit] = at_commit(commit)["kernel_source_sha"]
-        out[os.path.relpath(path, os.path.join(ROOT, directory))] = {"commit": commit[:12], "kernel_source_sha": cache[commit]}
+            h = at_commit(commit)
+            cache[commit] = {"kernel_source_sha": h["kernel_source_sha"], "source_sha256_16": h["source_sha256_16"]}
+        out[os.path.relpath(path, os.path.join(ROOT, directory))] = {"commit": commit[:12], **cache[commit]}
     with open(os.path.join(ROOT, directory, "MANIFEST.json"), "w") as f:
-        json.dump({"what": "file -> the commit that last changed it and the SHA of aobaker_amd/csrc/*.{hip,h} at that commit (tools/source_hash.py)",
+        json.dump({"what": "file -> the commit that last changed it, the SHA of aobaker_amd/csrc/*.{hip,h} at that commit (kernel_source_sha) and of the files k_trace's time depends on as bench.py hashes them (source_sha256_16; before round 3's end that list had no bvh_build.hip) — tools/source_hash.py",
                    "files": out}, f, indent=1)
         f.write("\n")
     print(f"{len(out)} files -> {directory}/MANIFEST.json")
