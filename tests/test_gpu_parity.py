@@ -531,6 +531,23 @@ def test_invalid_arguments_are_reported(engine, orc):
             b.trace(0)                      # BVH not built yet
         with pytest.raises(capi.AobError):
             b.rasterize(3)                  # no such material
+        # aob_bake_add_results: another handle's cells on the same device are added word by word (what an RCCL sum-reduce does
+        # between devices); a cell count that is not the material's is refused
+        import ctypes as C
+        b.build_bvh(); b.rasterize(0); b.trace(0)
+        once = b.results(0).copy()
+        with Baker(flat, opt) as other:
+            other.build_bvh(); other.rasterize(0); other.trace(0)
+            ptr, nbytes = C.c_void_p(), C.c_uint64()
+            capi.check(other.lib.aob_bake_results_device_ptr(other.handle, 0, C.byref(ptr), C.byref(nbytes)))
+            cells = nbytes.value // 8
+            assert cells == len(once)
+            assert b.lib.aob_bake_add_results(b.handle, 0, ptr, cells - 1) == -1 and b"cells" in b.lib.aob_last_error()
+            capi.check(b.lib.aob_bake_add_results(b.handle, 0, ptr, cells))
+            b.sync()
+            twice = b.results(0)
+        assert np.array_equal(twice["total_bits"].view(np.int32), 2 * once["total_bits"].view(np.int32))
+        assert np.array_equal(twice["weight_bits"].view(np.int32), 2 * once["weight_bits"].view(np.int32))
 
 
 def test_handles_work_from_threads_that_never_called_init(engine, orc):
