@@ -356,7 +356,9 @@ int aob_bake_image_device_ptr(AobBake* bake, int32_t material, void** ptr, uint6
 /* cells += other_cells (cell_count = W*H AobResult records in the SAME device's memory, e.g. another handle's buffer from
  * aob_bake_results_device_ptr), enqueued on the bake's stream: int32 sums in QUANTISED mode, float sums in FLOAT mode —
  * what ncclReduce(ncclSum) does between devices, for hosts whose ranks share one device (aobaker_multi.h rehearsals).
- * QUANTISED sums are exact; FLOAT sums of cells that two parts both touched are the sum of two rounded floats. */
+ * QUANTISED sums are exact; FLOAT sums of cells that two parts both touched are the sum of two rounded floats.  The kernel
+ * runs on THIS bake's stream: whatever writes other_cells (another handle's trace on its own stream) must have finished
+ * (aob_bake_sync on that handle) before the call. */
 int aob_bake_add_results(AobBake* bake, int32_t material, const void* other_cells, uint64_t cell_count);
 /* The HIP stream the stages are enqueued on (a hipStream_t as void*). */
 int aob_bake_stream(AobBake* bake, void** stream);

@@ -538,6 +538,7 @@ def test_invalid_arguments_are_reported(engine, orc):
         once = b.results(0).copy()
         with Baker(flat, opt) as other:
             other.build_bvh(); other.rasterize(0); other.trace(0)
+            other.sync()                    # the sum runs on b's stream: the other handle's work must have finished
             ptr, nbytes = C.c_void_p(), C.c_uint64()
             capi.check(other.lib.aob_bake_results_device_ptr(other.handle, 0, C.byref(ptr), C.byref(nbytes)))
             cells = nbytes.value // 8
