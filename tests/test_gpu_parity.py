@@ -577,12 +577,12 @@ def test_handles_work_from_threads_that_never_called_init(engine, orc):
     assert bits(out["own"]).tobytes() == bits(want).tobytes() and bits(out["foreign"]).tobytes() == bits(want).tobytes()
 
 
-@pytest.mark.parametrize("name,parts", [("terrain", 3), ("cube", 2), ("sphere", 5), ("two_section", 2)])
+@pytest.mark.parametrize("name,parts", [("terrain", 3), ("cube", 2), ("sphere", 5), ("two_section", 2), ("instanced", 4)])
 def test_sharded_trace_equals_full_trace(engine, orc, name, parts):
     """aob_bake_shard_bounds + aob_bake_trace(begin, end): the multi-GPU decomposition on one GPU.
     Parts are traced one after the other into the same result buffer; single-section materials get
-    tile-row aligned parts that own disjoint strips of cells."""
-    flat = FlatScene(SCENES[name]())
+    tile-row aligned parts that own disjoint strips of cells.  (`instanced`: ranges of a list whose 13 sections go in one launch.)"""
+    flat = FlatScene(scenes.instanced_scene(instances=12, rock_n=20, atlas=256, seed=5, bpc=4) if name == "instanced" else SCENES[name]())
     opt = make_options(orc, sample_count=16, sampler=capi.SAMPLER_COSINE, accumulate=capi.ACCUMULATE_FLOAT, seed=11)
     m = flat.material_array[0]
     with Baker(flat, opt) as b:
@@ -592,7 +592,8 @@ def test_sharded_trace_equals_full_trace(engine, orc, name, parts):
         n = b.surfel_count(0)
         bounds, strips, overlapping = b.shard_bounds(0, parts)
         assert bounds[0] == 0 and bounds[-1] == n and all(bounds[i] <= bounds[i + 1] for i in range(parts))
-        assert overlapping == (name == "two_section")
+        # (`overlapping`: the parts' cells are not one strip each — several sections; whether two sections share a TEXEL is another matter)
+        assert overlapping == (name in ("two_section", "instanced"))
         b.clear_results(0)
         owned = np.zeros(m.width * m.height, dtype=np.int32)
         for r in range(parts):
@@ -600,13 +601,16 @@ def test_sharded_trace_equals_full_trace(engine, orc, name, parts):
             b.trace(0, bounds[r], bounds[r + 1])
             part = b.results(0)
             touched = (part["weight_bits"] != 0)
+            if name == "instanced":
+                # sections that share no texel: every surfel has its own cell, so a part's cells are the full bake's, or untouched
+                assert np.array_equal(part[touched], full[touched])
             if not overlapping and bounds[r + 1] > bounds[r]:
                 c0, c1 = strips[r]
                 assert c0 % (8 * m.width) == 0                       # starts on a tile row
                 assert not touched[:c0].any() and not touched[c1 + 1:].any()
                 assert np.array_equal(part[c0:c1 + 1], full[c0:c1 + 1])
             owned += touched
-        if not overlapping:
+        if not overlapping or name == "instanced":
             assert owned.max() == 1 and np.array_equal(owned > 0, full["weight_bits"] != 0)
         sizes = [bounds[i + 1] - bounds[i] for i in range(parts)]
         if name in ("terrain", "sphere"):
@@ -765,11 +769,13 @@ def test_deep_stacks_spill_to_hbm_and_come_back(engine, orc, mode, structure):
 
 # ---- a rank's strip of texel rows (aob_bake_rasterize_rows) ------------------------------------------------------
 @pytest.mark.parametrize("parts", [2, 3])
-@pytest.mark.parametrize("name", ["cube", "terrain", "two_section"])
+@pytest.mark.parametrize("name", ["cube", "terrain", "two_section", "instanced"])
 def test_row_window_bakes_stitch_to_the_full_bake(engine, orc, name, parts):
-    """Rasterising and tracing the atlas strip by strip gives the cells of the whole bake (what bench.py does per rank)."""
+    """Rasterising and tracing the atlas strip by strip gives the cells of the whole bake (what bench.py does per rank).
+    `instanced`: 13 sections of one material that share no texel — one launch for all of them, per strip too; `two_section`:
+    sections that do overlap — a launch each."""
     from aobaker_amd import dist as aod
-    flat = FlatScene(SCENES[name]())
+    flat = FlatScene(scenes.instanced_scene(instances=12, rock_n=20, atlas=256, seed=5, bpc=4) if name == "instanced" else SCENES[name]())
     opt = make_options(orc, sample_count=16, **MODES[2])
     m = flat.material_array[0]
     with Baker(flat, opt) as b:
