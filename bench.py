@@ -21,11 +21,12 @@ The JSON line also carries
                 fetches counted by the CPU oracle on a texel subsample of the same rays — over the kernel's time from HIP
                 events on the library's own stream, against HBM peak.  `frac` can exceed 1: the model counts every node
                 fetch as memory traffic although L1 / L2 / Infinity Cache serve most of them; a fraction above 1 means
-                "cache-served", not "faster than HBM".  `traffic` / `hbm_counter_frac` (what the memory-side counters
-                saw), `valu_issue_frac` and the instruction counts per ray (the roofs that actually bind: VALU issue and the CU's
-                vector-memory path) come from the committed rocprofv3
-                PMC passes of THIS kernel source and THIS configuration (profiles/k_trace_counters.json) and are null
-                when either differs.
+                "cache-served", not "faster than HBM".  `bound` / `roof` name the roof that binds THIS kernel — the CU's
+                vector-memory path: `roof.frac` is the busy fraction of its data-return unit, with the marginal cost of one
+                more load and of one more vector instruction per visit from the slope builds —
+                `traffic` / `hbm_counter_frac` are what the memory-side counters saw; these and the instruction counts per
+                ray come from the committed rocprofv3 PMC passes and A/B builds of THIS kernel source and THIS
+                configuration (profiles/k_trace_counters.json) and are null when either differs.
   cpu_baseline  the CPU oracle (a port, oracle/) timed on this box's host cores on a bounded texel subsample (N = 1 only).
   bake_wallclock_ms  the PCIe-inclusive `aob_bake` (allocation + upload + device step + download), first call of the
                 process (cold) and second (warm), beside the device step (N = 1 only) — SURVEY.md §8(d)(ii).
