@@ -122,6 +122,8 @@ struct AobBake {
     bool      any_mesh_flags = false;
     int cu_count = 256;
     uint64_t gstack_words = 0;
+    unsigned long long* acc_cells = nullptr;   // 2 x 64-bit exact sums per result cell of the largest material: where the sample parts of a tile
+    uint64_t acc_cells_count = 0;              // add up when the cells are floats that hold fractions (trace.hip; allocated on first use, kept zero)
 
     float* hemisphere = nullptr;        // compat sampler table (float3 packed)
     uint64_t hemisphere_entries = 0;

@@ -113,6 +113,7 @@ static void free_bake(AobBake* b)
         if (m.tile_row_prefix_host) hipHostFree(m.tile_row_prefix_host);
     }
     release_device(b, b->gstack);
+    release_device(b, b->acc_cells);
     if (b->arena) hipFree(b->arena);
     if (b->pinned) hipHostFree(b->pinned);
     for (auto& e : b->ev) if (e) hipEventDestroy(e);

@@ -104,6 +104,7 @@ struct TraceParams {
     uint32_t coarse_tiles;
     uint32_t parts_fine;           // the last tiles of every queue are cut into this many parts: a shorter tail of idle CUs at the end
     uint32_t* unit_next;           // [8] next unit of each XCD's queue (zeroed before the launch)
+    unsigned long long* acc_cells; // parts > 1 with float cells that hold fractions: the parts' exact sums meet here (2 per cell), k_acc_to_cells rounds them once
     // MASKED: section visibility (AOB_MESH_*)
     const uint32_t* hidden_from_others;    // bit s: the triangles of shape s are ignored by rays of other shapes
     uint32_t self_shape;           // shape id of the section whose surfels this launch traces (mesh index + 1)
@@ -642,8 +643,8 @@ void k_trace(TraceParams p)
 
     // ProcessIntersectionsComputeShader.hlsl:89-90: one surfel per cell per launch.  A workgroup that traced all
     // samples of its tile owns the cells: a plain read-modify-write replaces the 2*spp InterlockedAdds.  Parts of a
-    // tile add atomically — only in the modes where that is exact in any order: integer cells, or float cells that
-    // hold whole numbers (unit weights, any hit: misses and samples counted), see kSplitExact.
+    // tile add atomically, exactly in any order: to integer cells, to float cells that hold whole numbers (unit weights, any
+    // hit: misses and samples counted), or — fractions — to 64-bit accumulators that are rounded once after the launch.
     if (valid) {
         const float4 d = p.frames[4ull * (wave_first + lane) + 3];
         const long long sT = COUNT32 ? (long long)miss_count[lane] * kUnit : (long long)acc[lane][0];
@@ -653,9 +654,16 @@ void k_trace(TraceParams p)
             if (ACCUM == AOB_ACCUMULATE_QUANTISED) {
                 atomicAdd((int32_t*)&cell->total_bits, (int32_t)sT);
                 atomicAdd((int32_t*)&cell->weight_bits, (int32_t)sW);
-            } else {
+            } else if (COUNT32) {
+                // whole numbers (unit weights, samples counted): float adds of them are exact in any order
                 unsafeAtomicAdd((float*)&cell->total_bits, (float)sT * 2.3283064365386962890625e-10f);
                 unsafeAtomicAdd((float*)&cell->weight_bits, (float)sW * 2.3283064365386962890625e-10f);
+            } else {
+                // fractions: a float cell is the exact sum rounded ONCE, so the parts add their Q32.32 sums as integers and
+                // k_acc_to_cells rounds the total after the launch — the cell a single part would have written
+                unsigned long long* a = p.acc_cells + 2ull * __float_as_uint(d.x);
+                atomicAdd(a, (unsigned long long)sT);
+                atomicAdd(a + 1, (unsigned long long)sW);
             }
         } else {
             AobResult c = *cell;
@@ -671,6 +679,24 @@ void k_trace(TraceParams p)
         }
     }
   }   // next unit
+}
+
+// After a launch whose parts met in acc_cells: every surfel of the launch owns one cell (sections in one launch share no texel);
+// its exact sums are rounded to float once, added to the cell as a single part would have added them, and cleared for the next launch.
+__global__ __launch_bounds__(256)
+void k_acc_to_cells(const float4* __restrict__ frames, uint64_t begin, uint64_t end, unsigned long long* __restrict__ acc, AobResult* __restrict__ results)
+{
+    const uint64_t i = begin + (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= end) return;
+    const float4 d = frames[4ull * i + 3];
+    if (__float_as_uint(d.z) == 0u) return;              // no tangent frame: no rays, nothing was added
+    const uint32_t c = __float_as_uint(d.x);
+    const long long sT = (long long)acc[2ull * c], sW = (long long)acc[2ull * c + 1];
+    acc[2ull * c] = 0ull; acc[2ull * c + 1] = 0ull;
+    AobResult r = results[c];
+    r.total_bits = __float_as_uint(__uint_as_float(r.total_bits) + (float)sT * 2.3283064365386962890625e-10f);
+    r.weight_bits = __float_as_uint(__uint_as_float(r.weight_bits) + (float)sW * 2.3283064365386962890625e-10f);
+    results[c] = r;
 }
 
 // Stack entries per lane kept in LDS (deeper ones go to an HBM array): 5 KB per wavefront = 2 KB of queued rays + the
@@ -795,8 +821,23 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
             // Sample parts: a wavefront lives ~11 ms on the headline workload and the launch ends with a tail of idle
             // CUs about that long; four parts per tile shorten both fourfold (a part is at least 16 samples: fewer cost more in
             // prologues and result atomics than they balance).  Only where adding the parts is exact.
-            const bool split_exact = o.accumulate == AOB_ACCUMULATE_QUANTISED || (o.sampler == AOB_SAMPLER_COSINE && o.use_any_hit);
-            p.parts = split_exact ? (uint32_t)max(1, min(knob(o.trace_parts, 4), o.sample_count / knob(o.trace_part_min, 16))) : 1u;
+            // Adding the parts is exact with integer cells and with float cells that hold whole numbers (unit weights, any hit); float
+            // cells that hold fractions go through 64-bit accumulators and are rounded once after the launch (k_acc_to_cells).
+            const bool split_direct = o.accumulate == AOB_ACCUMULATE_QUANTISED || (o.sampler == AOB_SAMPLER_COSINE && o.use_any_hit);
+            p.parts = (uint32_t)max(1, min(knob(o.trace_parts, 4), o.sample_count / knob(o.trace_part_min, 16)));
+            const bool through_acc = !split_direct && p.parts > 1u;
+            if (through_acc) {
+                const uint64_t cells = (uint64_t)m.width * m.height;
+                if (cells > b->acc_cells_count) {
+                    AOB_HIP(hipStreamSynchronize(s));
+                    if (b->acc_cells) AOB_HIP(hipFree(b->acc_cells));
+                    b->acc_cells = nullptr; b->acc_cells_count = 0;
+                    AOB_HIP(hipMalloc((void**)&b->acc_cells, 16ull * cells));
+                    AOB_HIP(hipMemsetAsync(b->acc_cells, 0, 16ull * cells, s));
+                    b->acc_cells_count = cells;
+                }
+            }
+            p.acc_cells = b->acc_cells;
             // chunks: bands of 8 tile rows when every texel of the rasterised rows has exactly one surfel (then the trace
             // order is the plain tile grid), else 2048 tiles
             p.band_row = 0;
@@ -834,6 +875,8 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
             p.self_hidden = (b->meshes[m.section_mesh[si]].flags & AOB_MESH_HIDDEN_FROM_SELF) ? 1u : 0u;
             if (o.sampler == AOB_SAMPLER_REFERENCE_COMPAT) launch_masked<AOB_SAMPLER_REFERENCE_COMPAT>(b->any_mesh_flags, o.use_any_hit, o.accumulate, quant, grid, s, p);
             else launch_masked<AOB_SAMPLER_COSINE>(b->any_mesh_flags, o.use_any_hit, o.accumulate, quant, grid, s, p);
+            if (through_acc)
+                hipLaunchKernelGGL(k_acc_to_cells, dim3((uint32_t)((se - sb + 255) / 256)), dim3(256), 0, s, m.frames, sb, se, b->acc_cells, m.results);
         }
         AOB_HIP(hipGetLastError());
     }
