@@ -1128,8 +1128,11 @@ static inline float min3n(float a, float b, float c) { return fminf(fminf(a, b),
  *     [0, 1] (NaN -> 0, the clamp modifier of v_max3_f32); the far distance is not clamped — a box wholly beyond t_max
  *     passes, which is harmless because the triangle test has the last word;
  *   - closest hit: intersect_bvh2_lds.cl:54-63 as before, near clamped at 0 and far at closest_t. */
-static inline int traverse4q(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const AobLeafTri* tris,
-                             f3 o, f3 d, float t_max, int any_hit, float* t_out, OrcTraceStats* st, int* error, const OrcMask* mask)
+/* (start / n_start: measurement only — the walk begins with these refs on its stack instead of at the root, start[0] first;
+ * NULL: the root) */
+static inline int traverse4q_from(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const AobLeafTri* tris,
+                                  f3 o, f3 d, float t_max, int any_hit, float* t_out, OrcTraceStats* st, int* error, const OrcMask* mask,
+                                  const uint32_t* start, int n_start)
 {
     if (count4 == 0) { *t_out = t_max; return 0; }
     f3 invdir = safe_invdir(d);
@@ -1154,6 +1157,11 @@ static inline int traverse4q(const AobBvh4QNode* nq, uint64_t count4, const AobQ
     int sp = 0;
     stack[sp++] = AOB_INVALID_ADDR;
     uint32_t node = 0;
+    if (start) {
+        if (n_start < 1) { *t_out = t_max; return 0; }
+        for (int k = n_start - 1; k >= 1; k--) stack[sp++] = start[k];
+        node = start[0];
+    }
     while (node != AOB_INVALID_ADDR) {
         if (!(node & AOB_LEAF_FLAG)) {
             const uint32_t* w = nq[node].w;
@@ -1214,6 +1222,12 @@ static inline int traverse4q(const AobBvh4QNode* nq, uint64_t count4, const AobQ
     }
     *t_out = closest_t;
     return hit;
+}
+
+static inline int traverse4q(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const AobLeafTri* tris,
+                             f3 o, f3 d, float t_max, int any_hit, float* t_out, OrcTraceStats* st, int* error, const OrcMask* mask)
+{
+    return traverse4q_from(nq, count4, fr, tris, o, d, t_max, any_hit, t_out, st, error, mask, NULL, 0);
 }
 
 
@@ -1935,6 +1949,25 @@ int orc_walk4q(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr,
                                    r->o[3], any_hit, &t, &st, &error, NULL);
         all->rays++; all->inner_visits += st.inner_visits; all->leaf_visits += st.leaf_visits; all->hits += (uint64_t)hit;
         if (hit && of_hit_rays) { of_hit_rays->rays++; of_hit_rays->inner_visits += st.inner_visits; of_hit_rays->leaf_visits += st.leaf_visits; of_hit_rays->hits++; }
+    }
+    return error;
+}
+
+/* The same walk started from a list of refs instead of the root (tests/measure_region_cut.py: what starting every ray of a tile
+ * below the nodes its rays cannot leave would save); t_sum: the hit distances added up in double, to compare with the plain walk. */
+int orc_walk4q_from(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const AobLeafTri* tris,
+                    const OrcRay* rays, uint64_t n, int32_t any_hit, const uint32_t* start, int32_t n_start, OrcTraceStats* all, double* t_sum)
+{
+    int error = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const OrcRay* r = &rays[i];
+        if (r->extra[1] == 0) continue;
+        OrcTraceStats st; memset(&st, 0, sizeof st);
+        float t;
+        const int hit = traverse4q_from(nq, count4, fr, tris, f3_make(r->o[0], r->o[1], r->o[2]), f3_make(r->d[0], r->d[1], r->d[2]),
+                                        r->o[3], any_hit, &t, &st, &error, NULL, start, n_start);
+        all->rays++; all->inner_visits += st.inner_visits; all->leaf_visits += st.leaf_visits; all->hits += (uint64_t)hit;
+        if (hit && t_sum) *t_sum += (double)t;
     }
     return error;
 }

@@ -188,6 +188,8 @@ int orc_flat_intersect(const AobBvhNode* nodes, uint64_t node_count, const OrcRa
                        OrcIntersection* hits, OrcTraceStats* st);
 
 /* ---- measurement helpers (tests/measure_tree_variants.py) ---------------------------------------------------------- */
+int orc_walk4q_from(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const AobLeafTri* tris,
+                    const OrcRay* rays, uint64_t n, int32_t any_hit, const uint32_t* start, int32_t n_start, OrcTraceStats* all, double* t_sum);
 int orc_walk4q(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const AobLeafTri* tris,
                const OrcRay* rays, uint64_t n, int32_t any_hit, OrcTraceStats* all, OrcTraceStats* of_hit_rays);
 int orc_kary_visits(const AobBvhNode* nodes2, uint64_t node_count2, const OrcRay* rays, uint64_t n, int32_t levels, int32_t pairs,
