@@ -107,7 +107,7 @@ class AobSceneDesc(C.Structure):
 
 
 class AobDeviceConfig(C.Structure):
-    _fields_ = [("device", C.c_int32), ("reserved", C.c_int32 * 7)]
+    _fields_ = [("device", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32 * 6)]
 
 
 class AobStats(C.Structure):

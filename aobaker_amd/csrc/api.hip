@@ -9,7 +9,11 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <new>
+#include <thread>
+#include <vector>
 
 #include <rocprim/rocprim.hpp>
 
@@ -34,12 +38,21 @@ void set_error(const char* fmt, ...)
 
 // BakeEngine.cpp:312-333 with the MSVC CRT rand() the reference draws from (never seeded, so
 // the state starts at 1): x = sin(theta)cos(phi), z = sin(theta)sin(phi), y = 1 - sin(theta).
-static void hemisphere_table(float* out, uint64_t count)
+// Entries [first, last) of the table.  The generator is the LCG s -> 214013 s + 2531011 (mod 2^32), two draws per entry: its
+// state before entry `first` is 2 * first steps from 1, reached in O(log) by squaring the affine map — so every host thread
+// fills its own run of entries and the bytes are those of the serial loop (same libm calls, same order per entry).
+static void hemisphere_entries(float* out, uint64_t first, uint64_t last)
 {
-    uint32_t state = 1u;
+    uint32_t mul = 1u, add = 0u;                    // the map applied 2 * first times: s -> mul * s + add
+    uint32_t m = 214013u, a = 2531011u;
+    for (uint64_t k = 2 * first; k; k >>= 1) {
+        if (k & 1) { mul = mul * m; add = add * m + a; }
+        a = a * m + a; m = m * m;
+    }
+    uint32_t state = mul * 1u + add;
     auto msvc_rand = [&]() { state = state * 214013u + 2531011u; return (state >> 16) & 0x7fffu; };
     const float two_pi = 2.0f * 3.14159265358979323846f;
-    for (uint64_t i = 0; i < count; i++) {
+    for (uint64_t i = first; i < last; i++) {
         float u = (float)msvc_rand() / 32767.0f;
         float v = (float)msvc_rand() / 32767.0f;
         float sintheta = std::sqrt(-u * (u - 2.0f));
@@ -49,6 +62,35 @@ static void hemisphere_table(float* out, uint64_t count)
         float len = std::sqrt(x * x + z * z);
         out[3 * i + 0] = x; out[3 * i + 1] = 1.0f - len; out[3 * i + 2] = z;
     }
+}
+
+// The table of the first `count` entries, filled on all host cores and kept for the process: a prefix of the sequence is the
+// same for every bake, so a later bake that needs no more entries reuses it (the reference refills its 16.7 M entries on every
+// Bake, serially: BakeEngine.cpp:348-356 — 98 ms of a 160 ms one-shot bake of BASELINE configs[2]'s terrain here, before this).
+static std::mutex g_table_mutex;
+static std::shared_ptr<const std::vector<float>> g_table;       // 3 floats per entry; grown by replacement, never in place:
+                                                                // a bake that is still uploading from an older one keeps it alive
+static std::shared_ptr<const std::vector<float>> hemisphere_table(uint64_t count)
+{
+    std::lock_guard<std::mutex> lock(g_table_mutex);
+    const uint64_t have = g_table ? g_table->size() / 3 : 0;
+    if (count > have) {
+        auto grown = std::make_shared<std::vector<float>>(3 * count);
+        if (have) memcpy(grown->data(), g_table->data(), sizeof(float) * 3 * have);
+        const uint64_t todo = count - have;
+        unsigned threads = std::thread::hardware_concurrency();
+        if (threads < 1) threads = 1;
+        if (threads > 32) threads = 32;
+        if (todo < 65536) threads = 1;
+        std::vector<std::thread> pool;
+        float* out = grown->data();
+        for (unsigned t = 1; t < threads; t++)
+            pool.emplace_back(hemisphere_entries, out, have + todo * t / threads, have + todo * (t + 1) / threads);
+        hemisphere_entries(out, have, have + todo / threads);
+        for (auto& th : pool) th.join();
+        g_table = grown;
+    }
+    return g_table;
 }
 
 static int validate_options(const AobOptions* o)
@@ -110,6 +152,7 @@ static void free_bake(AobBake* b)
     // buffers that were allocated (or re-allocated: the surfel lists of overlapping sections can outgrow W*H) on their own
     for (auto& m : b->materials) {
         release_device(b, m.prev_layer); release_device(b, m.surfels); release_device(b, m.section_index); release_device(b, m.frames); release_device(b, m.perm);
+        release_device(b, m.tile_cuts);
         if (m.tile_row_prefix_host) hipHostFree(m.tile_row_prefix_host);
     }
     release_device(b, b->gstack);
@@ -217,6 +260,27 @@ int aob_init(const AobDeviceConfig* config)
     g_device = dev;
     g_initialised = true;
     g_process_device.store(dev);
+    // the first time on this device: one throw-away bake of a triangle (include/aobaker.h, AOB_INIT_NO_WARMUP)
+    static std::atomic<uint64_t> warmed[4];            // one bit per device ordinal
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(config && (config->flags & AOB_INIT_NO_WARMUP)) && dev < 256 && !(warmed[dev >> 6].fetch_or(bit) & bit)) {
+        const float pos[9] = { 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f }, nrm[9] = { 0.f, 1.f, 0.f, 0.f, 1.f, 0.f, 0.f, 1.f, 0.f };
+        const float uv[6] = { 0.1f, 0.1f, 0.9f, 0.1f, 0.1f, 0.9f };
+        const uint32_t idx[3] = { 0u, 1u, 2u };
+        AobMeshDesc mesh; memset(&mesh, 0, sizeof mesh);
+        mesh.positions = pos; mesh.normals = nrm; mesh.uvs = uv; mesh.position_stride = 12; mesh.normal_stride = 12; mesh.uv_stride = 8;
+        mesh.indices = idx; mesh.vertex_count = 3; mesh.index_count = 3; mesh.material = 0;
+        mesh.model[0] = mesh.model[5] = mesh.model[10] = mesh.model[15] = 1.0f;
+        uint8_t texels[16 * 16];
+        AobMaterialDesc mat; memset(&mat, 0, sizeof mat);
+        mat.width = 16; mat.height = 16; mat.channels = 1; mat.bytes_per_channel = 1; mat.data = texels;
+        AobSceneDesc scene; memset(&scene, 0, sizeof scene);
+        scene.meshes = &mesh; scene.mesh_count = 1; scene.materials = &mat; scene.material_count = 1;
+        AobOptions o; aob_default_options(&o);
+        o.sample_count = 16; o.sampler = AOB_SAMPLER_COSINE;      // (no hemisphere table to fill)
+        const int rc = aob_bake(&scene, &o, nullptr);
+        if (rc != AOB_OK) { warmed[dev >> 6].fetch_and(~bit); g_initialised = false; g_process_device.store(-1); return rc; }
+    }
     return AOB_OK;
 }
 
@@ -354,6 +418,12 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
         plan.want(&d.section_index, cells);
         plan.want(&d.frames, 4 * cells);
         plan.want(&d.perm, cells);
+        // a cut per 64-surfel tile of a trace launch (any-hit walk of the quantised 4-ary nodes with the COSINE sampler, trace.hip):
+        // every section's last tile may be ragged, hence one tile of slack per mesh; lists that outgrow it are re-allocated
+        if (options->use_any_hit && options->sampler == AOB_SAMPLER_COSINE && options->bvh_quantised && options->bvh_width == 4) {
+            d.tile_cut_capacity = (cells / 64 + scene->mesh_count + 1) * 32;
+            plan.want(&d.tile_cuts, 4 * d.tile_cut_capacity);
+        }
         const uint64_t tiles_x = (uint64_t)(d.width + 7) / 8, tiles_y = (uint64_t)(d.height + 7) / 8;
         plan.want(&d.tile_sums, (tiles_x * tiles_y * 64 + 2047) / 2048 + 1);
         plan.want(&d.tile_row_prefix, tiles_y + 1);
@@ -394,11 +464,10 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
     AOB_CH(hipMemcpyAsync(b->hidden_from_others, bits.data(), sizeof(uint32_t) * bits.size(), hipMemcpyHostToDevice, b->stream));
     for (auto& d : b->materials)
         AOB_CH(hipMemsetAsync(d.results, 0, sizeof(AobResult) * (uint64_t)d.width * d.height, b->stream));
-    std::vector<float> table;
+    std::shared_ptr<const std::vector<float>> table;                // (held until the stream has drained, below)
     if (b->hemisphere_entries) {
-        table.resize(3 * b->hemisphere_entries);
-        hemisphere_table(table.data(), b->hemisphere_entries);
-        AOB_CH(hipMemcpyAsync(b->hemisphere, table.data(), sizeof(float) * table.size(), hipMemcpyHostToDevice, b->stream));
+        table = hemisphere_table(b->hemisphere_entries);
+        AOB_CH(hipMemcpyAsync(b->hemisphere, table->data(), sizeof(float) * 3 * b->hemisphere_entries, hipMemcpyHostToDevice, b->stream));
     }
     AOB_CH(hipEventRecord(b->ev[1], b->stream));
     AOB_CH(hipStreamSynchronize(b->stream));

@@ -63,6 +63,22 @@ __device__ __forceinline__ uint4 as_uint4(v4u v) { return make_uint4(v.x, v.y, v
 #define AOB_VISIT_BRANCHLESS 1
 #endif
 
+#ifndef AOB_TRACE_CUT
+#define AOB_TRACE_CUT 1            // tile cuts (k_tile_cuts + the entry phase of k_trace); 0 builds the walk from the root, for A/B runs
+#endif
+#ifndef AOB_CUT_ENTRIES
+#define AOB_CUT_ENTRIES 32         // entries a tile's cut may hold (<= kCutMax, the record's capacity and the width of a ray's mask)
+#endif
+#ifndef AOB_CUT_ORDER
+#define AOB_CUT_ORDER 0            // 0: a ray walks the entries it entered deepest (nearest to the tile) first; 1: shallowest first
+#endif
+#ifndef AOB_CUT_PREFETCH
+#define AOB_CUT_PREFETCH 0         // 1: the entry phase fetches the next four boxes while it tests the current four
+#endif
+#ifndef AOB_CUT_SCALAR
+#define AOB_CUT_SCALAR 0           // CUT mode: scalar steps after a refill, from the node its first ray starts on
+#endif
+
 #ifndef AOB_TRACE_STATS
 #define AOB_TRACE_STATS 0          // diagnostic build (tools/build_variants.py stats=-DAOB_TRACE_STATS=1): loop counters in g_trace_stats
 #endif
@@ -112,7 +128,97 @@ struct TraceParams {
     int32_t refill_idle;           // lanes without a ray that trigger the refill section
     int32_t leaf_wait;             // lanes parked at a leaf that trigger the leaf section
     uint32_t scalar_min;           // lanes on one node that make a scalar step (refill section) worth its pass
+    const uint32_t* tile_cuts;     // CUT: kCutWords words per tile of [begin, end) (k_tile_cuts: kCutMax refs, then kCutMax x 3 plane words), or null
 };
+
+// ---- tile cuts (CUT mode of k_trace) ----
+// The rays of one tile (64 neighbouring surfels) all start inside one chain of nodes, and each of them tests that chain's boxes
+// on its way down only to find itself inside them.  A CUT of the tree for a tile is a list of child slots {ref, box} that every
+// root-to-leaf path crosses exactly once: breadth first from the root's four slots, every inner slot whose box meets the tile's
+// box (the surfels' positions, a ray bias wider) is replaced by its own slots while the list fits kCutMax entries — what is left
+// is the chain's SIBLINGS at every level plus whatever the chain ends in.  A new ray tests the boxes of all entries when it is
+// GENERATED — all 64 lanes busy, the boxes in scalar registers, no stack, no vector memory — and starts its walk below the
+// entries it entered (a 32-bit mask in its queue record).  Child boxes are nested in their parent's on the quantisation grid and
+// the slab test is monotone in the planes (an fma with the ray's constants), so a slot whose ancestor fails the test fails it
+// too: the triangles a ray reaches are exactly those of the walk from the root, whatever the cut (the oracle's orc_tile_cut /
+// orc_cut_walk count it; tools/measure_tile_cuts.py).  Any hit only: the order of the walk differs, the answer cannot.
+static constexpr int kCutMax = 32;
+static constexpr int kCutWords = 4 * kCutMax;      // per tile: ref[kCutMax], then {x, y, z plane words}[kCutMax] (a box as in AobBvh4QNode)
+static constexpr int kCutList = 128;               // working list of k_tile_cuts (4 + 4 per expansion)
+static constexpr uint32_t kEmptyPlanes = 0x8000ffffu;   // an empty slot's inverted box (bvh_build.hip k_emit_nodes4q); here: end of the list
+
+__global__ __launch_bounds__(64)
+void k_tile_cuts(const float4* __restrict__ frames, uint64_t begin, uint64_t end, const uint4* __restrict__ nodes4q,
+                 const float* __restrict__ quant_frame, uint32_t node_count, float margin, uint32_t* __restrict__ out)
+{
+    __shared__ uint4 list[kCutList];
+    __shared__ uint32_t dead[kCutList];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t k = begin + (uint64_t)blockIdx.x * 64u + lane;       // one wavefront per tile, lane = surfel
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    if (k < end) {
+        const float4 a = frames[4ull * k], d = frames[4ull * k + 3];
+        if (__float_as_uint(d.z) != 0u) { lo[0] = hi[0] = a.x; lo[1] = hi[1] = a.y; lo[2] = hi[2] = a.z; }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { lo[q] = fminf(lo[q], __shfl_xor(lo[q], off)); hi[q] = fmaxf(hi[q], __shfl_xor(hi[q], off)); }
+    // the tile's box in units of the quantisation grid (a stored plane q sits at origin + q * scale)
+    float glo[3], ghi[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const float o = quant_frame[q], sc = quant_frame[3 + q];
+        glo[q] = sc > 0.0f ? ((lo[q] - margin) - o) / sc : -INFINITY;
+        ghi[q] = sc > 0.0f ? ((hi[q] + margin) - o) / sc : INFINITY;
+    }
+    // wave-uniform control flow; lanes 0..3 fetch the four slots of the node that is opened
+    int n = 0, live = 0;
+    auto open = [&](uint32_t node) {
+        uint4 c = make_uint4(0u, 0u, 0u, 0u);
+        bool there = false;
+        if (lane < 4u) { c = nodes4q[4ull * node + lane]; there = !(c.x == kEmptyPlanes && c.y == kEmptyPlanes && c.z == kEmptyPlanes); }
+        const uint64_t m = __ballot(there);
+        const int kids = __popcll(m);
+        if (there) {
+            const int at = n + __popcll(m & ((1ull << lane) - 1ull));
+            list[at] = make_uint4(c.w, c.x, c.y, c.z);
+            dead[at] = 0u;
+        }
+        n += kids; live += kids;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    };
+    if (node_count) {
+        open(0u);
+        for (int e = 0; e < n; e++) {
+            const uint4 en = list[e];
+            if (en.x & 0x80000000u) continue;                          // a leaf or a pair
+            const float x0 = (float)(en.y & 0x7fffu), x1 = (float)((en.y >> 16) & 0x7fffu), y0 = (float)(en.z & 0x7fffu), y1 = (float)((en.z >> 16) & 0x7fffu),
+                        z0 = (float)(en.w & 0x7fffu), z1 = (float)((en.w >> 16) & 0x7fffu);
+            if (!(x0 <= ghi[0] && x1 >= glo[0] && y0 <= ghi[1] && y1 >= glo[1] && z0 <= ghi[2] && z1 >= glo[2])) continue;
+            bool there = false;
+            if (lane < 4u) { const uint4 c = nodes4q[4ull * en.x + lane]; there = !(c.x == kEmptyPlanes && c.y == kEmptyPlanes && c.z == kEmptyPlanes); }
+            const int kids = __popcll(__ballot(there));
+            if (live - 1 + kids > AOB_CUT_ENTRIES || n + kids > kCutList) continue;
+            if (lane == 0u) dead[e] = 1u;
+            live--;
+            open(en.x);
+        }
+    }
+    // compact in list order; unused entries end the list with an empty slot's planes
+    uint32_t* dst = out + (uint64_t)blockIdx.x * kCutWords;
+    int m = 0;
+    auto put = [&](int at, uint4 en) { dst[at] = en.x; dst[kCutMax + 3 * at] = en.y; dst[kCutMax + 3 * at + 1] = en.z; dst[kCutMax + 3 * at + 2] = en.w; };
+    for (int base = 0; base < n; base += 64) {
+        const int e = base + (int)lane;
+        const bool keep = e < n && dead[e] == 0u;
+        const uint64_t km = __ballot(keep);
+        if (keep) put(m + __popcll(km & ((1ull << lane) - 1ull)), list[e]);
+        m += __popcll(km);
+    }
+    if ((int)lane >= m && lane < (uint32_t)kCutMax) put((int)lane, make_uint4(0x80000000u, kEmptyPlanes, kEmptyPlanes, kEmptyPlanes));
+}
 
 // One slab test of the any-hit walk over quantised 4-ary nodes: two v_perm_b32 per axis build the near and the far plane's float
 // (byte selectors per ray: min for rays that travel up the axis, max for rays that travel down it), (t_near, t_far) = (f_near, f_far)
@@ -175,8 +281,13 @@ void k_trace(TraceParams p)
     // (QUANTISED sums are the reference's int32 cells: 4-byte sums are the same arithmetic, and free two or three entries more)
     typedef typename std::conditional<ACCUM == AOB_ACCUMULATE_QUANTISED, unsigned int, unsigned long long>::type acc_t;
     __shared__ acc_t acc[COUNT32 ? 1 : kWave][TOTAL_ONLY ? 1 : 2];
-    __shared__ uint32_t miss_count[COUNT32 ? kWave : 1];
-    __shared__ uint4 queue[kWave * 2];                  // ray queue: {dir.xyz, slot}, {1/dir.xyz, weight}
+    // CUT: the rays start below their tile's cut (k_tile_cuts).  Unit weights leave the queue record's weight word to the mask of
+    // the entries a ray entered; the miss counters shrink to 16 bits (a part is at most 65 535 samples: trace_range) and the
+    // 128 bytes they free hold the entries' refs.
+    constexpr bool CUT = AOB_TRACE_CUT && QUANT == 2 && ANYHIT && SAMPLER == AOB_SAMPLER_COSINE;
+    __shared__ uint32_t miss_count[COUNT32 ? (CUT ? kWave / 2 : kWave) : 1];
+    __shared__ uint32_t cut_refs[CUT ? kCutMax : 1];
+    __shared__ uint4 queue[kWave * 2];                  // ray queue: {dir.xyz, slot}, {1/dir.xyz, weight — CUT: the ray's entry mask}
 
     const uint32_t lane = threadIdx.x;
 #if AOB_TRACE_STATS
@@ -195,7 +306,7 @@ void k_trace(TraceParams p)
     // the quantised 4-ary nodes as a raw buffer (base in SGPRs, 4 GiB window: 64 Mi nodes — trace_range checks the count)
     const __amdgpu_buffer_rsrc_t nodes_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.nodes4q, 0, 0xffffffff, 0x00020000);
     // any hit: the rays of a refill start together and visit the top of the tree together, in the refill section
-    constexpr bool SCALAR_STEPS = QUANT == 2 && ANYHIT;
+    constexpr bool SCALAR_STEPS = QUANT == 2 && ANYHIT && (!CUT || AOB_CUT_SCALAR);
     // lanes on one node that make a scalar step worth its pass: all but two of a refill's rays (p.scalar_min; measured on BASELINE
     // configs[2] at 42 rays per refill: 16 / 24 / 32 / 40 / 48 lanes -> 73.3 / 71.9 / 71.2 / 70.9 / 72.4 ms; the root alone 71.8, none 73.9)
     const uint32_t kScalarMin = p.scalar_min;
@@ -243,9 +354,18 @@ void k_trace(TraceParams p)
     const uint64_t wave_first = p.begin + (uint64_t)tile * kWave;            // first surfel of this unit
     const uint32_t nsurf = (uint32_t)min((uint64_t)kWave, p.end - wave_first);
 
-    if (COUNT32) miss_count[lane] = 0u;
+    if (COUNT32) { if (!CUT || lane < kWave / 2) miss_count[lane] = 0u; }
     else { acc[lane][0] = 0; if (!TOTAL_ONLY) acc[lane][1] = 0; }
     lds_stack[lane] = kInvalid;      // entry 0: the INVALID sentinel (intersect_bvh2_lds.cl:103): a pop is one read
+    // CUT: this tile's cut — the boxes stay in memory (scalar loads where they are tested), the refs go to LDS
+    const bool cut_on = CUT && p.tile_cuts != nullptr;
+    const uint32_t* tile_cut = cut_on ? p.tile_cuts + (uint64_t)kCutWords * tile : nullptr;
+    if (cut_on && lane < (uint32_t)kCutMax) cut_refs[lane] = tile_cut[lane];
+    // (entries in use: the list ends with an empty slot's planes; entry e of n is bit n - 1 - e of a ray's mask)
+    uint32_t cut_count = 0;
+    if (cut_on) cut_count = (uint32_t)__popcll(__ballot(lane < (uint32_t)kCutMax && tile_cut[kCutMax + 3u * (lane & (kCutMax - 1))] != kEmptyPlanes));
+    cut_count = (cut_count + 3u) & ~3u;               // tested four at a time
+    const uint32_t cut_shift = 32u - cut_count;       // clz(mask bit of entry e) = 32 - n + e
 
 
     // ---- the generator: lane = surfel; sample `gen_next` of every surfel is made in one go ----
@@ -310,7 +430,8 @@ void k_trace(TraceParams p)
             // r is 0 or 1: the sample adds its weight to the weight sum and, if unoccluded, to the total
             // ((1.0f * w) * 255.0f == w * 255.0f exactly).  Unit weights: the weight sum is the sample count (epilogue).
             if (UNITW) {
-                if (addr == kInvalid) atomicAdd(&miss_count[slot], 1u);
+                if (CUT) { if (addr == kInvalid) atomicAdd(&miss_count[slot >> 1], 1u << ((slot & 1u) << 4)); }
+                else if (addr == kInvalid) atomicAdd(&miss_count[slot], 1u);
             } else {
                 const long long cW = ACCUM == AOB_ACCUMULATE_QUANTISED ? (long long)ftoi(w * 255.0f) : f2fix(w);
                 atomicAdd(&acc[slot][1], (acc_t)cW);
@@ -449,6 +570,29 @@ void k_trace(TraceParams p)
                         if (!ANYHIT) closest_t = p.tmax;            // any hit: the bound never moves off tmax, no register for it
                         spa = sp_first;
                         addr = 0;
+                        if (cut_on) {
+                            // the walk starts below the entries the ray entered: the last of the list (the deepest, nearest to the tile)
+                            // first, the others deferred on the stack in list order.  Bit 0 of the mask is the list's last entry.
+                            uint32_t m = e1.w;
+#if AOB_TRACE_STATS
+                            { unsigned long long bits_ = __popc(m); for (int off = 32; off > 0; off >>= 1) bits_ += __shfl_xor(bits_, off); if (lane == (uint32_t)__builtin_ctzll(__ballot(true))) st_[9] += bits_; }
+#endif
+#if AOB_CUT_ORDER
+                            while (m) {
+                                const uint32_t lb = (uint32_t)__builtin_ctz(m);
+                                push(cut_refs[31u - lb - cut_shift]);
+                                m &= m - 1u;
+                            }
+#else
+                            while (m) {
+                                const uint32_t hb = (uint32_t)__clz((int)m);
+                                push(cut_refs[hb - cut_shift]);
+                                m &= ~(0x80000000u >> hb);
+                            }
+#endif
+                            addr = pop();
+                            if (addr == kInvalid) finish();          // no box entered: the ray misses (so does every ray of an empty scene)
+                        } else
                         if (p.node_count == 0) { addr = kInvalid; finish(); }      // empty scene: every ray misses
                     }
                     const uint32_t taken = min((uint32_t)__popcll(idle_m), q_count);
@@ -479,9 +623,63 @@ void k_trace(TraceParams p)
                                          fmaf(h.z, Z.z, fmaf(h.y, N.z, h.x * X.z)));                       // GenerateRays:46
                     const float gw = SAMPLER == AOB_SAMPLER_REFERENCE_COMPAT ? dot(N, d) : 1.0f;
                     const uint32_t pos = (q_head + __builtin_amdgcn_mbcnt_hi((uint32_t)(valid_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)valid_m, 0u))) & (kWave - 1u);
+                    const f3 gi = make_f3(safe_inv1(d.x), safe_inv1(d.y), safe_inv1(d.z));
                     queue[pos * 2] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), lane);
-                    queue[pos * 2 + 1] = make_uint4(__float_as_uint(safe_inv1(d.x)), __float_as_uint(safe_inv1(d.y)), __float_as_uint(safe_inv1(d.z)),
-                                                    __float_as_uint(gw));
+                    uint32_t entry_mask = 0u;
+                    if (cut_on) {
+                        AOB_STAT(8, cut_count);
+                        // the new ray against its tile's cut, now, while every lane has a ray: the ray as the pop sets it up (same
+                        // expressions, same values), each entry's planes by scalar loads, the walk's own slab test
+                        const f3 go = make_f3(fmaf(d.x, p.bias, a.x), fmaf(d.y, p.bias, a.y), fmaf(d.z, p.bias, a.z));
+                        f3 ox = make_f3(-go.x * gi.x, -go.y * gi.y, -go.z * gi.z);
+                        ox = make_f3(fmaf(q_origin.x, gi.x, ox.x), fmaf(q_origin.y, gi.y, ox.y), fmaf(q_origin.z, gi.z, ox.z));
+                        f3 iv = make_f3(q_scale.x * gi.x, q_scale.y * gi.y, q_scale.z * gi.z);
+                        iv = make_f3(iv.x * p.inv_tmax, iv.y * p.inv_tmax, iv.z * p.inv_tmax);
+                        ox = make_f3(ox.x * p.inv_tmax, ox.y * p.inv_tmax, ox.z * p.inv_tmax);
+                        constexpr uint32_t kLow = 0x0701000cu, kHigh = 0x0703020cu;
+                        const uint3 ns = make_uint3((__float_as_uint(gi.x) >> 31) ? kHigh : kLow, (__float_as_uint(gi.y) >> 31) ? kHigh : kLow, (__float_as_uint(gi.z) >> 31) ? kHigh : kLow);
+                        const uint3 fs = make_uint3(ns.x ^ (kLow ^ kHigh), ns.y ^ (kLow ^ kHigh), ns.z ^ (kLow ^ kHigh));
+                        typedef const __attribute__((address_space(4))) uint32_t* const_words;
+                        // (four entries per scalar fetch; the list is padded to a multiple of four with empty slots, which no ray enters)
+                        // mask = 2 * mask + (the ray enters the box): the compare's carry goes in with one v_addc_co_u32
+                        auto shift_in = [&](const uint4& bx) {
+                            float tn;
+                            const bool h = slab4q_anyhit(bx, iv, ox, ns, fs, tn);
+                            asm("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(entry_mask) : "s"(__ballot(h)) : "vcc");
+                        };
+#if AOB_CUT_PREFETCH
+                        {
+                            const uint32_t* eg = tile_cut + kCutMax;
+                            asm volatile("" : "+s"(eg));
+                            const_words ew = (const_words)eg;
+                            uint32_t w0 = ew[0], w1 = ew[1], w2 = ew[2], w3 = ew[3], w4 = ew[4], w5 = ew[5], w6 = ew[6], w7 = ew[7], w8 = ew[8], w9 = ew[9], w10 = ew[10], w11 = ew[11];
+                            for (uint32_t e = 0; e < cut_count; e += 4u) {
+                                // (the record is followed by the next tile's: the fetch past this list's end reads valid memory)
+                                eg += 12;
+                                asm volatile("" : "+s"(eg));
+                                ew = (const_words)eg;
+                                const uint32_t x0 = ew[0], x1 = ew[1], x2 = ew[2], x3 = ew[3], x4 = ew[4], x5 = ew[5], x6 = ew[6], x7 = ew[7], x8 = ew[8], x9 = ew[9], x10 = ew[10], x11 = ew[11];
+                                shift_in(make_uint4(w0, w1, w2, 0u));
+                                shift_in(make_uint4(w3, w4, w5, 0u));
+                                shift_in(make_uint4(w6, w7, w8, 0u));
+                                shift_in(make_uint4(w9, w10, w11, 0u));
+                                w0 = x0; w1 = x1; w2 = x2; w3 = x3; w4 = x4; w5 = x5; w6 = x6; w7 = x7; w8 = x8; w9 = x9; w10 = x10; w11 = x11;
+                            }
+                        }
+#else
+                        for (uint32_t e = 0; e < cut_count; e += 4u) {
+                            const uint32_t* eg = tile_cut + kCutMax + 3u * e;
+                            asm volatile("" : "+s"(eg));
+                            const const_words ew = (const_words)eg;
+                            shift_in(make_uint4(ew[0], ew[1], ew[2], 0u));
+                            shift_in(make_uint4(ew[3], ew[4], ew[5], 0u));
+                            shift_in(make_uint4(ew[6], ew[7], ew[8], 0u));
+                            shift_in(make_uint4(ew[9], ew[10], ew[11], 0u));
+                        }
+#endif
+                    }
+                    queue[pos * 2 + 1] = make_uint4(__float_as_uint(gi.x), __float_as_uint(gi.y), __float_as_uint(gi.z),
+                                                    cut_on ? entry_mask : __float_as_uint(gw));
                 }
                 q_count = n_valid;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the queue writes land before other lanes read them
@@ -497,7 +695,17 @@ void k_trace(TraceParams p)
                 // which is what lets the compiler use scalar loads; its address passes an empty asm so that the loads stay here)
                 typedef const __attribute__((address_space(4))) uint32_t* const_words;
                 uint32_t a0 = 0u;
-                for (int step = 0; step < 24; step++) {
+                int steps = 24;
+                if (CUT) {
+                    // (the rays start below their tile's cut: the first step is where the first of them starts, if enough others do)
+                    const uint64_t in_m = __ballot(addr < leaf_base);
+                    if (in_m == 0ull) steps = 0;
+                    else {
+                        a0 = (uint32_t)__builtin_amdgcn_readlane((int)addr, (int)__builtin_ctzll(in_m));
+                        if ((uint32_t)__popcll(__ballot(addr == a0)) < kScalarMin) steps = 0;
+                    }
+                }
+                for (int step = 0; step < steps; step++) {
                     const uint4* ng = p.nodes4q + 4ull * a0;
                     asm volatile("" : "+s"(ng));
                     const const_words nw = (const_words)ng;
@@ -647,7 +855,7 @@ void k_trace(TraceParams p)
     // hit: misses and samples counted), or — fractions — to 64-bit accumulators that are rounded once after the launch.
     if (valid) {
         const float4 d = p.frames[4ull * (wave_first + lane) + 3];
-        const long long sT = COUNT32 ? (long long)miss_count[lane] * kUnit : (long long)acc[lane][0];
+        const long long sT = COUNT32 ? (long long)(CUT ? (miss_count[lane >> 1] >> ((lane & 1u) << 4)) & 0xffffu : miss_count[lane]) * kUnit : (long long)acc[lane][0];
         const long long sW = UNITW ? (long long)(gen_end - gen_begin) * kUnit : (long long)acc[lane][TOTAL_ONLY ? 0 : 1];
         AobResult* cell = p.results + __float_as_uint(d.x);
         if (p.parts > 1u) {
@@ -761,7 +969,9 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
     } else if (begin < end) {
         // a lane's stack holds the sentinel plus at most one deferred sibling per tree level
         // (the 4-ary walk defers up to three children per 4-ary level)
-        const uint32_t need = (o.bvh_quantised && o.bvh_width == 4) ? 3u * ((b->bvh_depth + 2) / 2) + 2u : b->bvh_depth + 2;
+        // (a walk that starts below a tile cut holds, besides, up to kCutMax start refs)
+        const bool cut = AOB_TRACE_CUT && o.bvh_quantised && o.bvh_width == 4 && o.use_any_hit && o.sampler == AOB_SAMPLER_COSINE && b->node_count > 0;
+        const uint32_t need = ((o.bvh_quantised && o.bvh_width == 4) ? 3u * ((b->bvh_depth + 2) / 2) + 2u : b->bvh_depth + 2) + (cut ? (uint32_t)kCutMax : 0u);
         // 8, 10 or 11 stack entries per lane live in LDS (2 KB + 1 KB of sums, 2.5 KB + 512 B of totals, or 2.75 KB + 256 B of counters, + 2 KB of queued
         // rays per wavefront = 32 wavefronts per CU); deeper entries — rare — go to an HBM array.
         const uint32_t in_lds = (uint32_t)lds_stack_entries(o.sampler, o.use_any_hit, o.accumulate);
@@ -871,6 +1081,22 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
                 b->gstack_words = words;
             }
             p.gstack = b->gstack;
+            p.tile_cuts = nullptr;
+            // (16-bit miss counters: a part of at most 65 535 samples)
+            if (cut && (uint32_t)o.sample_count / p.parts <= 65535u - 1u) {
+                // the cuts of this launch's tiles (a wavefront per tile; kCutMax entries of four words each)
+                const uint64_t entries = ((uint64_t)p.ntiles + 1u) * kCutMax;      // (one record of slack: the entry phase may fetch 48 bytes past a list)
+                if (entries > m.tile_cut_capacity) {
+                    AOB_HIP(hipStreamSynchronize(s));
+                    release_device(b, m.tile_cuts);
+                    m.tile_cuts = nullptr; m.tile_cut_capacity = 0;
+                    AOB_HIP(hipMalloc((void**)&m.tile_cuts, sizeof(uint32_t) * 4u * entries));
+                    m.tile_cut_capacity = entries;
+                }
+                hipLaunchKernelGGL(k_tile_cuts, dim3(p.ntiles), dim3(kWave), 0, s, m.frames, sb, se, b->nodes4q, b->quant_frame, p.node_count,
+                                   fabsf(o.ray_bias), m.tile_cuts);
+                p.tile_cuts = m.tile_cuts;
+            }
             p.self_shape = m.section_mesh[si] + 1u;
             p.self_hidden = (b->meshes[m.section_mesh[si]].flags & AOB_MESH_HIDDEN_FROM_SELF) ? 1u : 0u;
             if (o.sampler == AOB_SAMPLER_REFERENCE_COMPAT) launch_masked<AOB_SAMPLER_REFERENCE_COMPAT>(b->any_mesh_flags, o.use_any_hit, o.accumulate, quant, grid, s, p);

@@ -178,9 +178,15 @@ typedef struct AobSceneDesc {
     uint32_t               material_count;
 } AobSceneDesc;
 
+/* aob_init flags.  By default the first aob_init of a process on a device bakes a one-triangle scene there and throws it away:
+ * the library's code object is loaded, the device's context, allocator and streams have been used once, and the FIRST real
+ * Bake() costs what every later one costs (BASELINE configs[2]: 236 ms -> the 65 ms of a warm bake; the reference's Init pays
+ * its shader compiles and ~3 GB of buffers up front likewise, BakeEngine.cpp:66-212).  NO_WARMUP skips it. */
+#define AOB_INIT_NO_WARMUP 1
 typedef struct AobDeviceConfig {
     int32_t device;               /* HIP device ordinal, -1 = current device */
-    int32_t reserved[7];
+    int32_t flags;                /* AOB_INIT_* (was reserved[0]: zero keeps meaning "defaults") */
+    int32_t reserved[6];
 } AobDeviceConfig;
 
 typedef struct AobStats {

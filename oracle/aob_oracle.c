@@ -2137,6 +2137,97 @@ int orc_entry_walk(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame*
     return 0;
 }
 
+/* ---- tile cuts (trace.hip, CUT mode: k_tile_cuts + the entry phase of k_trace) ------------------------------------------
+ * The rays of one 8x8-texel tile all start inside the same chain of nodes.  A CUT of the tree for a tile is a list of child
+ * slots {ref, plane words x, y, z} such that every root-to-leaf path crosses exactly one of them: starting from the root's four
+ * slots, the first slot in list order that is an inner node whose box meets (rule 1) or contains (rule 0) the tile's box — the
+ * surfels' positions, a margin wider — is replaced by its own slots (appended), while the list fits `max_entries`.  A ray tests
+ * the boxes of ALL entries (same arithmetic as a visit) and walks the subtrees of those it enters.  Child boxes are nested in
+ * their parent's on the quantisation grid and fma is monotone in the plane, so a slot whose ancestor's test fails fails
+ * itself: the triangles a ray reaches are EXACTLY those of the walk from the root (any hit: the answer, too).
+ * orc_tile_cut returns the number of entries (4 words each). */
+int32_t orc_tile_cut(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const float lo[3], const float hi[3],
+                     int32_t max_entries, int32_t rule, uint32_t* out)
+{
+    if (count4 == 0 || max_entries < 4) return 0;
+    float glo[3], ghi[3];
+    for (int k = 0; k < 3; k++) {
+        glo[k] = fr->scale[k] > 0.0f ? (lo[k] - fr->origin[k]) / fr->scale[k] : -INFINITY;
+        ghi[k] = fr->scale[k] > 0.0f ? (hi[k] - fr->origin[k]) / fr->scale[k] : INFINITY;
+    }
+    uint32_t list[4 * 128]; uint8_t dead[128]; int n = 0, live = 0;
+    /* append the non-empty slots of `node` */
+    #define CUT_APPEND(node) do { for (int j_ = 0; j_ < 4; j_++) { const uint32_t* c_ = &nq[node].w[4 * j_]; \
+        if (c_[0] == 0x8000ffffu && c_[1] == 0x8000ffffu && c_[2] == 0x8000ffffu) continue; \
+        list[4 * n] = c_[3]; list[4 * n + 1] = c_[0]; list[4 * n + 2] = c_[1]; list[4 * n + 3] = c_[2]; dead[n] = 0; n++; live++; } } while (0)
+    CUT_APPEND(0);
+    for (int e = 0; e < n; e++) {
+        const uint32_t ref = list[4 * e];
+        if (ref & AOB_LEAF_FLAG) continue;
+        int ok = 1;
+        for (int k = 0; k < 3; k++) {
+            const float qmin = (float)(list[4 * e + 1 + k] & 0x7fffu), qmax = (float)((list[4 * e + 1 + k] >> 16) & 0x7fffu);
+            if (rule == 0) ok &= qmin <= glo[k] && qmax >= ghi[k];
+            else ok &= qmin <= ghi[k] && qmax >= glo[k];
+        }
+        if (!ok) continue;
+        int kids = 0;
+        for (int j = 0; j < 4; j++) { const uint32_t* c = &nq[ref].w[4 * j]; kids += !(c[0] == 0x8000ffffu && c[1] == 0x8000ffffu && c[2] == 0x8000ffffu); }
+        if (live - 1 + kids > max_entries || n + kids > 128) continue;
+        dead[e] = 1; live--;
+        CUT_APPEND(ref);
+    }
+    #undef CUT_APPEND
+    int m = 0;
+    for (int e = 0; e < n; e++) if (!dead[e]) { memcpy(&out[4 * m], &list[4 * e], 16); m++; }
+    return m;
+}
+
+/* The any-hit walk of a batch of rays from a tile's cut, counted: entries tested (= n_cut per ray), entries entered, inner and leaf
+ * visits below them.  `hits` must equal the plain walk's. */
+int orc_cut_walk(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const AobLeafTri* tris,
+                 const OrcRay* rays, uint64_t n, const uint32_t* cut, int32_t n_cut, OrcEntryStats* out, int32_t* hit_out)
+{
+    if (count4 == 0 || n_cut < 1 || n_cut > 64) return AOB_ERR_INVALID_ARGUMENT;
+    for (uint64_t i = 0; i < n; i++) {
+        const OrcRay* rr = &rays[i];
+        if (hit_out) hit_out[i] = 0;
+        if (rr->extra[1] == 0) continue;
+        const f3 o = f3_make(rr->o[0], rr->o[1], rr->o[2]), d = f3_make(rr->d[0], rr->d[1], rr->d[2]);
+        const float t_max = rr->o[3];
+        Ray4q r; ray4q_prepare(&r, fr, o, d, t_max, 1);
+        uint32_t stack[ORC_STACK4]; int sp = 0;
+        out->rays++;
+        for (int e = 0; e < n_cut; e++) {
+            out->entries_tested++;
+            if (ray4q_box(&r, &cut[4 * e + 1], t_max)) { stack[sp++] = cut[4 * e]; out->mask_bits++; }
+        }
+        int hit = 0;
+        while (sp > 0 && !hit) {
+            const uint32_t node = stack[--sp];
+            if (!(node & AOB_LEAF_FLAG)) {
+                out->inner_visits++;
+                int chit[4], nhit = 0;
+                for (int j = 0; j < 4; j++) { chit[j] = ray4q_box(&r, &nq[node].w[4 * j], t_max); nhit += chit[j]; }
+                if (sp + nhit > ORC_STACK4) return AOB_ERR_BVH_TOO_DEEP;
+                for (int j = 3; j >= 0; j--) if (chit[j]) stack[sp++] = nq[node].w[4 * j + 3];
+            } else {
+                const AobLeafTri* tr = &tris[node & ~(AOB_LEAF_FLAG | AOB_PAIR_FLAG)];
+                const int count = (node & AOB_PAIR_FLAG) ? 2 : 1;
+                for (int k = 0; k < count; k++) {
+                    out->leaf_visits++;
+                    const float t = intersect_triangle(o, d, f3_make(tr[k].v0[0], tr[k].v0[1], tr[k].v0[2]), f3_make(tr[k].v1[0], tr[k].v1[1], tr[k].v1[2]),
+                                                       f3_make(tr[k].v2[0], tr[k].v2[1], tr[k].v2[2]), t_max);
+                    if (t < t_max) hit = 1;
+                }
+            }
+        }
+        out->hits += (uint64_t)hit;
+        if (hit_out) hit_out[i] = hit;
+    }
+    return 0;
+}
+
 /* A top-down binned-SAH BVH2 (16 bins per axis, one triangle per leaf) in the AobBvhNode layout — the tree quality a
  * treelet-restructuring pass over the PLOC tree could approach at best.  CPU only; never built on the GPU. */
 typedef struct { uint32_t begin, end, index; } SahTask;

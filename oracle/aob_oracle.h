@@ -197,6 +197,11 @@ int orc_kary_visits(const AobBvhNode* nodes2, uint64_t node_count2, const OrcRay
 uint64_t orc_bvh_build_sah(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes, uint32_t* depth);
 /* the any-hit walk with a tile's entry list (trace.hip, ENTRY mode), counted per phase: tests/measure_entry_lists.py */
 typedef struct OrcEntryStats { uint64_t rays, hits, inner_visits, leaf_visits, entries_tested, mask_bits; } OrcEntryStats;
+/* tile cuts (trace.hip CUT mode): a cut of the 4-ary tree for a tile's box, and the any-hit walk from it, counted */
+int32_t orc_tile_cut(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const float lo[3], const float hi[3],
+                     int32_t max_entries, int32_t rule, uint32_t* out);
+int orc_cut_walk(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const AobLeafTri* tris,
+                 const OrcRay* rays, uint64_t n, const uint32_t* cut, int32_t n_cut, OrcEntryStats* out, int32_t* hit_out);
 int orc_entry_walk(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const AobLeafTri* tris,
                    const OrcRay* rays, uint64_t n, const uint32_t* entries, int32_t n_entries, OrcEntryStats* out);
 

@@ -450,6 +450,40 @@ def walk4q(nodes4q, frame, leaf_tris, rays, any_hit=True):
     return a, h
 
 
+class OrcEntryStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("rays", "hits", "inner_visits", "leaf_visits", "entries_tested", "mask_bits")]
+
+
+def tile_cut(nodes4q, frame, lo, hi, max_entries=32, rule=1):
+    """A tile's cut of the quantised 4-ary tree (trace.hip k_tile_cuts): rows of {ref, x, y, z plane words}."""
+    nodes4q = np.ascontiguousarray(nodes4q, dtype=np.uint32)
+    frame = np.ascontiguousarray(frame, dtype=np.float32)
+    lo, hi = np.ascontiguousarray(lo, dtype=np.float32), np.ascontiguousarray(hi, dtype=np.float32)
+    out = np.zeros((128, 4), dtype=np.uint32)
+    lib = load()
+    lib.orc_tile_cut.restype = C.c_int32
+    m = lib.orc_tile_cut(C.c_void_p(nodes4q.ctypes.data), C.c_uint64(len(nodes4q)), C.c_void_p(frame.ctypes.data), C.c_void_p(lo.ctypes.data),
+                         C.c_void_p(hi.ctypes.data), C.c_int32(max_entries), C.c_int32(rule), C.c_void_p(out.ctypes.data))
+    return out[:m].copy()
+
+
+def cut_walk(nodes4q, frame, leaf_tris, rays, cut):
+    """(stats, per-ray hit flags) of the any-hit walk that starts below a tile's cut."""
+    nodes4q = np.ascontiguousarray(nodes4q, dtype=np.uint32)
+    frame = np.ascontiguousarray(frame, dtype=np.float32)
+    leaf_tris, rays, cut = np.ascontiguousarray(leaf_tris), np.ascontiguousarray(rays), np.ascontiguousarray(cut, dtype=np.uint32)
+    st = OrcEntryStats()
+    hits = np.zeros(max(1, len(rays)), dtype=np.int32)
+    lib = load()
+    lib.orc_cut_walk.restype = C.c_int
+    rc = lib.orc_cut_walk(C.c_void_p(nodes4q.ctypes.data), C.c_uint64(len(nodes4q)), C.c_void_p(frame.ctypes.data), C.c_void_p(leaf_tris.ctypes.data),
+                          C.c_void_p(rays.ctypes.data), C.c_uint64(len(rays)), C.c_void_p(cut.ctypes.data), C.c_int32(len(cut)), C.byref(st),
+                          C.c_void_p(hits.ctypes.data))
+    if rc != 0:
+        raise RuntimeError(f"orc_cut_walk failed: {rc}")
+    return st, hits[:len(rays)]
+
+
 def kary_visits(nodes2, rays, levels, pairs=True, any_hit=True):
     """(stats, box tests) of a 2^levels-ary collapse of the BVH2 walked on fp32 boxes."""
     nodes2, rays = np.ascontiguousarray(nodes2), np.ascontiguousarray(rays)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tests/measure_entry_lists.py (a measurement script that uses the oracle, hence under tests/; not a test) — what a per-tile
+"""tools/measure_entry_lists.py (a measurement script: the oracle as a counter; not a test, not product code) — what a per-tile
 ENTRY LIST would take off k_trace's walk on BASELINE configs[2], counted by the CPU oracle before the kernel is built.
 
 The rays of one 8x8-texel tile all start inside the same few top nodes of the tree.  An entry list names up to 8 of those
@@ -8,7 +8,7 @@ when it is generated — all 64 lanes busy, the nodes in scalar registers — an
 children that are not entries themselves.  Counted here: inner visits of the plain walk, of the walk after the entry phase,
 entries tested and mask bits per ray.
 
-  python tests/measure_entry_lists.py [--tiles 200] [--entries 8] [--rule overlap|contain] [--out profiles/r03/entry_lists_prototype.json]
+  python tools/measure_entry_lists.py [--tiles 200] [--entries 8] [--rule overlap|contain] [--out profiles/r03/entry_lists_prototype.json]
 """
 import argparse
 import ctypes as C

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tests/measure_region_cut.py (a measurement script that uses the oracle, hence under tests/; not a test) — what a per-tile
+"""tools/measure_region_cut.py (a measurement script: the oracle as a counter; not a test, not product code) — what a per-tile
 REGION CUT would take off the walk of SHORT rays (BASELINE configs[4]: max ray distance = falloff distance 1.25), counted by the
 CPU oracle before anything is built for the GPU.
 
@@ -8,7 +8,7 @@ the surfels' positions grown by tmax + bias.  Walk the tree with R once per tile
 entered by any of the tile's rays and is dropped, the others replace their parent, until the list would outgrow `entries`.
 Every ray of the tile then starts with that list on its stack instead of the root.  Same hits, same distances (checked).
 
-  python tests/measure_region_cut.py [--instances 100] [--rock-n 64] [--atlas 2048] [--tiles 300] [--entries 8] [--out FILE]
+  python tools/measure_region_cut.py [--instances 100] [--rock-n 64] [--atlas 2048] [--tiles 300] [--entries 8] [--out FILE]
 """
 import argparse
 import ctypes as C

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tests/measure_tree_variants.py (a measurement script that uses the oracle, hence under tests/, not a test) — what a better
+"""tools/measure_tree_variants.py (a measurement script: the oracle as a counter; not a test, not product code) — what a better
 tree, a wider node or another child order would buy k_trace on BASELINE configs[2], counted by the CPU oracle on the rays of
 a pseudo-random texel subset BEFORE anything is built for the GPU (task 5 (b) and (c)).
 
@@ -7,7 +7,7 @@ k_trace is VALU-issue bound (profiles/k_trace_counters.json): what matters is bo
 per ray, not bytes.  A quantised 4-ary visit costs ~70 VALU instructions (4 x 12 for the boxes + ~22 for fetch address,
 validity, ranking, push/pop; aobaker_amd/csrc/trace.hip, ISA of k_trace<1,1,1,11,2,0>), a triangle test ~64.
 
-  python tests/measure_tree_variants.py [--one-in 1024] [--out profiles/r02/tree_variants.json]
+  python tools/measure_tree_variants.py [--one-in 1024] [--out profiles/r02/tree_variants.json]
 """
 import argparse
 import json

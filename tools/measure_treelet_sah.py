@@ -1,4 +1,4 @@
-"""tests/measure_treelet_sah.py — what re-building subtrees by binned SAH would buy (CPU, oracle only; measurement, no test).
+"""tools/measure_treelet_sah.py — what re-building subtrees by binned SAH would buy (CPU, oracle only; measurement, no test).
 
 Takes the LBVH (build_hlbvh.cl's tree) or the PLOC tree of BASELINE configs[2]'s terrain, replaces every maximal subtree of at
 most K triangles by the oracle's top-down binned-SAH tree over the same triangles (the shape a one-workgroup-per-treelet
@@ -7,7 +7,7 @@ profiles/r02/treelet_sah_prototype.json): under an LBVH top K = 128 / 512 / 2048
 model; under the PLOC top K = 16 / 64 / 512 / 4096 -> -0.3 / -1.2 / -3.2 / -5.2 %.  The gain of a SAH tree sits in the top
 levels; treelets do not reach it.
 
-  PYTHONPATH=. python tests/measure_treelet_sah.py
+  PYTHONPATH=. python tools/measure_treelet_sah.py
 """
 import json
 import os

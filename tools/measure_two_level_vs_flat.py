@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tests/measure_two_level_vs_flat.py (a measurement script that uses the oracle, hence under tests/, not a test) — node visits per ray of the flat tree vs the two-level (instanced) structure on BASELINE
+"""tools/measure_two_level_vs_flat.py (a measurement script: the oracle as a counter; not a test, not product code) — node visits per ray of the flat tree vs the two-level (instanced) structure on BASELINE
 configs[4], counted by the CPU oracle (no GPU): the measurement behind DESIGN.md §8's "instancing is flattened".
 
 Flat: one BVH over the 10 035 202 world-space triangles (what the library builds; what the reference itself does, since it
@@ -9,7 +9,7 @@ tree for the rocks (+ the ground's), the ray transformed into object space on en
 traversal discipline (traverse()), same rays: the COSINE sampler's rays of a pseudo-random subset of the 8192^2 atlas,
 max distance = falloff distance = 1.25 (configs[4]: "max-ray-distance + cosine falloff on").
 
-  python tests/measure_two_level_vs_flat.py [--spp 64] [--one-in 16384] [--out profiles/r02/two_level_vs_flat.json]
+  python tools/measure_two_level_vs_flat.py [--spp 64] [--one-in 16384] [--out profiles/r02/two_level_vs_flat.json]
 """
 import argparse
 import json

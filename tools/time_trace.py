@@ -89,7 +89,7 @@ def child(modes, reps, knobs):
                 b.clear_results(0); b.trace(0); b.sync()
                 b.lib.aob_debug_trace_stats(buf)
                 names = ("loop_iterations", "inner_sections", "inner_lanes", "leaf_sections", "leaf_lanes", "refill_sections", "pops", "generation_batches",
-                         "unused8", "unused9", "unused10", "deep_stack_visits")
+                         "cut_entries_tested", "cut_entries_entered", "unused10", "deep_stack_visits")
                 stats = {k: int(buf[i]) for i, k in enumerate(names)}
                 rays = n * spp
                 stats["per_ray"] = {"loop_iterations": round(stats["loop_iterations"] / rays, 4), "inner_visits": round(stats["inner_lanes"] / rays, 3),
