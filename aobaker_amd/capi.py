@@ -12,7 +12,7 @@ import importlib.util
 import os
 import sys
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # ---- enums (include/aobaker.h) ------------------------------------------------
 AOB_OK = 0
@@ -64,6 +64,7 @@ class AobOptions(C.Structure):
         ("trace_fine_div", C.c_int32),
         ("trace_bands", C.c_int32),
         ("trace_scalar_min", C.c_int32),
+        ("trace_cut", C.c_int32),
     ]
 
 

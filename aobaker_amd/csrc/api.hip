@@ -112,6 +112,7 @@ static int validate_options(const AobOptions* o)
     if (o->trace_refill_idle < 0 || o->trace_refill_idle > 64 || o->trace_leaf_wait < 0 || o->trace_leaf_wait > 64) { set_error("trace_refill_idle %d / trace_leaf_wait %d: must be 0 (default) or 1..64", o->trace_refill_idle, o->trace_leaf_wait); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->trace_parts < 0 || o->trace_parts > 64 || o->trace_part_min < 0 || o->trace_fine_div < 0) { set_error("trace_parts %d (0..64), trace_part_min %d, trace_fine_div %d: must not be negative", o->trace_parts, o->trace_part_min, o->trace_fine_div); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->trace_scalar_min < 0 || o->trace_scalar_min > 64) { set_error("trace_scalar_min %d: must be 0 (default) or 1..64", o->trace_scalar_min); return AOB_ERR_INVALID_ARGUMENT; }
+    if (o->trace_cut < 0 || o->trace_cut > 32 || o->trace_cut == 2 || o->trace_cut == 3) { set_error("trace_cut %d: must be 0 (default: 32 entries), 1 (off) or 4..32", o->trace_cut); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->trace_bands < 0 || o->trace_bands > 2) { set_error("trace_bands %d: must be 0 (default), 1 or 2", o->trace_bands); return AOB_ERR_INVALID_ARGUMENT; }
     if (!(o->falloff_distance > 0.0f)) { set_error("falloff_distance must be positive"); return AOB_ERR_INVALID_ARGUMENT; }
     return AOB_OK;
@@ -240,6 +241,7 @@ void aob_default_options(AobOptions* o)
     o->trace_fine_div = 8;
     o->trace_bands = 1;
     o->trace_scalar_min = 0;       // by sampler (trace.hip)
+    o->trace_cut = 0;              // tile cuts of 32 entries where they apply (trace.hip)
 }
 
 int aob_init(const AobDeviceConfig* config)
@@ -420,7 +422,7 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
         plan.want(&d.perm, cells);
         // a cut per 64-surfel tile of a trace launch (any-hit walk of the quantised 4-ary nodes with the COSINE sampler, trace.hip):
         // every section's last tile may be ragged, hence one tile of slack per mesh; lists that outgrow it are re-allocated
-        if (options->use_any_hit && options->sampler == AOB_SAMPLER_COSINE && options->bvh_quantised && options->bvh_width == 4) {
+        if (options->use_any_hit && options->sampler == AOB_SAMPLER_COSINE && options->bvh_quantised && options->bvh_width == 4 && options->trace_cut != 1) {
             d.tile_cut_capacity = (cells / 64 + scene->mesh_count + 1) * 32;
             plan.want(&d.tile_cuts, 4 * d.tile_cut_capacity);
         }

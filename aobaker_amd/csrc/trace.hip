@@ -66,17 +66,8 @@ __device__ __forceinline__ uint4 as_uint4(v4u v) { return make_uint4(v.x, v.y, v
 #ifndef AOB_TRACE_CUT
 #define AOB_TRACE_CUT 1            // tile cuts (k_tile_cuts + the entry phase of k_trace); 0 builds the walk from the root, for A/B runs
 #endif
-#ifndef AOB_CUT_ENTRIES
-#define AOB_CUT_ENTRIES 32         // entries a tile's cut may hold (<= kCutMax, the record's capacity and the width of a ray's mask)
-#endif
-#ifndef AOB_CUT_ORDER
-#define AOB_CUT_ORDER 0            // 0: a ray walks the entries it entered deepest (nearest to the tile) first; 1: shallowest first
-#endif
-#ifndef AOB_CUT_PREFETCH
-#define AOB_CUT_PREFETCH 0         // 1: the entry phase fetches the next four boxes while it tests the current four
-#endif
 #ifndef AOB_CUT_SCALAR
-#define AOB_CUT_SCALAR 0           // CUT mode: scalar steps after a refill, from the node its first ray starts on
+#define AOB_CUT_SCALAR 0           // CUT mode: scalar steps after a refill, from the node its first ray starts on (measured: slower)
 #endif
 
 #ifndef AOB_TRACE_STATS
@@ -149,7 +140,7 @@ static constexpr uint32_t kEmptyPlanes = 0x8000ffffu;   // an empty slot's inver
 
 __global__ __launch_bounds__(64)
 void k_tile_cuts(const float4* __restrict__ frames, uint64_t begin, uint64_t end, const uint4* __restrict__ nodes4q,
-                 const float* __restrict__ quant_frame, uint32_t node_count, float margin, uint32_t* __restrict__ out)
+                 const float* __restrict__ quant_frame, uint32_t node_count, float margin, int max_entries, uint32_t* __restrict__ out)
 {
     __shared__ uint4 list[kCutList];
     __shared__ uint32_t dead[kCutList];
@@ -200,7 +191,7 @@ void k_tile_cuts(const float4* __restrict__ frames, uint64_t begin, uint64_t end
             bool there = false;
             if (lane < 4u) { const uint4 c = nodes4q[4ull * en.x + lane]; there = !(c.x == kEmptyPlanes && c.y == kEmptyPlanes && c.z == kEmptyPlanes); }
             const int kids = __popcll(__ballot(there));
-            if (live - 1 + kids > AOB_CUT_ENTRIES || n + kids > kCutList) continue;
+            if (live - 1 + kids > max_entries || n + kids > kCutList) continue;
             if (lane == 0u) dead[e] = 1u;
             live--;
             open(en.x);
@@ -267,7 +258,7 @@ __device__ __forceinline__ long long f2fix(float v)
 #define AOB_TRACE_WAVES 8          // waves per SIMD the register allocator must leave room for (<= 64 VGPRs): the walk
                                    // lives on latency hiding — 27 instead of 32 wavefronts per CU cost 11 %
 #endif
-template <int SAMPLER, int ANYHIT, int ACCUM, int LDS_N, int QUANT, int MASKED>
+template <int SAMPLER, int ANYHIT, int ACCUM, int LDS_N, int QUANT, int MASKED, int CUTMODE>
 __global__ __launch_bounds__(kWave, AOB_TRACE_WAVES)
 void k_trace(TraceParams p)
 {
@@ -284,7 +275,8 @@ void k_trace(TraceParams p)
     // CUT: the rays start below their tile's cut (k_tile_cuts).  Unit weights leave the queue record's weight word to the mask of
     // the entries a ray entered; the miss counters shrink to 16 bits (a part is at most 65 535 samples: trace_range) and the
     // 128 bytes they free hold the entries' refs.
-    constexpr bool CUT = AOB_TRACE_CUT && QUANT == 2 && ANYHIT && SAMPLER == AOB_SAMPLER_COSINE;
+    constexpr bool CUT = CUTMODE != 0;
+    static_assert(!CUT || (QUANT == 2 && ANYHIT && SAMPLER == AOB_SAMPLER_COSINE), "tile cuts: any-hit walk of the quantised 4-ary nodes, unit weights");
     __shared__ uint32_t miss_count[COUNT32 ? (CUT ? kWave / 2 : kWave) : 1];
     __shared__ uint32_t cut_refs[CUT ? kCutMax : 1];
     __shared__ uint4 queue[kWave * 2];                  // ray queue: {dir.xyz, slot}, {1/dir.xyz, weight — CUT: the ray's entry mask}
@@ -358,8 +350,8 @@ void k_trace(TraceParams p)
     else { acc[lane][0] = 0; if (!TOTAL_ONLY) acc[lane][1] = 0; }
     lds_stack[lane] = kInvalid;      // entry 0: the INVALID sentinel (intersect_bvh2_lds.cl:103): a pop is one read
     // CUT: this tile's cut — the boxes stay in memory (scalar loads where they are tested), the refs go to LDS
-    const bool cut_on = CUT && p.tile_cuts != nullptr;
-    const uint32_t* tile_cut = cut_on ? p.tile_cuts + (uint64_t)kCutWords * tile : nullptr;
+    constexpr bool cut_on = CUT;
+    const uint32_t* tile_cut = cut_on ? p.tile_cuts + (uint64_t)kCutWords * tile : nullptr;     // (trace_range: never null with CUT)
     if (cut_on && lane < (uint32_t)kCutMax) cut_refs[lane] = tile_cut[lane];
     // (entries in use: the list ends with an empty slot's planes; entry e of n is bit n - 1 - e of a ray's mask)
     uint32_t cut_count = 0;
@@ -571,25 +563,18 @@ void k_trace(TraceParams p)
                         spa = sp_first;
                         addr = 0;
                         if (cut_on) {
-                            // the walk starts below the entries the ray entered: the last of the list (the deepest, nearest to the tile)
-                            // first, the others deferred on the stack in list order.  Bit 0 of the mask is the list's last entry.
+                            // the walk starts below the entries the ray entered: the first of the list (the shallowest: the big boxes
+                            // far from the tile) first, the others deferred on the stack — 51.9 -> 50.3 ms on BASELINE configs[2] against
+                            // deepest first (profiles/r04/cuts/).  Bit 0 of the mask is the list's last entry.
                             uint32_t m = e1.w;
 #if AOB_TRACE_STATS
                             { unsigned long long bits_ = __popc(m); for (int off = 32; off > 0; off >>= 1) bits_ += __shfl_xor(bits_, off); if (lane == (uint32_t)__builtin_ctzll(__ballot(true))) st_[9] += bits_; }
 #endif
-#if AOB_CUT_ORDER
                             while (m) {
                                 const uint32_t lb = (uint32_t)__builtin_ctz(m);
                                 push(cut_refs[31u - lb - cut_shift]);
                                 m &= m - 1u;
                             }
-#else
-                            while (m) {
-                                const uint32_t hb = (uint32_t)__clz((int)m);
-                                push(cut_refs[hb - cut_shift]);
-                                m &= ~(0x80000000u >> hb);
-                            }
-#endif
                             addr = pop();
                             if (addr == kInvalid) finish();          // no box entered: the ray misses (so does every ray of an empty scene)
                         } else
@@ -647,7 +632,6 @@ void k_trace(TraceParams p)
                             const bool h = slab4q_anyhit(bx, iv, ox, ns, fs, tn);
                             asm("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(entry_mask) : "s"(__ballot(h)) : "vcc");
                         };
-#if AOB_CUT_PREFETCH
                         {
                             const uint32_t* eg = tile_cut + kCutMax;
                             asm volatile("" : "+s"(eg));
@@ -666,17 +650,6 @@ void k_trace(TraceParams p)
                                 w0 = x0; w1 = x1; w2 = x2; w3 = x3; w4 = x4; w5 = x5; w6 = x6; w7 = x7; w8 = x8; w9 = x9; w10 = x10; w11 = x11;
                             }
                         }
-#else
-                        for (uint32_t e = 0; e < cut_count; e += 4u) {
-                            const uint32_t* eg = tile_cut + kCutMax + 3u * e;
-                            asm volatile("" : "+s"(eg));
-                            const const_words ew = (const_words)eg;
-                            shift_in(make_uint4(ew[0], ew[1], ew[2], 0u));
-                            shift_in(make_uint4(ew[3], ew[4], ew[5], 0u));
-                            shift_in(make_uint4(ew[6], ew[7], ew[8], 0u));
-                            shift_in(make_uint4(ew[9], ew[10], ew[11], 0u));
-                        }
-#endif
                     }
                     queue[pos * 2 + 1] = make_uint4(__float_as_uint(gi.x), __float_as_uint(gi.y), __float_as_uint(gi.z),
                                                     cut_on ? entry_mask : __float_as_uint(gw));
@@ -920,9 +893,11 @@ template <int SAMPLER, int ANYHIT, int ACCUM, int MASKED>
 static void launch_stack(int quant, dim3 grid, hipStream_t s, const TraceParams& p)
 {
     constexpr int N = lds_stack_entries(SAMPLER, ANYHIT, ACCUM);
-    if (quant == 2) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 2, MASKED>), grid, dim3(kWave), 0, s, p);
-    else if (quant == 1) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 1, MASKED>), grid, dim3(kWave), 0, s, p);
-    else hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 0, MASKED>), grid, dim3(kWave), 0, s, p);
+    constexpr bool CAN_CUT = AOB_TRACE_CUT && SAMPLER == AOB_SAMPLER_COSINE && ANYHIT;
+    if (quant == 2 && CAN_CUT && p.tile_cuts) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 2, MASKED, CAN_CUT ? 1 : 0>), grid, dim3(kWave), 0, s, p);
+    else if (quant == 2) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 2, MASKED, 0>), grid, dim3(kWave), 0, s, p);
+    else if (quant == 1) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 1, MASKED, 0>), grid, dim3(kWave), 0, s, p);
+    else hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 0, MASKED, 0>), grid, dim3(kWave), 0, s, p);
 }
 template <int SAMPLER, int ANYHIT, int MASKED>
 static void launch_acc(int accum, int quant, dim3 grid, hipStream_t s, const TraceParams& p)
@@ -970,7 +945,9 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
         // a lane's stack holds the sentinel plus at most one deferred sibling per tree level
         // (the 4-ary walk defers up to three children per 4-ary level)
         // (a walk that starts below a tile cut holds, besides, up to kCutMax start refs)
-        const bool cut = AOB_TRACE_CUT && o.bvh_quantised && o.bvh_width == 4 && o.use_any_hit && o.sampler == AOB_SAMPLER_COSINE && b->node_count > 0;
+        const bool cut = AOB_TRACE_CUT && o.bvh_quantised && o.bvh_width == 4 && o.use_any_hit && o.sampler == AOB_SAMPLER_COSINE && b->node_count > 0 &&
+                         o.trace_cut != 1;
+        const int cut_entries = o.trace_cut >= 4 ? min(o.trace_cut, kCutMax) : kCutMax;
         const uint32_t need = ((o.bvh_quantised && o.bvh_width == 4) ? 3u * ((b->bvh_depth + 2) / 2) + 2u : b->bvh_depth + 2) + (cut ? (uint32_t)kCutMax : 0u);
         // 8, 10 or 11 stack entries per lane live in LDS (2 KB + 1 KB of sums, 2.5 KB + 512 B of totals, or 2.75 KB + 256 B of counters, + 2 KB of queued
         // rays per wavefront = 32 wavefronts per CU); deeper entries — rare — go to an HBM array.
@@ -1005,11 +982,14 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
         // (round 3, with a material's sections in one launch: closest-hit scoring — no scalar steps, so nothing to gain from rays that
         // start together — is best at 16: 4 / 8 / 12 / 16 / 20 / 24 / 32 / 42 -> 187.6 / 180.7 / 179.4 / 180.0 / 182.2 / 184.3 / 196.5 / 193.0 ms on
         // configs[4]'s scene at 16 spp, 116.9 / 108.8 / 104.8 / 104.1 / 104.8 / 106.1 / 115.4 / 110.2 on the terrain; profiles/r03/roofs/closest_hit_refill.jsonl)
-        p.refill_idle = knob(o.trace_refill_idle, o.use_any_hit ? (o.sampler == AOB_SAMPLER_COSINE ? 42 : 24) : 16);
+        // (round 4: rays that start below their tile's cut have no top of the tree to share — 16 idle lanes, and 20 parked at a leaf: refill
+        // 8 / 16 / 24 / 32 / 48 -> 53.1 / 52.1 / 52.8 / 53.7 / 56.4 ms, leaf wait 16 / 20 / 28 -> 52.6 / 52.1 / 52.5 on BASELINE configs[2];
+        // profiles/r04/cuts/)
+        p.refill_idle = knob(o.trace_refill_idle, o.use_any_hit ? (o.sampler == AOB_SAMPLER_COSINE ? (cut ? 16 : 42) : 24) : 16);
         // (the leaf section: 16 parked lanes, 24 with any-hit scoring — 12 / 16 / 20 / 24 / 28 -> 59.5 / 58.3 / 57.9 / 57.7 / 57.7 ms on
         // BASELINE configs[2]; the scalar steps: since the vector-memory path is what binds the walk (profiles/r03/roofs/) a step pays
         // for 24 lanes on one node — 16 / 24 / 32 / 36 / 40 -> 56.9 / 56.6 / 56.9 / 57.2 / 57.7 ms — where round 2's kernel wanted 40)
-        p.leaf_wait = knob(o.trace_leaf_wait, o.use_any_hit ? 24 : 16);
+        p.leaf_wait = knob(o.trace_leaf_wait, o.use_any_hit ? (cut ? 20 : 24) : 16);
         // (the table sampler's rays of one refill point everywhere — a sample index means a different direction for every surfel — and
         // part ways a level or two below the root: there a step pays from 8 lanes, 2 / 4 / 6 / 8 / 12 / 24 -> 49.1 / 48.2 / 47.9 / 47.8 /
         // 48.0 / 49.6 ms on the reference's own constants; profiles/r03/roofs/knobs_other_workloads.jsonl)
@@ -1094,7 +1074,7 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
                     m.tile_cut_capacity = entries;
                 }
                 hipLaunchKernelGGL(k_tile_cuts, dim3(p.ntiles), dim3(kWave), 0, s, m.frames, sb, se, b->nodes4q, b->quant_frame, p.node_count,
-                                   fabsf(o.ray_bias), m.tile_cuts);
+                                   fabsf(o.ray_bias), cut_entries, m.tile_cuts);
                 p.tile_cuts = m.tile_cuts;
             }
             p.self_shape = m.section_mesh[si] + 1u;

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AOB_ABI_VERSION 4
+#define AOB_ABI_VERSION 5
 
 typedef enum AobStatus {
     AOB_OK = 0,
@@ -108,7 +108,7 @@ typedef struct AobOptions {
                                      node visits per ray on the 1 M-triangle terrain                                  */
     int32_t  raster_mode;         /* AOB_RASTER_*; default REFERENCE                                  */
     int32_t  raster_layers;       /* AOB_LAYERS_*; default LAST                                       */
-    /* Schedule of the fused trace kernel (trace.hip).  These seven move work between wavefronts and never change a result
+    /* Schedule of the fused trace kernel (trace.hip).  These eight move work between wavefronts and never change a result
      * cell (tests/test_gpu_parity.py::test_trace_schedule_knobs_do_not_change_results).  aob_default_options writes the
      * values measured fastest on MI355X for BASELINE configs[2]; 0 in any of them also means "that default". */
     int32_t  trace_refill_idle;   /* lanes of a wavefront without a ray that trigger the refill section: 1..64; default 0 = by
@@ -124,6 +124,12 @@ typedef struct AobOptions {
     int32_t  trace_scalar_min;    /* any-hit walk of the quantised 4-ary nodes: lanes that must stand on ONE node for it to be
                                      visited from scalar registers (after a refill): 1..64; 0 (default) = by sampler: 24
                                      with the COSINE sampler, 8 with the table sampler (its rays part ways sooner)          */
+    int32_t  trace_cut;           /* any-hit walk of the quantised 4-ary nodes with the COSINE sampler: every 8x8-texel tile gets a
+                                     CUT of the tree — the siblings of the chain of nodes its rays start inside, at most this many
+                                     entries — which a new ray tests in one go when it is generated, starting its walk below the
+                                     entries it entered instead of at the root (trace.hip k_tile_cuts).  0 (default)
+                                     = 32 entries, 4..32 = that many, 1 = off (the walk from the root).  Like the knobs above it
+                                     moves work and never changes a result cell.  (ABI 5)                                        */
 } AobOptions;
 
 /* ---- scene description ----------------------------------------------------

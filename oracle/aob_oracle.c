@@ -2186,22 +2186,25 @@ int32_t orc_tile_cut(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFram
 /* The any-hit walk of a batch of rays from a tile's cut, counted: entries tested (= n_cut per ray), entries entered, inner and leaf
  * visits below them.  `hits` must equal the plain walk's. */
 int orc_cut_walk(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const AobLeafTri* tris,
-                 const OrcRay* rays, uint64_t n, const uint32_t* cut, int32_t n_cut, OrcEntryStats* out, int32_t* hit_out)
+                 const OrcRay* rays, uint64_t n, const uint32_t* cut, int32_t n_cut, OrcEntryStats* out, int32_t* hit_out, uint64_t* mask_out)
 {
     if (count4 == 0 || n_cut < 1 || n_cut > 64) return AOB_ERR_INVALID_ARGUMENT;
     for (uint64_t i = 0; i < n; i++) {
         const OrcRay* rr = &rays[i];
         if (hit_out) hit_out[i] = 0;
+        if (mask_out) mask_out[i] = 0;
         if (rr->extra[1] == 0) continue;
         const f3 o = f3_make(rr->o[0], rr->o[1], rr->o[2]), d = f3_make(rr->d[0], rr->d[1], rr->d[2]);
         const float t_max = rr->o[3];
         Ray4q r; ray4q_prepare(&r, fr, o, d, t_max, 1);
         uint32_t stack[ORC_STACK4]; int sp = 0;
         out->rays++;
+        uint64_t entered = 0;
         for (int e = 0; e < n_cut; e++) {
             out->entries_tested++;
-            if (ray4q_box(&r, &cut[4 * e + 1], t_max)) { stack[sp++] = cut[4 * e]; out->mask_bits++; }
+            if (ray4q_box(&r, &cut[4 * e + 1], t_max)) { stack[sp++] = cut[4 * e]; out->mask_bits++; entered |= 1ull << e; }
         }
+        if (mask_out) mask_out[i] = entered;
         int hit = 0;
         while (sp > 0 && !hit) {
             const uint32_t node = stack[--sp];

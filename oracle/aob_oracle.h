@@ -201,7 +201,7 @@ typedef struct OrcEntryStats { uint64_t rays, hits, inner_visits, leaf_visits, e
 int32_t orc_tile_cut(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const float lo[3], const float hi[3],
                      int32_t max_entries, int32_t rule, uint32_t* out);
 int orc_cut_walk(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const AobLeafTri* tris,
-                 const OrcRay* rays, uint64_t n, const uint32_t* cut, int32_t n_cut, OrcEntryStats* out, int32_t* hit_out);
+                 const OrcRay* rays, uint64_t n, const uint32_t* cut, int32_t n_cut, OrcEntryStats* out, int32_t* hit_out, uint64_t* mask_out);
 int orc_entry_walk(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const AobLeafTri* tris,
                    const OrcRay* rays, uint64_t n, const uint32_t* entries, int32_t n_entries, OrcEntryStats* out);
 

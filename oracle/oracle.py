@@ -467,20 +467,23 @@ def tile_cut(nodes4q, frame, lo, hi, max_entries=32, rule=1):
     return out[:m].copy()
 
 
-def cut_walk(nodes4q, frame, leaf_tris, rays, cut):
+def cut_walk(nodes4q, frame, leaf_tris, rays, cut, want_masks=False):
     """(stats, per-ray hit flags) of the any-hit walk that starts below a tile's cut."""
     nodes4q = np.ascontiguousarray(nodes4q, dtype=np.uint32)
     frame = np.ascontiguousarray(frame, dtype=np.float32)
     leaf_tris, rays, cut = np.ascontiguousarray(leaf_tris), np.ascontiguousarray(rays), np.ascontiguousarray(cut, dtype=np.uint32)
     st = OrcEntryStats()
     hits = np.zeros(max(1, len(rays)), dtype=np.int32)
+    masks = np.zeros(max(1, len(rays)), dtype=np.uint64)
     lib = load()
     lib.orc_cut_walk.restype = C.c_int
     rc = lib.orc_cut_walk(C.c_void_p(nodes4q.ctypes.data), C.c_uint64(len(nodes4q)), C.c_void_p(frame.ctypes.data), C.c_void_p(leaf_tris.ctypes.data),
                           C.c_void_p(rays.ctypes.data), C.c_uint64(len(rays)), C.c_void_p(cut.ctypes.data), C.c_int32(len(cut)), C.byref(st),
-                          C.c_void_p(hits.ctypes.data))
+                          C.c_void_p(hits.ctypes.data), C.c_void_p(masks.ctypes.data))
     if rc != 0:
         raise RuntimeError(f"orc_cut_walk failed: {rc}")
+    if want_masks:
+        return st, hits[:len(rays)], masks[:len(rays)]
     return st, hits[:len(rays)]
 
 
@@ -525,5 +528,5 @@ def default_options():
     o.bvh_builder = 1
     o.morton_adaptive = 1
     # the schedule of the library's trace kernel (no meaning for the oracle; stated so that the two defaults compare equal)
-    o.trace_refill_idle, o.trace_leaf_wait, o.trace_parts, o.trace_part_min, o.trace_fine_div, o.trace_bands, o.trace_scalar_min = 0, 0, 4, 16, 8, 1, 0
+    o.trace_refill_idle, o.trace_leaf_wait, o.trace_parts, o.trace_part_min, o.trace_fine_div, o.trace_bands, o.trace_scalar_min, o.trace_cut = 0, 0, 4, 16, 8, 1, 0, 0
     return o

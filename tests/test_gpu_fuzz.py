@@ -66,6 +66,7 @@ def random_options(rng):
         o.trace_parts = int(rng.choice([0, 1, 3, 8])); o.trace_part_min = int(rng.choice([0, 1, 4, 16])); o.trace_fine_div = int(rng.choice([0, 1, 3, 8]))
         o.trace_bands = int(rng.integers(0, 3))
         o.trace_scalar_min = int(rng.choice([0, 1, 8, 24, 64]))
+        o.trace_cut = int(rng.choice([0, 0, 1, 4, 7, 16, 32]))
     return o
 
 

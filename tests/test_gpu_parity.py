@@ -512,11 +512,14 @@ def test_trace_schedule_knobs_do_not_change_results(engine, orc, mode):
     want = cells()
     for knobs in (dict(trace_parts=1), dict(trace_parts=8, trace_part_min=4), dict(trace_fine_div=2), dict(trace_fine_div=1000000),
                   dict(trace_refill_idle=1, trace_leaf_wait=1), dict(trace_refill_idle=64, trace_leaf_wait=64), dict(trace_bands=2),
-                  dict(trace_refill_idle=0, trace_leaf_wait=0, trace_parts=0, trace_part_min=0, trace_fine_div=0, trace_bands=0)):
+                  dict(trace_refill_idle=0, trace_leaf_wait=0, trace_parts=0, trace_part_min=0, trace_fine_div=0, trace_bands=0),
+                  dict(trace_cut=1), dict(trace_cut=4), dict(trace_cut=19), dict(trace_cut=32, trace_refill_idle=42, trace_parts=1)):
         got = cells(**knobs)
         assert np.array_equal(got["total_bits"], want["total_bits"]) and np.array_equal(got["weight_bits"], want["weight_bits"]), knobs
     with pytest.raises(capi.AobError):
         cells(trace_refill_idle=65)
+    with pytest.raises(capi.AobError):
+        cells(trace_cut=3)
 
 
 def test_invalid_arguments_are_reported(engine, orc):

@@ -60,7 +60,7 @@ def main():
     lib.orc_tile_cut.restype = C.c_int32
     lib.orc_tile_cut.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     lib.orc_cut_walk.restype = C.c_int
-    lib.orc_cut_walk.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int32, C.POINTER(OrcEntryStats), C.c_void_p]
+    lib.orc_cut_walk.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int32, C.POINTER(OrcEntryStats), C.c_void_p, C.c_void_p]
     n4q_c, frame_c, lt_c = np.ascontiguousarray(n4q, dtype=np.uint32), np.ascontiguousarray(frame, dtype=np.float32), np.ascontiguousarray(lt)
 
     # the tiles of the trace order: 8x8 texels where the atlas is fully covered, else 64 consecutive surfels of the row-major list
@@ -106,7 +106,7 @@ def main():
                 hi = np.ascontiguousarray(pos.max(axis=0) + np.float32(margin), dtype=np.float32)
                 m = lib.orc_tile_cut(n4q_c.ctypes.data, len(n4q_c), frame_c.ctypes.data, lo.ctypes.data, hi.ctypes.data, E, rule, cut.ctypes.data)
                 lengths.append(m)
-                rc = lib.orc_cut_walk(n4q_c.ctypes.data, len(n4q_c), frame_c.ctypes.data, lt_c.ctypes.data, rays.ctypes.data, len(rays), cut.ctypes.data, m, C.byref(es), None)
+                rc = lib.orc_cut_walk(n4q_c.ctypes.data, len(n4q_c), frame_c.ctypes.data, lt_c.ctypes.data, rays.ctypes.data, len(rays), cut.ctypes.data, m, C.byref(es), None, None)
                 assert rc == 0
             assert es.hits == plain.hits and es.rays == plain.rays, (es.hits, plain.hits)
             rec["cuts"].append({"rule": "meets" if rule else "contains", "max_entries": E,
