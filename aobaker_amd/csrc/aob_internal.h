@@ -58,8 +58,8 @@ struct DeviceMaterial {
     uint32_t* section_index = nullptr;    // surfel -> index inside its section's list
     float4*   frames = nullptr;           // 64 B per surfel IN TRACE (8x8 tile) ORDER: P, N, tangent X/Z, cell, table base, valid
     uint32_t* perm = nullptr;             // trace order -> row-major rank (per section)
-    uint32_t* tile_cuts = nullptr;        // 32 x 4 words per 64-surfel tile of a trace launch: the tile's cut of the tree (trace.hip k_tile_cuts)
-    uint64_t  tile_cut_capacity = 0;      // ... in entries
+    uint32_t* tile_cuts = nullptr;        // 128 words per 64-surfel tile and sample part of a trace launch: the tile's cut of the tree (trace.hip k_tile_cuts)
+    uint64_t  tile_cut_capacity = 0;      // ... in words
     uint32_t* tile_sums = nullptr;        // scan partials of the tile-order pass
     uint32_t* tile_row_prefix = nullptr;  // covered texels before each 8-texel tile row (first section)
     uint32_t* tile_row_prefix_host = nullptr;   // pinned copy

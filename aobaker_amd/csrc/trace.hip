@@ -34,6 +34,8 @@
 #include "aob_internal.h"
 #include "aob_math.h"
 
+#include <cmath>
+#include <cstring>
 #include <type_traits>
 
 namespace aob {
@@ -65,6 +67,9 @@ __device__ __forceinline__ uint4 as_uint4(v4u v) { return make_uint4(v.x, v.y, v
 
 #ifndef AOB_TRACE_CUT
 #define AOB_TRACE_CUT 1            // tile cuts (k_tile_cuts + the entry phase of k_trace); 0 builds the walk from the root, for A/B runs
+#endif
+#ifndef AOB_CUT_WEDGES
+#define AOB_CUT_WEDGES 1           // 0: every unit tests every entry of its tile's cut (A/B runs)
 #endif
 #ifndef AOB_CUT_SCALAR
 #define AOB_CUT_SCALAR 0           // CUT mode: scalar steps after a refill, from the node its first ray starts on (measured: slower)
@@ -119,7 +124,8 @@ struct TraceParams {
     int32_t refill_idle;           // lanes without a ray that trigger the refill section
     int32_t leaf_wait;             // lanes parked at a leaf that trigger the leaf section
     uint32_t scalar_min;           // lanes on one node that make a scalar step (refill section) worth its pass
-    const uint32_t* tile_cuts;     // CUT: kCutWords words per tile of [begin, end) (k_tile_cuts: kCutMax refs, then kCutMax x 3 plane words), or null
+    const uint32_t* tile_cuts;     // CUT: kCutWords words per tile of [begin, end) (k_tile_cuts), or null
+    uint32_t cut_records;          // CUT: records per tile — one per sample part (coarse parts first, then the fine ones), or 1
 };
 
 // ---- tile cuts (CUT mode of k_trace) ----
@@ -134,32 +140,57 @@ struct TraceParams {
 // too: the triangles a ray reaches are exactly those of the walk from the root, whatever the cut (the oracle's orc_tile_cut /
 // orc_cut_walk count it; tools/measure_tile_cuts.py).  Any hit only: the order of the walk differs, the answer cannot.
 static constexpr int kCutMax = 32;
-static constexpr int kCutWords = 4 * kCutMax;      // per tile: ref[kCutMax], then {x, y, z plane words}[kCutMax] (a box as in AobBvh4QNode)
+static constexpr int kCutWedges = 16;              // sample parts (coarse + fine) a tile's entries are culled for
+static constexpr int kCutLines = 8;                // distinct boundaries of those parts' azimuth wedges
+static constexpr int kCutWords = 4 * kCutMax;      // per record: ref[kCutMax], then {x, y, z plane words}[kCutMax] (a box as in AobBvh4QNode);
+                                                   // a tile has one record per sample part (CutWedges::count; one in all without culling)
 static constexpr int kCutList = 128;               // working list of k_tile_cuts (4 + 4 per expansion)
-static constexpr uint32_t kEmptyPlanes = 0x8000ffffu;   // an empty slot's inverted box (bvh_build.hip k_emit_nodes4q); here: end of the list
+static constexpr uint32_t kEmptyPlanes = 0x8000ffffu;   // an empty slot's inverted box (bvh_build.hip k_emit_nodes4q); here: an unused entry
+
+// Which entries of its tile's cut can a UNIT's rays reach at all?  A unit traces one part of the samples: with the COSINE
+// sampler's stratification that is a range of rows of the grid, i.e. of the azimuth in every surfel's own frame — rays of part
+// p of 4 leave a surfel inside one quadrant of its tangent plane.  Such a ray stays in the cone {P + a X' + b N + c Z' : a, b, c
+// >= 0} (X', Z' the wedge's two inward boundary normals): an entry whose box — grown by a margin far above the rounding of
+// any of this — lies wholly on the negative side of one of the three planes for EVERY surfel of the tile cannot be entered
+// by any ray of the unit, and the entry phase of k_trace skips it for the whole unit (a third of the entries on BASELINE
+// configs[2]; the prototype checked the entered ones against it: tools/measure_tile_cuts.py).
+struct CutWedges {
+    int32_t count;                          // wedges (0: no culling, live[0] = every entry)
+    int32_t lines;                          // distinct boundary lines
+    float line_s[kCutLines], line_c[kCutLines];      // normal of line l in the surfel's tangent plane: -s X + c Z
+    uint32_t need_pos[kCutLines];           // wedges whose cone lies on the positive side of line l ...
+    uint32_t need_neg[kCutLines];           // ... on the negative side
+};
 
 __global__ __launch_bounds__(64)
 void k_tile_cuts(const float4* __restrict__ frames, uint64_t begin, uint64_t end, const uint4* __restrict__ nodes4q,
-                 const float* __restrict__ quant_frame, uint32_t node_count, float margin, int max_entries, uint32_t* __restrict__ out)
+                 const float* __restrict__ quant_frame, uint32_t node_count, float margin, int max_entries, CutWedges W,
+                 uint32_t* __restrict__ out)
 {
     __shared__ uint4 list[kCutList];
     __shared__ uint32_t dead[kCutList];
+    __shared__ uint4 fin[kCutMax];
     const uint32_t lane = threadIdx.x;
     const uint64_t k = begin + (uint64_t)blockIdx.x * 64u + lane;       // one wavefront per tile, lane = surfel
     float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    bool valid = false;
+    f3 P = make_f3(0.f, 0.f, 0.f), N = P, X = P, Z = P;
     if (k < end) {
-        const float4 a = frames[4ull * k], d = frames[4ull * k + 3];
-        if (__float_as_uint(d.z) != 0u) { lo[0] = hi[0] = a.x; lo[1] = hi[1] = a.y; lo[2] = hi[2] = a.z; }
+        const float4 a = frames[4ull * k], b = frames[4ull * k + 1], c = frames[4ull * k + 2], d = frames[4ull * k + 3];
+        valid = __float_as_uint(d.z) != 0u;
+        P = make_f3(a.x, a.y, a.z); N = make_f3(a.w, b.x, b.y); X = make_f3(b.z, b.w, c.x); Z = make_f3(c.y, c.z, c.w);
+        if (valid) { lo[0] = hi[0] = a.x; lo[1] = hi[1] = a.y; lo[2] = hi[2] = a.z; }
     }
 #pragma unroll
     for (int q = 0; q < 3; q++)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { lo[q] = fminf(lo[q], __shfl_xor(lo[q], off)); hi[q] = fmaxf(hi[q], __shfl_xor(hi[q], off)); }
     // the tile's box in units of the quantisation grid (a stored plane q sits at origin + q * scale)
-    float glo[3], ghi[3];
+    float glo[3], ghi[3], qo[3], qs[3];
 #pragma unroll
     for (int q = 0; q < 3; q++) {
         const float o = quant_frame[q], sc = quant_frame[3 + q];
+        qo[q] = o; qs[q] = sc;
         glo[q] = sc > 0.0f ? ((lo[q] - margin) - o) / sc : -INFINITY;
         ghi[q] = sc > 0.0f ? ((hi[q] + margin) - o) / sc : INFINITY;
     }
@@ -197,18 +228,84 @@ void k_tile_cuts(const float4* __restrict__ frames, uint64_t begin, uint64_t end
             open(en.x);
         }
     }
-    // compact in list order; unused entries end the list with an empty slot's planes
-    uint32_t* dst = out + (uint64_t)blockIdx.x * kCutWords;
+    // compact in list order; unused entries hold an empty slot's planes
     int m = 0;
-    auto put = [&](int at, uint4 en) { dst[at] = en.x; dst[kCutMax + 3 * at] = en.y; dst[kCutMax + 3 * at + 1] = en.z; dst[kCutMax + 3 * at + 2] = en.w; };
+    if (lane < (uint32_t)kCutMax) fin[lane] = make_uint4(0x80000000u, kEmptyPlanes, kEmptyPlanes, kEmptyPlanes);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
     for (int base = 0; base < n; base += 64) {
         const int e = base + (int)lane;
         const bool keep = e < n && dead[e] == 0u;
         const uint64_t km = __ballot(keep);
-        if (keep) put(m + __popcll(km & ((1ull << lane) - 1ull)), list[e]);
+        if (keep) fin[m + __popcll(km & ((1ull << lane) - 1ull))] = list[e];
         m += __popcll(km);
     }
-    if ((int)lane >= m && lane < (uint32_t)kCutMax) put((int)lane, make_uint4(0x80000000u, kEmptyPlanes, kEmptyPlanes, kEmptyPlanes));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- the entries each part of the samples can reach (lane = surfel; lane w < count ends up with part w's mask) ----
+    const uint32_t every = m >= 32 ? 0xffffffffu : (1u << m) - 1u;
+    uint32_t mine = every;
+    if (W.count > 0 && m > 0) {
+        const uint32_t all_w = (1u << W.count) - 1u;
+        // a margin that dwarfs the rounding of the frames, of the sampler's sine and cosine and of the slab test itself
+        const float eps = 1e-4f * 32767.0f * fmaxf(fmaxf(qs[0], qs[1]), qs[2]);
+        // the planes that bound a part's cone of rays {a u0 + b N + c u1 : a, b, c >= 0} (u = cos X + sin Z at the wedge's two boundary
+        // azimuths): through N and a boundary direction — normal u x N, = -sin X + cos Z in an orthonormal frame, and exact also where
+        // the frame is not (normals within 0.0001 of the y axis keep X and Z on the axes, k_surfel_frames) — and the tangent plane,
+        // Z x X; all of them times the frame's handedness (X, N, Z is left-handed for those axis frames under a down-facing normal)
+        const float det = dot(cross(X, N), Z);
+        const float hand = det > 0.0f ? 1.0f : -1.0f;
+        const bool framed = valid && det != 0.0f && det == det;
+        f3 ln[kCutLines];
+#pragma unroll
+        for (int l = 0; l < kCutLines; l++) {
+            const f3 c = cross(make_f3(fmaf(W.line_s[l], Z.x, W.line_c[l] * X.x), fmaf(W.line_s[l], Z.y, W.line_c[l] * X.y), fmaf(W.line_s[l], Z.z, W.line_c[l] * X.z)), N);
+            ln[l] = make_f3(c.x * hand, c.y * hand, c.z * hand);
+        }
+        const f3 zx = cross(Z, X);
+        const f3 up = make_f3(zx.x * hand, zx.y * hand, zx.z * hand);
+        mine = 0u;
+        for (int e = 0; e < m; e++) {
+            const uint4 en = fin[e];
+            const f3 r0 = make_f3((fmaf((float)(en.y & 0x7fffu), qs[0], qo[0]) - eps) - P.x, (fmaf((float)(en.z & 0x7fffu), qs[1], qo[1]) - eps) - P.y,
+                                  (fmaf((float)(en.w & 0x7fffu), qs[2], qo[2]) - eps) - P.z);
+            const f3 r1 = make_f3((fmaf((float)((en.y >> 16) & 0x7fffu), qs[0], qo[0]) + eps) - P.x, (fmaf((float)((en.z >> 16) & 0x7fffu), qs[1], qo[1]) + eps) - P.y,
+                                  (fmaf((float)((en.w >> 16) & 0x7fffu), qs[2], qo[2]) + eps) - P.z);
+            // the largest and the smallest value of (c - P) . v over the box
+            auto most = [&](const f3& v) { return fmaxf(r0.x * v.x, r1.x * v.x) + fmaxf(r0.y * v.y, r1.y * v.y) + fmaxf(r0.z * v.z, r1.z * v.z); };
+            auto least = [&](const f3& v) { return fminf(r0.x * v.x, r1.x * v.x) + fminf(r0.y * v.y, r1.y * v.y) + fminf(r0.z * v.z, r1.z * v.z); };
+            uint32_t ok = 0u;
+            if (valid) {
+                ok = all_w;
+                if (framed) {
+                    if (!(most(up) >= 0.0f)) ok = 0u;                   // wholly below the surfel's tangent plane: no part reaches it
+#pragma unroll
+                    for (int l = 0; l < kCutLines; l++) {
+                        if (l < W.lines) {
+                            if (!(most(ln[l]) >= 0.0f)) ok &= ~W.need_pos[l];
+                            if (!(least(ln[l]) <= 0.0f)) ok &= ~W.need_neg[l];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) ok |= __shfl_xor(ok, off);
+            if ((ok >> lane) & 1u) mine |= 1u << e;
+        }
+    }
+    // one record per part: its live entries in list order, then empty slots
+    const int records = W.count > 0 ? W.count : 1;
+    for (int w = 0; w < records; w++) {
+        const uint32_t lv = W.count > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)mine, w) & every : every;
+        uint32_t* dst = out + ((uint64_t)blockIdx.x * records + w) * kCutWords;
+        if (lane < (uint32_t)kCutMax) {
+            const bool in = ((lv >> lane) & 1u) != 0u;
+            const int at = in ? __popc(lv & ((1u << lane) - 1u)) : __popc(lv) + __popc(~lv & ((1u << lane) - 1u));
+            const uint4 en = in ? fin[lane] : make_uint4(0x80000000u, kEmptyPlanes, kEmptyPlanes, kEmptyPlanes);
+            dst[at] = en.x; dst[kCutMax + 3 * at] = en.y; dst[kCutMax + 3 * at + 1] = en.z; dst[kCutMax + 3 * at + 2] = en.w;
+        }
+    }
 }
 
 // One slab test of the any-hit walk over quantised 4-ary nodes: two v_perm_b32 per axis build the near and the far plane's float
@@ -351,9 +448,10 @@ void k_trace(TraceParams p)
     lds_stack[lane] = kInvalid;      // entry 0: the INVALID sentinel (intersect_bvh2_lds.cl:103): a pop is one read
     // CUT: this tile's cut — the boxes stay in memory (scalar loads where they are tested), the refs go to LDS
     constexpr bool cut_on = CUT;
-    const uint32_t* tile_cut = cut_on ? p.tile_cuts + (uint64_t)kCutWords * tile : nullptr;     // (trace_range: never null with CUT)
+    // (one record per sample part where the entries were culled by part, k_tile_cuts)
+    const uint32_t* tile_cut = cut_on ? p.tile_cuts + (uint64_t)kCutWords * ((uint64_t)tile * p.cut_records + (p.cut_records > 1u ? (fine ? p.parts + part : part) : 0u)) : nullptr;
     if (cut_on && lane < (uint32_t)kCutMax) cut_refs[lane] = tile_cut[lane];
-    // (entries in use: the list ends with an empty slot's planes; entry e of n is bit n - 1 - e of a ray's mask)
+    // (entries in use: the list ends with empty slots' planes; entry e of n is bit n - 1 - e of a ray's mask)
     uint32_t cut_count = 0;
     if (cut_on) cut_count = (uint32_t)__popcll(__ballot(lane < (uint32_t)kCutMax && tile_cut[kCutMax + 3u * (lane & (kCutMax - 1))] != kEmptyPlanes));
     cut_count = (cut_count + 3u) & ~3u;               // tested four at a time
@@ -624,8 +722,6 @@ void k_trace(TraceParams p)
                         constexpr uint32_t kLow = 0x0701000cu, kHigh = 0x0703020cu;
                         const uint3 ns = make_uint3((__float_as_uint(gi.x) >> 31) ? kHigh : kLow, (__float_as_uint(gi.y) >> 31) ? kHigh : kLow, (__float_as_uint(gi.z) >> 31) ? kHigh : kLow);
                         const uint3 fs = make_uint3(ns.x ^ (kLow ^ kHigh), ns.y ^ (kLow ^ kHigh), ns.z ^ (kLow ^ kHigh));
-                        typedef const __attribute__((address_space(4))) uint32_t* const_words;
-                        // (four entries per scalar fetch; the list is padded to a multiple of four with empty slots, which no ray enters)
                         // mask = 2 * mask + (the ray enters the box): the compare's carry goes in with one v_addc_co_u32
                         auto shift_in = [&](const uint4& bx) {
                             float tn;
@@ -633,12 +729,14 @@ void k_trace(TraceParams p)
                             asm("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(entry_mask) : "s"(__ballot(h)) : "vcc");
                         };
                         {
+                            // four entries per pass (the list is padded to a multiple of four with empty slots, which no ray enters), the
+                            // next four fetched (scalar loads) while these are tested; the fetch past the list's end reads the next record
+                            typedef const __attribute__((address_space(4))) uint32_t* const_words;
                             const uint32_t* eg = tile_cut + kCutMax;
                             asm volatile("" : "+s"(eg));
                             const_words ew = (const_words)eg;
                             uint32_t w0 = ew[0], w1 = ew[1], w2 = ew[2], w3 = ew[3], w4 = ew[4], w5 = ew[5], w6 = ew[6], w7 = ew[7], w8 = ew[8], w9 = ew[9], w10 = ew[10], w11 = ew[11];
                             for (uint32_t e = 0; e < cut_count; e += 4u) {
-                                // (the record is followed by the next tile's: the fetch past this list's end reads valid memory)
                                 eg += 12;
                                 asm volatile("" : "+s"(eg));
                                 ew = (const_words)eg;
@@ -918,6 +1016,49 @@ static void launch_masked(int masked, int anyhit, int accum, int quant, dim3 gri
     else launch_hit<SAMPLER, 0>(anyhit, accum, quant, grid, s, p);
 }
 
+// The azimuth wedges of a launch's sample parts (k_tile_cuts): part q of n covers the samples [spp q / n, spp (q + 1) / n), i.e.
+// the rows cy0..cy1 of the COSINE sampler's sx x sy grid, whose azimuth is 2 pi (cy + jitter) / sy.  Coarse parts first, then the
+// fine ones (the units of the last tiles of every queue).  A part that reaches the unstratified samples beyond the grid, or
+// spans half the circle or more, gets no azimuth bound; more parts or boundaries than the record holds: no culling at all.
+static CutWedges cut_wedges(int32_t spp, const CosineGrid& g, uint32_t parts, uint32_t parts_fine)
+{
+    CutWedges w;
+    std::memset(&w, 0, sizeof w);
+    if (!AOB_CUT_WEDGES || parts + parts_fine > (uint32_t)kCutWedges || g.sx < 1 || g.sy < 1) return w;
+    const double pi = 3.14159265358979323846;
+    double line_angle[kCutLines];
+    auto line_of = [&](double frac) -> int {           // the line through the origin at azimuth 2 pi frac (mod pi)
+        double a = fmod(frac, 0.5);
+        if (a > 0.5 - 1e-12) a = 0.0;
+        for (int l = 0; l < w.lines; l++) if (fabs(line_angle[l] - a) < 1e-12) return l;
+        if (w.lines == kCutLines) return -1;
+        line_angle[w.lines] = a;
+        w.line_s[w.lines] = (float)sin(2.0 * pi * a); w.line_c[w.lines] = (float)cos(2.0 * pi * a);
+        return w.lines++;
+    };
+    uint32_t index = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        const uint32_t n = pass ? parts_fine : parts;
+        for (uint32_t q = 0; q < n; q++, index++) {
+            const int64_t i0 = (int64_t)spp * q / n, i1 = (int64_t)spp * (q + 1) / n;
+            if (i1 <= i0) continue;
+            const int64_t cy0 = i0 / g.sx, cy1 = (i1 - 1) / g.sx;
+            if (cy1 >= g.sy) continue;                                  // unstratified samples: any azimuth
+            const double f0 = (double)cy0 / g.sy, f1 = (double)(cy1 + 1) / g.sy;
+            if (f1 - f0 > 0.5 - 1e-9) continue;
+            // the cone lies on the positive side of the lower boundary's normal (-sin, cos)(f0) and on the negative side of the
+            // upper boundary's; a boundary in the second half of the circle is its line's normal negated
+            const int l0 = line_of(f0), l1 = line_of(f1);
+            if (l0 < 0 || l1 < 0) { std::memset(&w, 0, sizeof w); return w; }
+            const bool lo_flip = fmod(f0, 1.0) >= 0.5 - 1e-12, hi_flip = fmod(f1, 1.0) >= 0.5 - 1e-12 && fmod(f1, 1.0) < 1.0 - 1e-12;
+            (lo_flip ? w.need_neg[l0] : w.need_pos[l0]) |= 1u << index;
+            (hi_flip ? w.need_pos[l1] : w.need_neg[l1]) |= 1u << index;
+        }
+    }
+    w.count = (int32_t)(parts + parts_fine);
+    return w;
+}
+
 uint64_t chunk_texel_max(const AobOptions& opt)
 {
     // BakeEngine.cpp:359-364
@@ -1061,20 +1202,22 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
                 b->gstack_words = words;
             }
             p.gstack = b->gstack;
-            p.tile_cuts = nullptr;
+            p.tile_cuts = nullptr; p.cut_records = 1u;
             // (16-bit miss counters: a part of at most 65 535 samples)
             if (cut && (uint32_t)o.sample_count / p.parts <= 65535u - 1u) {
                 // the cuts of this launch's tiles (a wavefront per tile; kCutMax entries of four words each)
-                const uint64_t entries = ((uint64_t)p.ntiles + 1u) * kCutMax;      // (one record of slack: the entry phase may fetch 48 bytes past a list)
-                if (entries > m.tile_cut_capacity) {
+                const CutWedges wedges = cut_wedges(o.sample_count, p.grid, p.parts, fine_tiles ? p.parts_fine : 0u);
+                p.cut_records = wedges.count > 0 ? (uint32_t)wedges.count : 1u;
+                const uint64_t words = ((uint64_t)p.ntiles * p.cut_records + 1u) * kCutWords;      // (one record of slack: the entry phase fetches 48 bytes past a list)
+                if (words > m.tile_cut_capacity) {
                     AOB_HIP(hipStreamSynchronize(s));
                     release_device(b, m.tile_cuts);
                     m.tile_cuts = nullptr; m.tile_cut_capacity = 0;
-                    AOB_HIP(hipMalloc((void**)&m.tile_cuts, sizeof(uint32_t) * 4u * entries));
-                    m.tile_cut_capacity = entries;
+                    AOB_HIP(hipMalloc((void**)&m.tile_cuts, sizeof(uint32_t) * words));
+                    m.tile_cut_capacity = words;
                 }
                 hipLaunchKernelGGL(k_tile_cuts, dim3(p.ntiles), dim3(kWave), 0, s, m.frames, sb, se, b->nodes4q, b->quant_frame, p.node_count,
-                                   fabsf(o.ray_bias), cut_entries, m.tile_cuts);
+                                   fabsf(o.ray_bias), cut_entries, wedges, m.tile_cuts);
                 p.tile_cuts = m.tile_cuts;
             }
             p.self_shape = m.section_mesh[si] + 1u;
