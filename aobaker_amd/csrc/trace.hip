@@ -71,6 +71,9 @@ __device__ __forceinline__ uint4 as_uint4(v4u v) { return make_uint4(v.x, v.y, v
 #ifndef AOB_CUT_WEDGES
 #define AOB_CUT_WEDGES 1           // 0: every unit tests every entry of its tile's cut (A/B runs)
 #endif
+#ifndef AOB_CUT_LAZY
+#define AOB_CUT_LAZY 1              // 1: a ray keeps the entries it has still to walk as a mask and takes the next when its stack runs dry; 0: it pushes them all when it starts
+#endif
 #ifndef AOB_CUT_SCALAR
 #define AOB_CUT_SCALAR 0           // CUT mode: scalar steps after a refill, from the node its first ray starts on (measured: slower)
 #endif
@@ -486,6 +489,7 @@ void k_trace(TraceParams p)
     uint3 nsel = make_uint3(0u, 0u, 0u), fsel = make_uint3(0u, 0u, 0u);   // QUANT 2: v_perm_b32 selectors of the near / far plane
     uint32_t slot = 0;                         // the ray's surfel
     uint32_t addr = kIdle;
+    uint32_t pending = 0u;                     // CUT: the entries of the tile's cut the ray entered and has not walked yet (bit n - 1 - e: entry e)
     const uint32_t leaf_base = QUANT == 2 ? 0x80000000u : p.leaf_base;      // QUANT 2: a compile-time constant, the votes are sign tests
     // Any hit: the lane's stack top is kept as a BYTE offset into lds_stack (entry e of this lane lives at e * 256 + lane * 4): a
     // push or a pop is the LDS access itself and one add, no address arithmetic.  Closest hit keeps the entry index (its ranked
@@ -661,13 +665,17 @@ void k_trace(TraceParams p)
                         spa = sp_first;
                         addr = 0;
                         if (cut_on) {
-                            // the walk starts below the entries the ray entered: the first of the list (the shallowest: the big boxes
-                            // far from the tile) first, the others deferred on the stack — 51.9 -> 50.3 ms on BASELINE configs[2] against
-                            // deepest first (profiles/r04/cuts/).  Bit 0 of the mask is the list's last entry.
+                            // the walk starts below the entries the ray entered, the first of the list first.  Bit 0 of the mask is the
+                            // list's last entry.
                             uint32_t m = e1.w;
 #if AOB_TRACE_STATS
                             { unsigned long long bits_ = __popc(m); for (int off = 32; off > 0; off >>= 1) bits_ += __shfl_xor(bits_, off); if (lane == (uint32_t)__builtin_ctzll(__ballot(true))) st_[9] += bits_; }
 #endif
+#if AOB_CUT_LAZY
+                            // (the mask stays with the ray; "nothing left on the stack" sends it to the next entry, below the refill section)
+                            pending = m;
+                            addr = kInvalid;
+#else
                             while (m) {
                                 const uint32_t lb = (uint32_t)__builtin_ctz(m);
                                 push(cut_refs[31u - lb - cut_shift]);
@@ -675,6 +683,7 @@ void k_trace(TraceParams p)
                             }
                             addr = pop();
                             if (addr == kInvalid) finish();          // no box entered: the ray misses (so does every ray of an empty scene)
+#endif
                         } else
                         if (p.node_count == 0) { addr = kInvalid; finish(); }      // empty scene: every ray misses
                     }
@@ -797,6 +806,17 @@ void k_trace(TraceParams p)
             }
         }
 
+        // ---- CUT: a ray whose stack has run dry goes on below the next entry of its tile's cut that it entered, shallowest first (the big
+        // boxes far from the tile: 51.9 -> 50.3 ms on BASELINE configs[2] against deepest first) ----
+        if (CUT && AOB_CUT_LAZY) {
+            if (addr == kInvalid && pending != 0u) {
+                const uint32_t hb = (uint32_t)__clz((int)pending);
+                addr = cut_refs[hb - cut_shift];
+                pending &= ~(0x80000000u >> hb);
+                spa = sp_first;                     // (the pop that found the sentinel left the stack top below entry 1)
+            }
+        }
+
         // ---- leaf section: :162-182 (closest) / :323-339 (any hit); the triangle is inlined in the node ----
         const bool at_leaf = addr >= leaf_base && addr < kIdle;
         const bool inner = addr < leaf_base;
@@ -910,7 +930,8 @@ void k_trace(TraceParams p)
             }
           }
         }
-        if (addr > kIdle) finish();     // kInvalid or kEndHit: the one place a ray ends
+        // kInvalid or kEndHit: the one place a ray ends (CUT: unless it has entries of its tile's cut left to walk)
+        if (addr > kIdle && !(CUT && AOB_CUT_LAZY && addr == kInvalid && pending != 0u)) finish();
     }
 #if AOB_EXP_VALU || AOB_EXP_LOAD
     asm volatile("" :: "v"(exp_acc));
@@ -1089,7 +1110,7 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
         const bool cut = AOB_TRACE_CUT && o.bvh_quantised && o.bvh_width == 4 && o.use_any_hit && o.sampler == AOB_SAMPLER_COSINE && b->node_count > 0 &&
                          o.trace_cut != 1;
         const int cut_entries = o.trace_cut >= 4 ? min(o.trace_cut, kCutMax) : kCutMax;
-        const uint32_t need = ((o.bvh_quantised && o.bvh_width == 4) ? 3u * ((b->bvh_depth + 2) / 2) + 2u : b->bvh_depth + 2) + (cut ? (uint32_t)kCutMax : 0u);
+        const uint32_t need = ((o.bvh_quantised && o.bvh_width == 4) ? 3u * ((b->bvh_depth + 2) / 2) + 2u : b->bvh_depth + 2) + (cut && !AOB_CUT_LAZY ? (uint32_t)kCutMax : 0u);
         // 8, 10 or 11 stack entries per lane live in LDS (2 KB + 1 KB of sums, 2.5 KB + 512 B of totals, or 2.75 KB + 256 B of counters, + 2 KB of queued
         // rays per wavefront = 32 wavefronts per CU); deeper entries — rare — go to an HBM array.
         const uint32_t in_lds = (uint32_t)lds_stack_entries(o.sampler, o.use_any_hit, o.accumulate);
