@@ -125,13 +125,14 @@ struct AobBake {
     int cu_count = 256;
     uint64_t gstack_words = 0;
     unsigned long long* acc_cells = nullptr;   // 2 x 64-bit exact sums per result cell of the largest material: where the sample parts of a tile
-    uint64_t acc_cells_count = 0;              // add up when the cells are floats that hold fractions (trace.hip; allocated on first use, kept zero)
+    uint64_t acc_cells_count = 0;              // add up when the cells are floats that hold fractions (trace.hip; sized at creation, kept zero)
 
     float* hemisphere = nullptr;        // compat sampler table (float3 packed)
     uint64_t hemisphere_entries = 0;
 
     hipEvent_t ev[8] = {};
     hipEvent_t ev_trace[2] = {};
+    hipEvent_t ev_peer = nullptr;       // aob_bake_add_results_from: "everything enqueued on this handle's stream so far", for another handle to wait on
     hipEvent_t ev_ploc[2] = {};         // PLOC rounds: the list length of round r is read back while round r + 1 runs
     bool trace_timed = false;
     AobStats stats = {};

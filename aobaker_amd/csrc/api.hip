@@ -23,6 +23,7 @@ static thread_local char g_error[512] = "";
 // per host thread, like HIP's current device: a multi-GPU host runs one thread per device (aobaker_amd/host/MultiGpu.cpp)
 static thread_local bool g_initialised = false;
 static thread_local int g_device = 0;
+static std::atomic<int> g_process_inits{0};     // threads between their aob_init and their aob_shutdown
 // the device of the most recent aob_init on ANY thread (-1: none, or shut down): what a thread that has not called aob_init
 // itself creates handles on — a host that initialises once on its main thread and bakes from a worker keeps working
 static std::atomic<int> g_process_device{-1};
@@ -163,15 +164,29 @@ static void free_bake(AobBake* b)
     for (auto& e : b->ev) if (e) hipEventDestroy(e);
     for (auto& e : b->ev_trace) if (e) hipEventDestroy(e);
     for (auto& e : b->ev_ploc) if (e) hipEventDestroy(e);
+    if (b->ev_peer) hipEventDestroy(b->ev_peer);
     if (b->stream) hipStreamDestroy(b->stream);
     delete b;
 }
 
-static int check_bake(AobBake* b, int32_t material, bool need_material)
+// A handle lives on the device it was created on, whatever the calling thread's current device is: every entry point selects
+// that device for its own duration and gives the caller's device back when it returns — a host thread that shares HIP with
+// other code (torch, its own kernels on another GPU) does not find its current device changed by an aob_bake_* call.
+struct DeviceScope {
+    int prev = -1;
+    bool changed = false;
+    ~DeviceScope() { if (changed) hipSetDevice(prev); }
+};
+
+static int check_bake(DeviceScope& scope, AobBake* b, int32_t material, bool need_material)
 {
     if (!b) { set_error("bake handle is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
-    // a handle lives on the device it was created on, whatever the calling thread's current device is (cheap, idempotent)
-    AOB_HIP(hipSetDevice(b->device));
+    if (!scope.changed) {
+        AOB_HIP(hipGetDevice(&scope.prev));
+        if (scope.prev != b->device) { AOB_HIP(hipSetDevice(b->device)); scope.changed = true; }
+    } else {
+        AOB_HIP(hipSetDevice(b->device));
+    }
     if (need_material && (material < 0 || (size_t)material >= b->materials.size())) {
         set_error("material %d out of range (%zu)", material, b->materials.size());
         return AOB_ERR_INVALID_ARGUMENT;
@@ -234,7 +249,7 @@ void aob_default_options(AobOptions* o)
     o->raster_mode = AOB_RASTER_REFERENCE;
     o->raster_layers = AOB_LAYERS_LAST;
     // schedule of k_trace: the measured optima on BASELINE configs[2]
-    o->trace_refill_idle = 0;     // by scoring mode: 42 where a ray is a miss counter (COSINE sampler, any hit), else 24 (trace.hip)
+    o->trace_refill_idle = 0;     // by scoring mode (trace.hip): COSINE sampler with any-hit scoring 16 (42 without tile cuts), table sampler with any-hit scoring 24, closest-hit scoring 16
     o->trace_leaf_wait = 0;       // by scoring mode: 24 with any-hit scoring, 16 with closest-hit scoring (trace.hip)
     o->trace_parts = 4;
     o->trace_part_min = 16;
@@ -260,6 +275,7 @@ int aob_init(const AobDeviceConfig* config)
         return AOB_ERR_UNSUPPORTED;
     }
     g_device = dev;
+    if (!g_initialised) g_process_inits.fetch_add(1);
     g_initialised = true;
     g_process_device.store(dev);
     // the first time on this device: one throw-away bake of a triangle (include/aobaker.h, AOB_INIT_NO_WARMUP)
@@ -281,13 +297,20 @@ int aob_init(const AobDeviceConfig* config)
         AobOptions o; aob_default_options(&o);
         o.sample_count = 16; o.sampler = AOB_SAMPLER_COSINE;      // (no hemisphere table to fill)
         const int rc = aob_bake(&scene, &o, nullptr);
-        if (rc != AOB_OK) { warmed[dev >> 6].fetch_and(~bit); g_initialised = false; g_process_device.store(-1); return rc; }
+        if (rc != AOB_OK) { warmed[dev >> 6].fetch_and(~bit); aob_shutdown(); return rc; }
     }
     return AOB_OK;
 }
 
 // aob_init acquires nothing (every stream, event and buffer belongs to an AobBake handle), so there is nothing to release
-void aob_shutdown(void) { g_initialised = false; g_process_device.store(-1); }
+// (the process-wide fallback device — what threads without an aob_init of their own create handles on — goes with the LAST thread
+// that shuts down, not with the first: the workers of a multi-GPU bake shutting down leave a main-thread aob_init alive)
+void aob_shutdown(void)
+{
+    if (!g_initialised) return;
+    g_initialised = false;
+    if (g_process_inits.fetch_sub(1) == 1) g_process_device.store(-1);
+}
 
 int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBake** out)
 {
@@ -316,7 +339,9 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
         }
     }
 
-    AOB_HIP(hipSetDevice(device));
+    DeviceScope scope;                                  // (the caller's current device comes back when the call returns)
+    AOB_HIP(hipGetDevice(&scope.prev));
+    if (scope.prev != device) { AOB_HIP(hipSetDevice(device)); scope.changed = true; }
     AobBake* b = new (std::nothrow) AobBake();
     if (!b) { set_error("out of host memory"); return AOB_ERR_OUT_OF_MEMORY; }
     b->opt = *options;
@@ -330,6 +355,7 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
     for (auto& e : b->ev) AOB_CH(hipEventCreate(&e));
     for (auto& e : b->ev_trace) AOB_CH(hipEventCreate(&e));
     for (auto& e : b->ev_ploc) AOB_CH(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    AOB_CH(hipEventCreateWithFlags(&b->ev_peer, hipEventDisableTiming));
     AOB_CH(hipHostMalloc((void**)&b->pinned, 64));
     AOB_CH(hipDeviceGetAttribute(&b->cu_count, hipDeviceAttributeMultiprocessorCount, device));
     AOB_CH(hipEventRecord(b->ev[0], b->stream));
@@ -435,6 +461,20 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
         d.surfel_capacity = cells;
         d.section_offsets.push_back(0);
     }
+    // float cells that hold fractions (weighted samples, falloff scoring) with more than one sample part per tile: the parts' exact
+    // sums meet in two 64-bit accumulators per cell (trace.hip k_acc_to_cells) — sized for the largest material here, with
+    // everything else, so that an out-of-memory error surfaces at creation and no trace launch carries an allocation
+    {
+        const int parts_default = std::max(1, std::min(options->trace_parts > 0 ? options->trace_parts : 4,
+                                                       options->sample_count / (options->trace_part_min > 0 ? options->trace_part_min : 16)));
+        const bool direct = options->accumulate == AOB_ACCUMULATE_QUANTISED || (options->sampler == AOB_SAMPLER_COSINE && options->use_any_hit);
+        if (!direct && parts_default > 1 && !(options->bvh_width == 4 && !options->bvh_quantised)) {
+            uint64_t most = 0;
+            for (auto& d : b->materials) most = std::max<uint64_t>(most, (uint64_t)d.width * d.height);
+            b->acc_cells_count = most;
+            plan.want(&b->acc_cells, 2 * most);
+        }
+    }
     if (options->sampler == AOB_SAMPLER_REFERENCE_COMPAT) {
         // S0 (BakeEngine.cpp:348-356): only the entries a chunk can index are generated
         b->hemisphere_entries = chunk_texel_max(*options) * (uint64_t)options->sample_count;
@@ -468,6 +508,7 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
     AOB_CH(hipMemcpyAsync(b->hidden_from_others, bits.data(), sizeof(uint32_t) * bits.size(), hipMemcpyHostToDevice, b->stream));
     for (auto& d : b->materials)
         AOB_CH(hipMemsetAsync(d.results, 0, sizeof(AobResult) * (uint64_t)d.width * d.height, b->stream));
+    if (b->acc_cells) AOB_CH(hipMemsetAsync(b->acc_cells, 0, 16ull * b->acc_cells_count, b->stream));      // (kept zero between launches)
     std::shared_ptr<const std::vector<float>> table;                // (held until the stream has drained, below)
     if (b->hemisphere_entries) {
         table = hemisphere_table(b->hemisphere_entries);
@@ -488,14 +529,15 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
 void aob_bake_destroy(AobBake* bake)
 {
     if (!bake) return;
-    hipSetDevice(bake->device);
+    DeviceScope scope;
+    if (hipGetDevice(&scope.prev) == hipSuccess && scope.prev != bake->device) { hipSetDevice(bake->device); scope.changed = true; }
     if (bake->stream) hipStreamSynchronize(bake->stream);
     free_bake(bake);
 }
 
 int aob_bake_build_bvh(AobBake* b)
 {
-    AOB_TRY(check_bake(b, 0, false));
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, 0, false));
     AOB_HIP(hipEventRecord(b->ev[2], b->stream));
     AOB_TRY(build_bvh(b));
     b->depth_known = false;
@@ -508,13 +550,13 @@ int aob_bake_build_bvh(AobBake* b)
 
 int aob_bake_rasterize(AobBake* b, int32_t material)
 {
-    AOB_TRY(check_bake(b, material, true));
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, material, true));
     return rasterize_material(b, material, 0, b->materials[material].height);
 }
 
 int aob_bake_rasterize_rows(AobBake* b, int32_t material, int32_t row_begin, int32_t row_end)
 {
-    AOB_TRY(check_bake(b, material, true));
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, material, true));
     if (row_begin < 0 || row_end < row_begin || row_end > b->materials[material].height) {
         set_error("rows [%d, %d) outside the %d-row atlas", row_begin, row_end, b->materials[material].height);
         return AOB_ERR_INVALID_ARGUMENT;
@@ -524,7 +566,7 @@ int aob_bake_rasterize_rows(AobBake* b, int32_t material, int32_t row_begin, int
 
 int aob_bake_trace(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
 {
-    AOB_TRY(check_bake(b, material, true));
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, material, true));
     if (!b->bvh_built) { set_error("aob_bake_build_bvh has not run"); return AOB_ERR_INVALID_ARGUMENT; }
     if (!b->materials[material].rasterized) { set_error("material %d has not been rasterised", material); return AOB_ERR_INVALID_ARGUMENT; }
     AOB_TRY(ensure_depth(b));
@@ -533,13 +575,13 @@ int aob_bake_trace(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
 
 int aob_bake_resolve(AobBake* b, int32_t material)
 {
-    AOB_TRY(check_bake(b, material, true));
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, material, true));
     return resolve_material(b, material);
 }
 
 int aob_bake_clear_results(AobBake* b, int32_t material)
 {
-    AOB_TRY(check_bake(b, material, true));
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, material, true));
     DeviceMaterial& m = b->materials[material];
     AOB_HIP(hipMemsetAsync(m.results, 0, sizeof(AobResult) * (uint64_t)m.width * m.height, b->stream));
     return AOB_OK;
@@ -547,7 +589,7 @@ int aob_bake_clear_results(AobBake* b, int32_t material)
 
 int aob_bake_add_results(AobBake* b, int32_t material, const void* other_cells, uint64_t cell_count)
 {
-    AOB_TRY(check_bake(b, material, true));
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, material, true));
     DeviceMaterial& m = b->materials[material];
     const uint64_t cells = (uint64_t)m.width * m.height;
     if (!other_cells || cell_count != cells) { set_error("aob_bake_add_results: %llu cells given, the material has %llu", (unsigned long long)cell_count, (unsigned long long)cells); return AOB_ERR_INVALID_ARGUMENT; }
@@ -559,9 +601,24 @@ int aob_bake_add_results(AobBake* b, int32_t material, const void* other_cells, 
     return AOB_OK;
 }
 
+int aob_bake_add_results_from(AobBake* b, int32_t material, AobBake* other, int32_t other_material)
+{
+    DeviceScope scope;
+    AOB_TRY(check_bake(scope, other, other_material, true));
+    AOB_TRY(check_bake(scope, b, material, true));
+    if (other->device != b->device) { set_error("aob_bake_add_results_from: the handles live on devices %d and %d (between devices: an RCCL sum-reduce of the result buffers)", b->device, other->device); return AOB_ERR_INVALID_ARGUMENT; }
+    const DeviceMaterial& om = other->materials[other_material];
+    if (other != b) {
+        // everything `other` has enqueued so far — its trace — comes first
+        AOB_HIP(hipEventRecord(other->ev_peer, other->stream));
+        AOB_HIP(hipStreamWaitEvent(b->stream, other->ev_peer, 0));
+    }
+    return aob_bake_add_results(b, material, om.results, (uint64_t)om.width * om.height);
+}
+
 int aob_bake_download(AobBake* b, int32_t material, void* dst, size_t dst_bytes)
 {
-    AOB_TRY(check_bake(b, material, true));
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, material, true));
     DeviceMaterial& m = b->materials[material];
     const size_t bytes = (size_t)m.width * m.height * m.channels * m.bytes_per_channel;
     if (!dst) { dst = m.host_data; dst_bytes = bytes; }
@@ -575,7 +632,7 @@ int aob_bake_download(AobBake* b, int32_t material, void* dst, size_t dst_bytes)
 
 int aob_bake_run_device(AobBake* b)
 {
-    AOB_TRY(check_bake(b, 0, false));
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, 0, false));
     hipStream_t s = b->stream;
     AOB_TRY(aob_bake_build_bvh(b));
     float ms_r = 0.f, ms_t = 0.f, ms_p = 0.f;
@@ -602,14 +659,14 @@ int aob_bake_run_device(AobBake* b)
 
 int aob_bake_sync(AobBake* b)
 {
-    AOB_TRY(check_bake(b, 0, false));
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, 0, false));
     AOB_HIP(hipStreamSynchronize(b->stream));
     return AOB_OK;
 }
 
 int aob_bake_get_stats(AobBake* b, AobStats* stats)
 {
-    AOB_TRY(check_bake(b, 0, false));
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, 0, false));
     if (!stats) { set_error("stats is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
     AOB_TRY(ensure_depth(b));
     if (b->bvh_timed) { float ms = 0.f; hipEventElapsedTime(&ms, b->ev[2], b->ev[3]); b->stats.ms_bvh_build = ms; }
@@ -627,7 +684,7 @@ int aob_bake_get_stats(AobBake* b, AobStats* stats)
 
 int aob_bake_node_count(AobBake* b, uint64_t* count)
 {
-    AOB_TRY(check_bake(b, 0, false));
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, 0, false));
     if (!count) { set_error("count is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
     *count = b->node_count;
     return AOB_OK;
@@ -635,7 +692,7 @@ int aob_bake_node_count(AobBake* b, uint64_t* count)
 
 int aob_bake_copy_nodes(AobBake* b, AobBvhNode* dst, uint64_t capacity)
 {
-    AOB_TRY(check_bake(b, 0, false));
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, 0, false));
     if (capacity < b->node_count || (!dst && b->node_count)) { set_error("node buffer too small"); return AOB_ERR_INVALID_ARGUMENT; }
     AOB_TRY(ensure_nodes(b));
     if (b->node_count) AOB_HIP(hipMemcpyAsync(dst, b->nodes, sizeof(AobBvhNode) * b->node_count, hipMemcpyDeviceToHost, b->stream));
@@ -645,7 +702,7 @@ int aob_bake_copy_nodes(AobBake* b, AobBvhNode* dst, uint64_t capacity)
 
 int aob_bake_node4_count(AobBake* b, uint64_t* count)
 {
-    AOB_TRY(check_bake(b, 0, false));
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, 0, false));
     if (!count) { set_error("count is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
     *count = b->node4_count;
     return AOB_OK;
@@ -653,7 +710,7 @@ int aob_bake_node4_count(AobBake* b, uint64_t* count)
 
 int aob_bake_copy_nodes4(AobBake* b, AobBvh4Node* dst, uint64_t capacity)
 {
-    AOB_TRY(check_bake(b, 0, false));
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, 0, false));
     if (capacity < b->node4_count || (!dst && b->node4_count)) { set_error("node4 buffer too small"); return AOB_ERR_INVALID_ARGUMENT; }
     if (b->node4_count) AOB_HIP(hipMemcpyAsync(dst, b->nodes4, sizeof(AobBvh4Node) * b->node4_count, hipMemcpyDeviceToHost, b->stream));
     AOB_HIP(hipStreamSynchronize(b->stream));
@@ -662,7 +719,7 @@ int aob_bake_copy_nodes4(AobBake* b, AobBvh4Node* dst, uint64_t capacity)
 
 int aob_bake_copy_leaf_tris(AobBake* b, AobLeafTri* dst, uint64_t capacity)
 {
-    AOB_TRY(check_bake(b, 0, false));
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, 0, false));
     const uint64_t n = b->bvh_built ? b->triangle_count : 0;
     if (capacity < n || (!dst && n)) { set_error("leaf triangle buffer too small"); return AOB_ERR_INVALID_ARGUMENT; }
     if (n) AOB_HIP(hipMemcpyAsync(dst, b->leaf_tris, sizeof(AobLeafTri) * n, hipMemcpyDeviceToHost, b->stream));
@@ -672,7 +729,7 @@ int aob_bake_copy_leaf_tris(AobBake* b, AobLeafTri* dst, uint64_t capacity)
 
 int aob_bake_copy_nodes2q(AobBake* b, AobBvh2QNode* dst, uint64_t capacity)
 {
-    AOB_TRY(check_bake(b, 0, false));
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, 0, false));
     const uint64_t n = b->bvh_built && b->triangle_count ? b->triangle_count - 1 : 0;
     if (capacity < n || (!dst && n)) { set_error("quantised node buffer too small"); return AOB_ERR_INVALID_ARGUMENT; }
     AOB_TRY(ensure_nodes2q(b));
@@ -696,14 +753,14 @@ static int node4q_count(AobBake* b, uint64_t* count)
 
 int aob_bake_node4q_count(AobBake* b, uint64_t* count)
 {
-    AOB_TRY(check_bake(b, 0, false));
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, 0, false));
     if (!count) { set_error("count is null"); return AOB_ERR_INVALID_ARGUMENT; }
     return node4q_count(b, count);
 }
 
 int aob_bake_copy_nodes4q(AobBake* b, AobBvh4QNode* dst, uint64_t capacity)
 {
-    AOB_TRY(check_bake(b, 0, false));
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, 0, false));
     uint64_t n = 0;
     AOB_TRY(node4q_count(b, &n));
     if (capacity < n || (!dst && n)) { set_error("node4q buffer too small"); return AOB_ERR_INVALID_ARGUMENT; }
@@ -714,7 +771,7 @@ int aob_bake_copy_nodes4q(AobBake* b, AobBvh4QNode* dst, uint64_t capacity)
 
 int aob_bake_quant_frame(AobBake* b, AobQuantFrame* frame)
 {
-    AOB_TRY(check_bake(b, 0, false));
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, 0, false));
     if (!frame) { set_error("frame is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
     AOB_HIP(hipMemcpyAsync(frame, b->quant_frame, sizeof(AobQuantFrame), hipMemcpyDeviceToHost, b->stream));
     AOB_HIP(hipStreamSynchronize(b->stream));
@@ -723,7 +780,7 @@ int aob_bake_quant_frame(AobBake* b, AobQuantFrame* frame)
 
 int aob_bake_surfel_count(AobBake* b, int32_t material, uint64_t* count)
 {
-    AOB_TRY(check_bake(b, material, true));
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, material, true));
     if (!count) { set_error("count is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
     *count = b->materials[material].surfel_count;
     return AOB_OK;
@@ -731,7 +788,7 @@ int aob_bake_surfel_count(AobBake* b, int32_t material, uint64_t* count)
 
 int aob_bake_copy_surfels(AobBake* b, int32_t material, AobSurfel* dst, uint64_t capacity)
 {
-    AOB_TRY(check_bake(b, material, true));
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, material, true));
     DeviceMaterial& m = b->materials[material];
     if (capacity < m.surfel_count || (!dst && m.surfel_count)) { set_error("surfel buffer too small"); return AOB_ERR_INVALID_ARGUMENT; }
     if (m.surfel_count) AOB_HIP(hipMemcpyAsync(dst, m.surfels, sizeof(AobSurfel) * m.surfel_count, hipMemcpyDeviceToHost, b->stream));
@@ -741,7 +798,7 @@ int aob_bake_copy_surfels(AobBake* b, int32_t material, AobSurfel* dst, uint64_t
 
 int aob_bake_copy_results(AobBake* b, int32_t material, AobResult* dst, uint64_t capacity)
 {
-    AOB_TRY(check_bake(b, material, true));
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, material, true));
     DeviceMaterial& m = b->materials[material];
     const uint64_t cells = (uint64_t)m.width * m.height;
     if (capacity < cells || !dst) { set_error("result buffer too small"); return AOB_ERR_INVALID_ARGUMENT; }
@@ -753,7 +810,7 @@ int aob_bake_copy_results(AobBake* b, int32_t material, AobResult* dst, uint64_t
 int aob_bake_shard_bounds(AobBake* b, int32_t material, uint32_t parts, uint64_t* bounds,
                           uint64_t* first_cell, uint64_t* last_cell, int32_t* overlapping)
 {
-    AOB_TRY(check_bake(b, material, true));
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, material, true));
     DeviceMaterial& m = b->materials[material];
     if (!parts || !bounds) { set_error("parts is 0 or bounds is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
     if (!m.rasterized) { set_error("material %d has not been rasterised", material); return AOB_ERR_INVALID_ARGUMENT; }
@@ -799,7 +856,7 @@ int aob_bake_shard_bounds(AobBake* b, int32_t material, uint32_t parts, uint64_t
 
 int aob_bake_results_device_ptr(AobBake* b, int32_t material, void** ptr, uint64_t* bytes)
 {
-    AOB_TRY(check_bake(b, material, true));
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, material, true));
     DeviceMaterial& m = b->materials[material];
     if (ptr) *ptr = m.results;
     if (bytes) *bytes = sizeof(AobResult) * (uint64_t)m.width * m.height;
@@ -808,7 +865,7 @@ int aob_bake_results_device_ptr(AobBake* b, int32_t material, void** ptr, uint64
 
 int aob_bake_image_device_ptr(AobBake* b, int32_t material, void** ptr, uint64_t* bytes)
 {
-    AOB_TRY(check_bake(b, material, true));
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, material, true));
     DeviceMaterial& m = b->materials[material];
     if (ptr) *ptr = m.image;
     if (bytes) *bytes = (uint64_t)m.width * m.height * m.channels * m.bytes_per_channel;
@@ -817,14 +874,14 @@ int aob_bake_image_device_ptr(AobBake* b, int32_t material, void** ptr, uint64_t
 
 int aob_bake_stream(AobBake* b, void** stream)
 {
-    AOB_TRY(check_bake(b, 0, false));
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, 0, false));
     if (stream) *stream = (void*)b->stream;
     return AOB_OK;
 }
 
 int aob_bake_last_trace_ms(AobBake* b, float* ms)
 {
-    AOB_TRY(check_bake(b, 0, false));
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, 0, false));
     if (!ms) { set_error("ms is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
     if (!b->trace_timed) { set_error("no trace has been launched"); return AOB_ERR_INVALID_ARGUMENT; }
     AOB_HIP(hipEventSynchronize(b->ev_trace[1]));

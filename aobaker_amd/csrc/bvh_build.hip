@@ -1025,7 +1025,7 @@ void k_sah_level(const SahRange* __restrict__ ranges, const uint32_t* __restrict
                  height, depth_out, next, next_count, small, small_count);
 }
 
-// one WAVEFRONT per range of at most kSahSmall (= 64) clusters: the range and everything below it, a lane per cluster, the clusters
+// one WAVEFRONT per range of at most kSahSmall (= 32) clusters: the range and everything below it, a lane per cluster, the clusters
 // and the stack of sub-ranges in LDS.  The same cut as above, without bins: lane 15 * axis + q takes the plane behind bin q and
 // walks the sub-range's clusters (broadcast reads), collecting what lies on either side of it.
 static constexpr int kSahWaveBlock = 256;
@@ -1383,6 +1383,18 @@ static int build_sah_top(AobBake* b, uint32_t n, const uint32_t* cl, uint32_t* o
     (void)other;
     const uint32_t per_level = bound / (uint32_t)(kSahSmall + 1) + 1u;
     SahRange* table[2] = { (SahRange*)b->refit_flags, (SahRange*)b->refit_flags + per_level };
+    // the two tables live in refit_flags' slice of the arena: n words rounded up to the arena's 256-byte alignment (api.hip).  They
+    // fit because a range in a table holds more than kSahSmall clusters — checked here, not assumed: the slice after this one is
+    // the tree depth, which sizes the traversal stacks
+    static_assert(sizeof(SahRange) == 64, "the level tables of build_sah_top are sized for 64-byte SahRange records");
+    {
+        const uint64_t slice = (((uint64_t)n > 0 ? (uint64_t)n : 1u) * sizeof(uint32_t) + 255u) & ~(uint64_t)255u;
+        if (2ull * per_level * sizeof(SahRange) > slice) {
+            set_error("SAH top: two level tables of %u ranges need %llu bytes, the workspace slice holds %llu", per_level,
+                      (unsigned long long)(2ull * per_level * sizeof(SahRange)), (unsigned long long)slice);
+            return AOB_ERR_DEVICE;
+        }
+    }
     SahShort* small = (SahShort*)b->codes[1];
     uint32_t* counts = b->sah_counts;
     uint32_t* small_count = counts + kSahMaxLevels + 1, * root_k = counts + kSahMaxLevels + 2;

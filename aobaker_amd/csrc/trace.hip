@@ -58,6 +58,9 @@ __device__ __forceinline__ uint4 as_uint4(v4u v) { return make_uint4(v.x, v.y, v
 #ifndef AOB_EXP_LOAD
 #define AOB_EXP_LOAD 0
 #endif
+#ifndef AOB_EXP_VALU_SLOW
+#define AOB_EXP_VALU_SLOW 0        // N more v_perm_b32 (a 4.2-cycle instruction; AOB_EXP_VALU's v_xor_b32 is a 2.3-cycle one) per inner visit
+#endif
 #ifndef AOB_SLAB_FMA2
 #define AOB_SLAB_FMA2 1
 #endif
@@ -197,38 +200,64 @@ void k_tile_cuts(const float4* __restrict__ frames, uint64_t begin, uint64_t end
         glo[q] = sc > 0.0f ? ((lo[q] - margin) - o) / sc : -INFINITY;
         ghi[q] = sc > 0.0f ? ((hi[q] + margin) - o) / sc : INFINITY;
     }
-    // wave-uniform control flow; lanes 0..3 fetch the four slots of the node that is opened
+    // Breadth first, a level at a time: every lane looks at one entry of the level — an inner slot whose box meets the tile's box is
+    // a candidate and fetches its node — then the candidates are admitted IN LIST ORDER while the cut still fits (the same cut as
+    // opening them one by one, orc_tile_cut: a candidate's children go to the end of the list, behind the whole level), and the
+    // admitted ones append their slots.  One memory round trip per level instead of one per opened node.
     int n = 0, live = 0;
-    auto open = [&](uint32_t node) {
-        uint4 c = make_uint4(0u, 0u, 0u, 0u);
-        bool there = false;
-        if (lane < 4u) { c = nodes4q[4ull * node + lane]; there = !(c.x == kEmptyPlanes && c.y == kEmptyPlanes && c.z == kEmptyPlanes); }
-        const uint64_t m = __ballot(there);
-        const int kids = __popcll(m);
-        if (there) {
-            const int at = n + __popcll(m & ((1ull << lane) - 1ull));
-            list[at] = make_uint4(c.w, c.x, c.y, c.z);
-            dead[at] = 0u;
-        }
-        n += kids; live += kids;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-    };
     if (node_count) {
-        open(0u);
-        for (int e = 0; e < n; e++) {
-            const uint4 en = list[e];
-            if (en.x & 0x80000000u) continue;                          // a leaf or a pair
-            const float x0 = (float)(en.y & 0x7fffu), x1 = (float)((en.y >> 16) & 0x7fffu), y0 = (float)(en.z & 0x7fffu), y1 = (float)((en.z >> 16) & 0x7fffu),
-                        z0 = (float)(en.w & 0x7fffu), z1 = (float)((en.w >> 16) & 0x7fffu);
-            if (!(x0 <= ghi[0] && x1 >= glo[0] && y0 <= ghi[1] && y1 >= glo[1] && z0 <= ghi[2] && z1 >= glo[2])) continue;
+        {
+            uint4 c = make_uint4(0u, 0u, 0u, 0u);
             bool there = false;
-            if (lane < 4u) { const uint4 c = nodes4q[4ull * en.x + lane]; there = !(c.x == kEmptyPlanes && c.y == kEmptyPlanes && c.z == kEmptyPlanes); }
-            const int kids = __popcll(__ballot(there));
-            if (live - 1 + kids > max_entries || n + kids > kCutList) continue;
-            if (lane == 0u) dead[e] = 1u;
-            live--;
-            open(en.x);
+            if (lane < 4u) { c = nodes4q[lane]; there = !(c.x == kEmptyPlanes && c.y == kEmptyPlanes && c.z == kEmptyPlanes); }
+            const uint64_t m0 = __ballot(there);
+            if (there) { const int at = __popcll(m0 & ((1ull << lane) - 1ull)); list[at] = make_uint4(c.w, c.x, c.y, c.z); dead[at] = 0u; }
+            n = live = __popcll(m0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (int lo_e = 0; lo_e < n; ) {
+            const int hi_e = n;
+            for (int base = lo_e; base < hi_e; base += 64) {
+                const int e = base + (int)lane;
+                uint4 en = make_uint4(0x80000000u, 0u, 0u, 0u);
+                if (e < hi_e) en = list[e];
+                bool cand = e < hi_e && !(en.x & 0x80000000u);              // not a leaf or a pair
+                if (cand) {
+                    const float x0 = (float)(en.y & 0x7fffu), x1 = (float)((en.y >> 16) & 0x7fffu), y0 = (float)(en.z & 0x7fffu), y1 = (float)((en.z >> 16) & 0x7fffu),
+                                z0 = (float)(en.w & 0x7fffu), z1 = (float)((en.w >> 16) & 0x7fffu);
+                    cand = x0 <= ghi[0] && x1 >= glo[0] && y0 <= ghi[1] && y1 >= glo[1] && z0 <= ghi[2] && z1 >= glo[2];
+                }
+                uint4 k0 = make_uint4(0u, 0u, 0u, 0u), k1 = k0, k2 = k0, k3 = k0;
+                uint32_t present = 0u;
+                if (cand) {
+                    const uint4* np = nodes4q + 4ull * en.x;
+                    k0 = np[0]; k1 = np[1]; k2 = np[2]; k3 = np[3];
+                    auto empty = [](const uint4& c) { return c.x == kEmptyPlanes && c.y == kEmptyPlanes && c.z == kEmptyPlanes; };
+                    present = (empty(k0) ? 0u : 1u) | (empty(k1) ? 0u : 2u) | (empty(k2) ? 0u : 4u) | (empty(k3) ? 0u : 8u);
+                }
+                const int kids = __popc(present);
+                // admit in list order (wave-uniform loop over the candidates)
+                int my_at = -1;
+                for (uint64_t cm = __ballot(cand); cm; cm &= cm - 1ull) {
+                    const int l = (int)__builtin_ctzll(cm);
+                    const int kl = __builtin_amdgcn_readlane(kids, l);
+                    if (live - 1 + kl > max_entries || n + kl > kCutList) continue;
+                    if ((int)lane == l) my_at = n;
+                    n += kl; live += kl - 1;
+                }
+                if (my_at >= 0) {
+                    dead[e] = 1u;
+                    int at = my_at;
+                    if (present & 1u) { list[at] = make_uint4(k0.w, k0.x, k0.y, k0.z); dead[at] = 0u; at++; }
+                    if (present & 2u) { list[at] = make_uint4(k1.w, k1.x, k1.y, k1.z); dead[at] = 0u; at++; }
+                    if (present & 4u) { list[at] = make_uint4(k2.w, k2.x, k2.y, k2.z); dead[at] = 0u; at++; }
+                    if (present & 8u) { list[at] = make_uint4(k3.w, k3.x, k3.y, k3.z); dead[at] = 0u; at++; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+            lo_e = hi_e;
         }
     }
     // compact in list order; unused entries hold an empty slot's planes
@@ -395,6 +424,13 @@ void k_trace(TraceParams p)
         q_origin = make_f3(fmaf(-32768.0f, q_scale.x, q_origin.x), fmaf(-32768.0f, q_scale.y, q_origin.y), fmaf(-32768.0f, q_scale.z, q_origin.z));
         q_scale = make_f3(q_scale.x * 32768.0f, q_scale.y * 32768.0f, q_scale.z * 32768.0f);
     }
+    if (QUANT) {
+        // (the same in every lane: in scalar registers they are operands of the pop's arithmetic instead of six vector registers held —
+        // and, at the 64-register cap, spilt — across the walk)
+        auto uniform = [](float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); };
+        q_origin = make_f3(uniform(q_origin.x), uniform(q_origin.y), uniform(q_origin.z));
+        q_scale = make_f3(uniform(q_scale.x), uniform(q_scale.y), uniform(q_scale.z));
+    }
     // the quantised 4-ary nodes as a raw buffer (base in SGPRs, 4 GiB window: 64 Mi nodes — trace_range checks the count)
     const __amdgpu_buffer_rsrc_t nodes_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.nodes4q, 0, 0xffffffff, 0x00020000);
     // any hit: the rays of a refill start together and visit the top of the tree together, in the refill section
@@ -502,7 +538,7 @@ void k_trace(TraceParams p)
     int spa = sp_first;
     auto lds_entry = [&](int at) -> uint32_t& { return BYTE_SP ? *(uint32_t*)((char*)lds_stack + at) : lds_stack[at * kWave + lane]; };
     auto gs_entry = [&](int at) -> uint32_t* { return gs_slot((BYTE_SP ? at >> 8 : at) - LDS_N); };
-#if AOB_EXP_VALU || AOB_EXP_LOAD
+#if AOB_EXP_VALU || AOB_EXP_LOAD || AOB_EXP_VALU_SLOW
     uint32_t exp_acc = 0;
 #endif
 
@@ -885,6 +921,9 @@ void k_trace(TraceParams p)
 #if AOB_EXP_VALU
             for (int k = 0; k < AOB_EXP_VALU; k++) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(exp_acc) : "v"(addr));
 #endif
+#if AOB_EXP_VALU_SLOW
+            for (int k = 0; k < AOB_EXP_VALU_SLOW; k++) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(exp_acc) : "v"(addr), "v"(nsel.x));
+#endif
             // (wave-uniform: no lane that visits a node now has fewer than four free stack entries in LDS)
             const bool shallow = AOB_VISIT_BRANCHLESS && __ballot(spa >= kLdsTop - 3 * kSpUnit) == 0ull;
 #if AOB_TRACE_STATS
@@ -933,7 +972,7 @@ void k_trace(TraceParams p)
         // kInvalid or kEndHit: the one place a ray ends (CUT: unless it has entries of its tile's cut left to walk)
         if (addr > kIdle && !(CUT && AOB_CUT_LAZY && addr == kInvalid && pending != 0u)) finish();
     }
-#if AOB_EXP_VALU || AOB_EXP_LOAD
+#if AOB_EXP_VALU || AOB_EXP_LOAD || AOB_EXP_VALU_SLOW
     asm volatile("" :: "v"(exp_acc));
 #endif
 #if AOB_TRACE_STATS
@@ -1180,9 +1219,9 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
             const bool through_acc = !split_direct && p.parts > 1u;
             if (through_acc) {
                 const uint64_t cells = (uint64_t)m.width * m.height;
-                if (cells > b->acc_cells_count) {
+                if (cells > b->acc_cells_count) {               // (aob_bake_create sizes them: only schedules set after creation come here)
                     AOB_HIP(hipStreamSynchronize(s));
-                    if (b->acc_cells) AOB_HIP(hipFree(b->acc_cells));
+                    release_device(b, b->acc_cells);
                     b->acc_cells = nullptr; b->acc_cells_count = 0;
                     AOB_HIP(hipMalloc((void**)&b->acc_cells, 16ull * cells));
                     AOB_HIP(hipMemsetAsync(b->acc_cells, 0, 16ull * cells, s));

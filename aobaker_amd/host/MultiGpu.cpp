@@ -366,8 +366,9 @@ int AobMultiGpuBake::Step(AobMultiStepStats* stats)
 				{
 					// the sum-reduce on one device: the peers' whole cell arrays are added to rank 0's in rank order, on rank 0's
 					// stream (every rank's trace was waited for in phase 1)
+					// (aob_bake_add_results_from orders each sum behind the peer's own stream besides)
 					for (int p = 1; p < n; p++)
-						if (aob_bake_add_results(d.bakes[0], (int32_t)i, d.results[(size_t)p][i], cells) != AOB_OK) { d.errors[0] = aob_last_error(); return AOB_ERR_DEVICE; }
+						if (aob_bake_add_results_from(d.bakes[0], (int32_t)i, d.bakes[(size_t)p], (int32_t)i) != AOB_OK) { d.errors[0] = aob_last_error(); return AOB_ERR_DEVICE; }
 				}
 				else for (int p = 1; p < n; p++)
 					if (first[(size_t)p] <= last[(size_t)p])

@@ -47,6 +47,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# CRC-32 of the resolved float atlas of BASELINE configs[2] (999 698-triangle terrain, seed 3, 2048^2, 256 spp, cosine / any hit /
+# float): what every builder, schedule and host must produce (the cells are oracle-exact, and an any-hit answer does not depend on
+# the tree).  tests/test_gpu_fullsize.py asserts it for bvh_builder 1 and 2; the line carries it as config.image_crc32_expected.
+CONFIG2_IMAGE_CRC32 = 259823415
 # what k_trace's time depends on: the kernel, and the builder whose tree it walks
 KERNEL_SOURCES = ("aobaker_amd/csrc/trace.hip", "aobaker_amd/csrc/aob_math.h", "aobaker_amd/csrc/aob_internal.h", "aobaker_amd/csrc/bvh_build.hip")
 
@@ -327,6 +331,20 @@ def main():
         elapsed = float(t.item())
 
     stats = baker.stats()
+    # what a caller who leaves the library's default builder gets on the same workload (the headline asks for bvh_builder 2:
+    # --bvh-builder): a few steps after the timed region, reported beside the value, never as it
+    default_builder = None
+    if world == 1 and opts.bvh_builder != capi.default_options().bvh_builder and not args.no_wallclock:
+        o1 = capi.AobOptions.from_buffer_copy(opts)
+        o1.bvh_builder = capi.default_options().bvh_builder
+        with Baker(flat, o1) as b1:
+            ms1 = []
+            for _ in range(4):
+                t = time.perf_counter()
+                b1.build_bvh(); b1.rasterize(0); b1.trace(0, 0, b1.surfel_count(0)); b1.resolve(0); b1.sync()
+                ms1.append((time.perf_counter() - t) * 1e3)
+            default_builder = {"bvh_builder": int(o1.bvh_builder), "ms_per_step": round(min(ms1[1:]), 3),
+                               "rays_per_s": counts["mine"] * args.spp / (min(ms1[1:]) * 1e-3), "trace_kernel_ms": round(b1.last_trace_ms(), 3)}
     image_crc = None
     if rank == 0:
         import zlib
@@ -388,17 +406,22 @@ def main():
                        "rows": [[bounds[r], bounds[r + 1]] for r in range(world)],
                        "bvh_nodes": stats.node_count, "bvh_depth": stats.bvh_depth,
                        "image_crc32": image_crc,
+                       "image_crc32_expected": CONFIG2_IMAGE_CRC32 if (world == 1 and (W, H, args.spp, args.grid) == (2048, 2048, 256, 708)) else None,
                        "host": ("REHEARSAL: ranks share devices, strips gathered with gloo through host memory" if rehearsal else
                                 "python ranks, one process per GPU, torch.distributed nccl (= RCCL) point-to-point gather to rank 0")},
             "stage_ms": {"bvh_build": round(stats.ms_bvh_build, 3), "trace_kernel": round(kernel_ms, 3),
                          "rank_build_raster_trace": [round(v, 3) for v in rank_ms]},
             "bake_wallclock_ms": dict(wallclock or {}, device_step_ms=round(ms_per_step, 3)),
-            "roofline": roofline, "cpu_baseline": cpu, "cpp_host": cpp,
+            "roofline": roofline, "cpu_baseline": cpu, "cpp_host": cpp, "library_default_builder": default_builder,
         }
         if world > 1:
             line["balance"] = {"enabled": not args.no_balance, "warmup_history": history}
             if strong:
-                line["strong_scaling_base"] = strong_scaling_base(W, args.spp)
+                base = strong_scaling_base(W, args.spp)
+                line["strong_scaling_base"] = base
+                # what one GPU needed for each rank's strip of this atlas cut N ways, before any re-cut (tools/run_shapes.py ranks, the
+                # same kernel source): the first real N-GPU run's rank_build_raster_trace is to be read against these
+                line["expected_rank_ms"] = ((base or {}).get("rank_strip_ms") or {}).get(str(world))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
@@ -428,17 +451,20 @@ def cpp_host_leg(scene, world, args):
         return {"error": repr(e)[:300]}
 
 
-def strong_scaling_base(atlas, spp):
-    """The single-GPU time of the SAME fixed atlas the N > 1 value is to be read against (measured, committed)."""
-    p = os.path.join(ROOT, "profiles", "strong_scaling_base.json")
+def strong_scaling_base(atlas, spp, path=None):
+    """The single-GPU time of the SAME fixed atlas the N > 1 value is to be read against (measured, committed) — if it was
+    measured on THIS kernel source; a base from another kernel is refused, with the reason."""
+    p = path or os.path.join(ROOT, "profiles", "strong_scaling_base.json")
     try:
         with open(p) as f:
             rec = json.load(f)
-        if rec.get("atlas") == atlas and rec.get("spp") == spp:
-            return rec
     except Exception:
-        pass
-    return None
+        return None
+    if rec.get("atlas") != atlas or rec.get("spp") != spp:
+        return None
+    if rec.get("kernel_source_sha256_16") != kernel_source_hash():
+        return {"refused": f"profiles/strong_scaling_base.json was measured on kernel source {rec.get('kernel_source_sha256_16')}, this is {kernel_source_hash()}"}
+    return rec
 
 
 def kernel_source_hash():
@@ -449,16 +475,22 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def counter_record(opts, args, W, H, world):
+def counter_key(opts, args, W, H, world):
+    """What a counter record must have been measured on to describe this run: the line carries it (roofline.counter_key) and
+    tools/pmc_record.py copies it from the line of the PROFILED run into the record — never from literals."""
+    return {"atlas": [W, H], "spp": args.spp, "grid": args.grid, "n_gpus": world, "bvh_width": opts.bvh_width, "bvh_quantised": opts.bvh_quantised,
+            "bvh_builder": opts.bvh_builder, "trace_cut": opts.trace_cut}
+
+
+def counter_record(opts, args, W, H, world, path=None):
     """profiles/k_trace_counters.json if it was measured on this kernel source and this configuration, else (None, why)."""
-    p = os.path.join(ROOT, "profiles", "k_trace_counters.json")
+    p = path or os.path.join(ROOT, "profiles", "k_trace_counters.json")
     try:
         with open(p) as f:
             rec = json.load(f)
     except Exception:
         return None, "no profiles/k_trace_counters.json"
-    want = {"atlas": [W, H], "spp": args.spp, "grid": args.grid, "n_gpus": world, "bvh_width": opts.bvh_width, "bvh_quantised": opts.bvh_quantised,
-            "bvh_builder": opts.bvh_builder}
+    want = counter_key(opts, args, W, H, world)
     if rec.get("source_sha256_16") != kernel_source_hash():
         return None, f"counters were measured on kernel source {rec.get('source_sha256_16')}, this is {kernel_source_hash()}"
     if rec.get("config") != want:
@@ -499,7 +531,7 @@ def roofline_record(opts, args, W, H, world, visits, my_rays, kernel_ms):
             "bytes_per_ray": round(b_ray, 1), "bytes_per_ray_build": round(b_ray_build, 1),
             "frac_build": round(my_rays * b_ray_build / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "node_visits_per_ray": round(n_inner + n_leaf, 3), "inner_visits_per_ray": round(n_inner, 3), "leaf_visits_per_ray": round(n_leaf, 3),
-            "inner_packet_bytes": inner_bytes, "rays_per_launch": my_rays}
+            "inner_packet_bytes": inner_bytes, "rays_per_launch": my_rays, "counter_key": counter_key(opts, args, W, H, world)}
 
 
 def host_cores():

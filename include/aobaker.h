@@ -276,7 +276,8 @@ typedef struct AobResult { uint32_t total_bits, weight_bits; } AobResult;
  * later aob_bake_create of the calling THREAD allocates on (one host thread per GPU: each thread calls aob_init with
  * its own device); a thread that never called aob_init creates its handles on the device of the most recent aob_init of
  * any thread.  A handle stays on the device it was created on: every aob_bake_* entry point selects that device for the
- * calling thread (hipSetDevice), so a handle may be driven from any thread — one call at a time.  It acquires nothing: streams, events and buffers belong to the AobBake handles (the reference's
+ * duration of the call and restores the calling thread's current device before it returns, so a handle may be driven from
+ * any thread — one call at a time — and a thread that shares HIP with other code keeps its own current device.  It acquires nothing: streams, events and buffers belong to the AobBake handles (the reference's
  * Init allocates ~3 GB of fixed buffers here, BakeEngine.cpp:163-212; this library sizes them per scene). */
 int aob_init(const AobDeviceConfig* config);
 /* Replaces BakeEngine::Dispose (BakeEngine.cpp:215-279).  Since aob_init acquires nothing there is nothing to release
@@ -372,6 +373,10 @@ int aob_bake_image_device_ptr(AobBake* bake, int32_t material, void** ptr, uint6
  * runs on THIS bake's stream: whatever writes other_cells (another handle's trace on its own stream) must have finished
  * (aob_bake_sync on that handle) before the call. */
 int aob_bake_add_results(AobBake* bake, int32_t material, const void* other_cells, uint64_t cell_count);
+/* The same sum with the other HANDLE named instead of its buffer: cells(bake, material) += cells(other, other_material).
+ * The call orders itself behind whatever `other` has enqueued so far (an event recorded on other's stream, waited for on this
+ * bake's stream) — no aob_bake_sync, nothing for the caller to forget.  Both handles on one device, materials of equal size. */
+int aob_bake_add_results_from(AobBake* bake, int32_t material, AobBake* other, int32_t other_material);
 /* The HIP stream the stages are enqueued on (a hipStream_t as void*). */
 int aob_bake_stream(AobBake* bake, void** stream);
 /* Timing of the most recent aob_bake_trace launch, measured with HIP events

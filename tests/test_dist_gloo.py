@@ -92,7 +92,7 @@ def _row_worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_row_window_strips_gather_to_the_single_rank_result(tmp_path, world):
     port = 31500 + (os.getpid() + world * 11) % 2000
     out = tmp_path / "result.txt"

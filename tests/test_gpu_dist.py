@@ -61,8 +61,8 @@ def _bench(*args):
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
-@pytest.mark.parametrize("ranks", [2, 3])
-def test_bench_rank_processes_rehearsed_on_one_gpu(ranks):
+@pytest.mark.parametrize("ranks", [2, 3, 5])          # (5: with the test process itself, the GPU pool's limit of six processes on one card;
+def test_bench_rank_processes_rehearsed_on_one_gpu(ranks):  # eight ranks are rehearsed on the CPU: tests/test_dist_gloo.py, and by the C++ host)
     """`python bench.py --gpus N` end to end with N real rank processes — self-launch, strips of texel rows, cost re-cuts
     during warm-up, gather to rank 0, resolve — rehearsed on the one GPU of the test box: the ranks share the device and the
     strips travel through host memory with gloo (RCCL wants one rank per device); every other line of the N-rank path is

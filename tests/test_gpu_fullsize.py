@@ -78,9 +78,15 @@ def test_config3_bvh_and_surfels_bit_exact(engine, orc, terrain, builder):
     assert np.array_equal(got["total_bits"], ref["total_bits"]) and np.array_equal(got["weight_bits"], ref["weight_bits"])
 
 
-def test_config3_full_spp_properties(engine, orc, terrain):
+@pytest.mark.parametrize("builder", [1, 2])
+def test_config3_full_spp_properties(engine, orc, terrain, builder):
+    """bench.py's own configuration (bvh_builder 2; 1 is the library's default) at its own 256 spp: determinism, sharded ==
+    unsharded, the oracle on a texel subset, and the resolved atlas's CRC-32 — the constant bench.py carries
+    (config.image_crc32_expected): an any-hit answer does not depend on the tree, so both builders give the same image."""
+    import zlib
+    import bench
     flat = FlatScene(terrain)
-    opt = cosine_options(orc, 256)
+    opt = cosine_options(orc, 256, bvh_builder=builder)
     with Baker(flat, opt) as b:
         b.build_bvh(); b.rasterize(0)
         b.trace(0)
@@ -98,6 +104,7 @@ def test_config3_full_spp_properties(engine, orc, terrain):
         b.resolve(0)
         img = np.zeros(2048 * 2048 * 4, dtype=np.uint8)
         b.download(0, img)
+    assert zlib.crc32(img.tobytes()) == bench.CONFIG2_IMAGE_CRC32
     ao = img.view(np.float32).reshape(2048, 2048)
     t = first["total_bits"].view(np.float32).reshape(2048, 2048)
     w = first["weight_bits"].view(np.float32).reshape(2048, 2048)
@@ -106,7 +113,7 @@ def test_config3_full_spp_properties(engine, orc, terrain):
     assert np.array_equal(ao, t / w)
     assert 0.5 < ao.mean() < 0.95
     # the oracle on every 32nd texel in x and y (4096 surfels x 256 spp), exact
-    nodes, _ = orc.bvh_build(orc.scene_triangles(flat.desc))
+    nodes, _ = orc.bvh_build(orc.scene_triangles(flat.desc), builder, 1)
     surfels, _ = orc.rasterize(flat.desc, 0, opt)
     keep = (surfels["texel_x"] % 32 == 0) & (surfels["texel_y"] % 32 == 0)
     sub = np.ascontiguousarray(surfels[keep])

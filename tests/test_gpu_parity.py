@@ -550,8 +550,17 @@ def test_invalid_arguments_are_reported(engine, orc):
             capi.check(b.lib.aob_bake_add_results(b.handle, 0, ptr, cells))
             b.sync()
             twice = b.results(0)
+            # aob_bake_add_results_from: the other HANDLE named — the call waits for its stream itself (no sync by the caller:
+            # the trace below may still be running when the sum is enqueued)
+            other.clear_results(0); other.trace(0)
+            capi.check(b.lib.aob_bake_add_results_from(b.handle, 0, other.handle, 0))
+            b.sync()
+            thrice = b.results(0)
+            assert b.lib.aob_bake_add_results_from(b.handle, 0, other.handle, 7) == -1
         assert np.array_equal(twice["total_bits"].view(np.int32), 2 * once["total_bits"].view(np.int32))
         assert np.array_equal(twice["weight_bits"].view(np.int32), 2 * once["weight_bits"].view(np.int32))
+        assert np.array_equal(thrice["total_bits"].view(np.int32), 3 * once["total_bits"].view(np.int32))
+        assert np.array_equal(thrice["weight_bits"].view(np.int32), 3 * once["weight_bits"].view(np.int32))
 
 
 def test_handles_work_from_threads_that_never_called_init(engine, orc):

@@ -125,9 +125,11 @@ def test_bench_helpers_and_committed_counters():
         committed = json.load(open(path))
         if committed["source_sha256_16"] == bench.kernel_source_hash():
             assert rec is not None and 1e9 < rec["hbm_side_bytes_per_launch"] < 1e12
-            roof = rec["roof"]                                     # the binding roof comes with the measurements that name it
-            assert roof["bound"] in ("vmem", "valu") and 0 < roof["frac"] <= 1.05
-            assert roof["marginal_cost_per_vmem_instr"]["mean"] > 0 and roof["marginal_cost_per_valu_instr"]["mean"] > 0
+            roof = rec["roof"]                                     # BOTH roofs as throughput fractions, the larger one named
+            assert roof["bound"] in ("vmem", "valu") and 0 < roof["frac"] <= 1.3
+            assert roof["frac"] == max(roof["vmem"]["frac"], roof["valu"]["frac"])
+            assert roof["vmem"]["marginal_cu_cycles_per_instruction"]["mean"] > 0
+            assert rec["config"] == bench.counter_key(opts, args, 2048, 2048, 1) and rec["rays_per_launch"] == 2048 * 2048 * 256
         else:
             assert rec is None and "kernel source" in why        # a stale record is refused, not reported
     else:
@@ -146,6 +148,63 @@ def test_bench_helpers_and_committed_counters():
     assert set(zip(sub["texel_x"].tolist(), sub["texel_y"].tolist())) == set(zip(again["texel_x"].tolist(), again["texel_y"].tolist()))
     on_lattice = np.mean((sub["texel_x"] % 8 == 0) & (sub["texel_y"] % 8 == 0))
     assert on_lattice < 0.06                                     # not aligned with the terrain's noise lattice (1/64 expected)
+
+
+def test_counter_records_and_scaling_bases_of_other_runs_are_refused(tmp_path):
+    """A PMC record describes the run it was measured on: bench.py attaches it only where kernel source AND configuration match
+    (a record taken on another builder says so in the line), tools/pmc_record.py copies the configuration from the profiled
+    run's own JSON line and refuses to write a record without one, and a strong-scaling base from another kernel is refused."""
+    import json
+    import os
+    import sys
+    import types
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    opts = capi.default_options()
+    opts.bvh_builder = 2
+    args = types.SimpleNamespace(spp=256, grid=708)
+    key = bench.counter_key(opts, args, 2048, 2048, 1)
+    good = {"source_sha256_16": bench.kernel_source_hash(), "config": key, "hbm_side_bytes_per_launch": 4e10, "roof": None}
+    path = tmp_path / "rec.json"
+    path.write_text(json.dumps(good))
+    rec, why = bench.counter_record(opts, args, 2048, 2048, 1, str(path))
+    assert rec is not None and why is None
+    other = dict(good, config=dict(key, bvh_builder=1))            # the same kernel, profiled with another builder
+    path.write_text(json.dumps(other))
+    rec, why = bench.counter_record(opts, args, 2048, 2048, 1, str(path))
+    assert rec is None and why == "counters were measured on another configuration"
+    line = bench.roofline_record(opts, args, 2048, 2048, 1, (14.2, 1.8), 1 << 30, 50.0)
+    assert line["counter_key"] == key and line["rays_per_launch"] == 1 << 30
+    path.write_text(json.dumps(dict(good, config=dict(key, trace_cut=1))))        # ... or with the tile cuts switched off
+    assert bench.counter_record(opts, args, 2048, 2048, 1, str(path)) == (None, "counters were measured on another configuration")
+    path.write_text(json.dumps(dict(good, source_sha256_16="0123456789abcdef")))
+    rec, why = bench.counter_record(opts, args, 2048, 2048, 1, str(path))
+    assert rec is None and "kernel source" in why
+    # tools/pmc_record.py: the configuration comes from the profiled run's line
+    sys.path.insert(0, os.path.join(root, "tools"))
+    try:
+        import pmc_record
+    finally:
+        sys.path.pop(0)
+    d = tmp_path / "pmc"
+    d.mkdir()
+    (d / "pass1.log").write_text("noise\n" + json.dumps({"metric": "AO rays/sec", "roofline": line}) + "\n")
+    (d / "pass2.log").write_text(json.dumps({"metric": "AO rays/sec", "roofline": line}) + "\n")
+    assert pmc_record.profiled_run(str(d)) == (key, float(1 << 30))
+    (d / "pass2.log").write_text(json.dumps({"metric": "AO rays/sec", "roofline": dict(line, counter_key=dict(key, bvh_builder=1))}) + "\n")
+    with pytest.raises(SystemExit):
+        pmc_record.profiled_run(str(d))                            # two passes, two configurations
+    (d / "pass2.log").unlink()
+    (d / "pass1.log").write_text("a program that printed no bench line\n")
+    with pytest.raises(SystemExit):
+        pmc_record.profiled_run(str(d))
+    # the strong-scaling base
+    base = tmp_path / "base.json"
+    base.write_text(json.dumps({"atlas": 4096, "spp": 256, "kernel_source_sha256_16": bench.kernel_source_hash(), "ms_per_step": 200.0}))
+    assert bench.strong_scaling_base(4096, 256, str(base))["ms_per_step"] == 200.0
+    base.write_text(json.dumps({"atlas": 4096, "spp": 256, "kernel_source_sha256_16": "0123456789abcdef", "ms_per_step": 200.0}))
+    assert "refused" in bench.strong_scaling_base(4096, 256, str(base))
+    assert bench.strong_scaling_base(2048, 256, str(base)) is None
 
 
 def test_bench_launches_its_own_ranks_or_says_why_not():

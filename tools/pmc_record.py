@@ -7,19 +7,20 @@ SLOPES.jsonl) into the record bench.py reads (profiles/k_trace_counters.json):
   hbm_side_bytes_per_launch   FETCH_SIZE x 1 KiB x correction + WRITE_SIZE x 1 KiB, the correction being known bytes /
                               counted bytes of k_gather64 — a lane reading one random 64-byte record as 4 x 16 B, k_trace's
                               own access pattern (the guide's x2 is for wide streaming reads; measured here beside it)
-  roof                        which unit binds k_trace, from measurements on THIS kernel:
-      marginal_cost_per_vmem_instr   CU cycles one more vector-memory wave-instruction per inner visit costs the launch
-                                     (slope of the load1 / load2 builds: (ms - base) x clock x CUs / extra wave-instructions);
-                                     a 16-byte-per-lane load costs the CU's L1 path 4 + 0.65 x lanes cycles alone (tools/l1_probe.hip)
-      marginal_cost_per_valu_instr   SIMD cycles one more v_xor_b32 per inner visit costs (valu8 / 16 / 32 builds); issued alone
-                                     it costs 2.3 (tools/valu_probe.hip)
-      ta_busy_frac, td_busy_frac     TA_BUSY_avr / TD_TD_BUSY_sum over the launch's shader cycles: the address and the data-return
-                                     unit of the CU's vector-memory path
-      bound                          "vmem" if a vector-memory instruction costs the launch more of its stand-alone price than a
-                                     vector-ALU instruction does, else "valu"; frac = the busy fraction of that unit's counter
+  roof                        BOTH roofs of k_trace as throughput fractions, from measurements on THIS kernel, and the larger named:
+      vmem.frac                      vector-memory wave-instructions (SQ_INSTS_VMEM_RD) x the marginal CU cycles of one of them (slope of
+                                     the load1 / load2 builds: (ms - base) x clock x CUs / extra wave-instructions) / (shader cycles x 256 CUs)
+      valu.frac                      sum over instruction classes of count x issue price / (shader cycles x 1024 SIMDs): 2.3 cycles for the
+                                     FMA / MUL / ADD f32 and plain 32-bit integer classes, 4.2 for everything else (tools/valu_probe.hip),
+                                     a mixed stream max(4.2 N_slow, 2.3 N_all); the class counts are the SQ_INSTS_VALU_* counters where
+                                     the passes collected them, else SQ_INSTS_VALU at the kernel's static mix (tools/valu_mix.py)
+      marginal costs                 what one more v_xor_b32 (valuN builds), one more v_perm_b32 (slowN builds) and one more dword load
+                                     (loadN builds) per inner visit cost the launch
   valu_lane_occupancy         SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU)
-and ties it to the kernel source (sha256 of trace.hip + aob_math.h + aob_internal.h) and the bench configuration, so that
-bench.py reports it only for the kernel and workload it was measured on.
+and ties it to the kernel source (sha256 of trace.hip + aob_math.h + aob_internal.h + bvh_build.hip) and to the configuration of the
+PROFILED run: `config` and the ray count are copied from the JSON line that run printed (PMC_DIR/pass*.log: bench.py's
+roofline.counter_key / rays_per_launch) — a record is refused when the passes carry no such line or disagree with each other —
+so that bench.py reports it only for the kernel and workload it was measured on.
 """
 import csv
 import glob
@@ -74,6 +75,10 @@ def slopes(path, clock_hz, inner_iterations):
         return None
     out = {"trace_ms": ms, "inner_iterations_per_launch": inner_iterations}
     valu = [(n, (ms[f"valu{n}"] - ms["base"]) * 1e-3 * clock_hz * SIMDS / (n * inner_iterations)) for n in (8, 16, 32) if f"valu{n}" in ms]
+    slow = [(n, (ms[f"slow{n}"] - ms["base"]) * 1e-3 * clock_hz * SIMDS / (n * inner_iterations)) for n in (4, 8, 16) if f"slow{n}" in ms]
+    if slow:
+        out["marginal_cost_per_slow_valu_instr"] = {"simd_cycles_by_extra_instr_per_visit": {str(n): round(c, 2) for n, c in slow},
+                                                    "mean": round(sum(c for _, c in slow) / len(slow), 2), "alone": 4.2, "instruction": "v_perm_b32"}
     vmem = [(n, (ms[f"load{n}"] - ms["base"]) * 1e-3 * clock_hz * CUS / (n * inner_iterations)) for n in (1, 2) if f"load{n}" in ms]
     if valu:
         out["marginal_cost_per_valu_instr"] = {"simd_cycles_by_extra_instr_per_visit": {str(n): round(c, 2) for n, c in valu},
@@ -84,8 +89,59 @@ def slopes(path, clock_hz, inner_iterations):
     return out
 
 
+def profiled_run(pmc_dir):
+    """(configuration, rays per launch) of the run the counter passes profiled, from the JSON line each pass's program printed."""
+    keys = []
+    for p in sorted(glob.glob(os.path.join(pmc_dir, "pass*.log"))):
+        line = None
+        for text in open(p, errors="replace"):
+            text = text.strip()
+            if text.startswith("{") and '"roofline"' in text:
+                try:
+                    line = json.loads(text)
+                except ValueError:
+                    pass
+        if line is None:
+            continue
+        r = line.get("roofline") or {}
+        if r.get("counter_key") is None or not r.get("rays_per_launch"):
+            continue
+        keys.append((r["counter_key"], float(r["rays_per_launch"]), os.path.basename(p)))
+    if not keys:
+        raise SystemExit(f"{pmc_dir}: no pass log carries a bench line with roofline.counter_key / rays_per_launch — "
+                         "the record would describe a configuration nobody measured; refused")
+    for k, r, name in keys[1:]:
+        if k != keys[0][0] or r != keys[0][1]:
+            raise SystemExit(f"{pmc_dir}: {name} profiled {k} ({r:.0f} rays), {keys[0][2]} profiled {keys[0][0]} ({keys[0][1]:.0f} rays); refused")
+    return keys[0][0], keys[0][1]
+
+
+FAST_CLASSES = ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_INT32")
+
+
+def valu_roof(c, xcd_cycles, static_mix):
+    """The vector ALU's issue fraction: class counts x issue price / (cycles x SIMDs)."""
+    n_all = c["SQ_INSTS_VALU"]
+    if all(k in c for k in FAST_CLASSES):
+        n_fast = sum(c[k] for k in FAST_CLASSES)
+        how = "SQ_INSTS_VALU_{FMA,MUL,ADD}_F32 + INT32 counted as 2.3-cycle classes (an upper bound on them: INT32 holds shifts and compares too)"
+    elif static_mix:
+        n_fast = n_all * static_mix["fast_fraction"]
+        how = f"SQ_INSTS_VALU at the kernel's static mix ({static_mix['fast_fraction']:.3f} of its vector instructions are 2.3-cycle ones: tools/valu_mix.py)"
+    else:
+        return None
+    n_slow = n_all - n_fast
+    cycles = max(4.2 * n_slow, 2.3 * n_all)
+    return {"frac": round(cycles / (xcd_cycles * SIMDS), 4), "instructions": n_all, "of_which_2_3_cycle": round(n_fast),
+            "price_model": "max(4.2 N_slow, 2.3 N_all) SIMD cycles (tools/valu_probe.hip)", "counts_from": how,
+            "frac_if_every_instruction_cost_4_2": round(4.2 * n_all / (xcd_cycles * SIMDS), 4)}
+
+
 def main():
     pmc_dir, calib_dir, slopes_path, out_path = sys.argv[1:5]
+    static_mix = None
+    if len(sys.argv) > 5 and os.path.exists(sys.argv[5]):
+        static_mix = json.load(open(sys.argv[5]))
     import bench
     summary = json.load(open(os.path.join(pmc_dir, "summary.json")))
     c = summary["counters"]
@@ -96,7 +152,7 @@ def main():
     xcd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0
     stats = summary.get("kernel_ms")                    # tools/pmc_summary.py: mean k_trace duration over the counter passes
     clock_hz = xcd_cycles / (stats * 1e-3) if stats else 2.38e9
-    rays = 1073741824.0
+    key, rays = profiled_run(pmc_dir)
     # inner-section executions of one launch: four 16-byte node loads each (the other vector-memory instructions: leaf triangles, frames)
     iterations = None
     lc = os.path.join(os.path.dirname(slopes_path) if slopes_path else "", "loop_counters.jsonl")
@@ -110,29 +166,28 @@ def main():
     ta = c["TA_BUSY_avr"] / xcd_cycles if "TA_BUSY_avr" in c else None
     td = c["TD_TD_BUSY_sum"] / (xcd_cycles * CUS) if "TD_TD_BUSY_sum" in c else None
     roof = None
-    if sl and "marginal_cost_per_vmem_instr" in sl and "marginal_cost_per_valu_instr" in sl:
-        lanes = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_INSTS_VALU"]
-        vmem_alone = 4.0 + 0.65 * lanes * 0.65            # a dword load issued with the node's four: the L1 path's price for ~ the walking lanes
-        share_vmem = sl["marginal_cost_per_vmem_instr"]["mean"] / 16.0
-        share_valu = sl["marginal_cost_per_valu_instr"]["mean"] / VALU_ALONE_CYCLES
-        bound = "vmem" if share_vmem >= share_valu else "valu"
+    if sl and "marginal_cost_per_vmem_instr" in sl:
+        vm_cost = sl["marginal_cost_per_vmem_instr"]["mean"]
+        vmem = {"frac": round(c["SQ_INSTS_VMEM_RD"] * vm_cost / (xcd_cycles * CUS), 4), "wave_instructions": c["SQ_INSTS_VMEM_RD"],
+                "marginal_cu_cycles_per_instruction": sl["marginal_cost_per_vmem_instr"],
+                "ta_busy_frac": round(ta, 4) if ta is not None else None, "td_busy_frac": round(td, 4) if td is not None else None,
+                "note": "TA / TD busy are has-work counters, not throughput fractions; frac is instructions x their measured marginal cost"}
+        valu = valu_roof(c, xcd_cycles, static_mix)
+        if valu is not None:
+            valu["marginal_cost_per_valu_instr"] = sl.get("marginal_cost_per_valu_instr")
+            valu["marginal_cost_per_slow_valu_instr"] = sl.get("marginal_cost_per_slow_valu_instr")
+        bound = "vmem" if valu is None or vmem["frac"] >= valu["frac"] else "valu"
         roof = {"bound": bound,
                 "name": "the CU's vector-memory path (TA address unit / TD data return / L1): one lane's 16-byte request per node piece"
-                        if bound == "vmem" else "vector-ALU issue",
-                "frac": round(td if bound == "vmem" and td is not None else c["SQ_ACTIVE_INST_VALU"] / (xcd_cycles / 4.0 * SIMDS), 4),
-                "frac_is": "TD_TD_BUSY_sum / (shader cycles x 256 CUs): the data-return unit of the vector-memory path" if bound == "vmem" else
-                           "SQ_ACTIVE_INST_VALU / SIMD quad-cycles",
-                "ta_busy_frac": round(ta, 4) if ta is not None else None, "td_busy_frac": round(td, 4) if td is not None else None,
-                "marginal_cost_per_vmem_instr": sl["marginal_cost_per_vmem_instr"], "marginal_cost_per_valu_instr": sl["marginal_cost_per_valu_instr"],
-                "reading": "one more 4-byte load per inner visit costs the launch %.1f CU cycles per wave-instruction — all of what the L1 path charges for it; "
-                           "one more v_xor_b32 costs %.2f SIMD cycles of the %.1f it issues in: the vector-memory path binds, the vector ALU has slack"
-                           % (sl["marginal_cost_per_vmem_instr"]["mean"], sl["marginal_cost_per_valu_instr"]["mean"], VALU_ALONE_CYCLES),
-                "slope_builds_trace_ms": sl["trace_ms"]}
-        _ = vmem_alone
+                        if bound == "vmem" else "vector-ALU issue (1024 SIMDs)",
+                "frac": vmem["frac"] if bound == "vmem" else valu["frac"],
+                "frac_is": "the larger of vmem.frac (vector-memory wave-instructions x their marginal CU cycles / (cycles x 256)) and valu.frac "
+                           "(class counts x issue price / (cycles x 1024))",
+                "vmem": vmem, "valu": valu, "slope_builds_trace_ms": sl["trace_ms"]}
     rec = {
         "kernel": summary["kernel"],
         "source_sha256_16": bench.kernel_source_hash(),
-        "config": {"atlas": [2048, 2048], "spp": 256, "grid": 708, "n_gpus": 1, "bvh_width": 4, "bvh_quantised": 1, "bvh_builder": 2},
+        "config": key, "rays_per_launch": rays,
         "provenance": "rocprofv3 --pmc passes over `bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-cpp-host --no-wallclock` "
                       "(tools/pmc_passes.sh), summed over the k_trace dispatch; FETCH_SIZE corrected by the known-byte kernel k_gather64 "
                       "(tools/fetch_calib.hip); slopes from tools/build_variants.py + tools/time_trace.py; tools/pmc_record.py",
