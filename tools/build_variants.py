@@ -22,19 +22,26 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=o
 def main():
     os.makedirs(OUT, exist_ok=True)
     subprocess.run(["make", "-s", "-j", "8", "-C", CSRC], check=True)
-    others = [os.path.join(CSRC, o) for o in ("api.o", "bvh_build.o", "raster.o", "trace4.o", "resolve.o")]
+    # AOB_VARIANT_ALSO="bvh_build.hip ...": sources compiled with the variant's flags besides trace.hip (a flag that both sides of a
+    # data structure must see, e.g. -DAOB_FAN=1)
+    also = os.environ.get("AOB_VARIANT_ALSO", "").split()
+    others = [os.path.join(CSRC, o) for o in ("api.o", "bvh_build.o", "raster.o", "trace4.o", "resolve.o") if o.replace(".o", ".hip") not in also]
     procs = []
     for arg in sys.argv[1:]:
         name, _, flags = arg.partition("=")
         src = os.environ.get("AOB_VARIANT_SOURCE", "trace.hip")
-        obj = os.path.join(OUT, f"trace_{name}.o")
-        cmd = [HIPCC] + FLAGS + flags.split() + ["-c", os.path.join(CSRC, src), "-o", obj]
-        procs.append((name, obj, subprocess.Popen(cmd)))
-    for name, obj, p in procs:
-        if p.wait() != 0:
-            raise SystemExit(f"variant {name} failed to compile")
+        objs = []
+        for one in [src] + also:
+            obj = os.path.join(OUT, f"{os.path.splitext(one)[0]}_{name}.o")
+            cmd = [HIPCC] + FLAGS + flags.split() + ["-c", os.path.join(CSRC, one), "-o", obj]
+            objs.append((obj, subprocess.Popen(cmd)))
+        procs.append((name, objs))
+    for name, objs in procs:
+        for obj, p in objs:
+            if p.wait() != 0:
+                raise SystemExit(f"variant {name} failed to compile")
         lib = os.path.join(OUT, f"lib_{name}.so")
-        subprocess.run([HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", obj] + others + ["-o", lib], check=True)
+        subprocess.run([HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950"] + [o for o, _ in objs] + others + ["-o", lib], check=True)
         print(lib)
 
 

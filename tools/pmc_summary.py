@@ -30,12 +30,17 @@ def main():
                 out["scratch_size"] = int(row["Scratch_Size"])
         out["launches"][os.path.relpath(path, root)] = len(dispatches)
     # the kernel's duration in the counter passes (kernel-trace of the same runs): the clock the counters ran at = cycles / this
+    # (per pass the SUM over the kernel's launches — the sections of a bake, and the one-triangle warm-up bake of aob_init, a few
+    # microseconds — as the counters are summed; then the mean over the passes)
     ms = []
     for path in sorted(glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True)):
+        total = 0.0
         with open(path, newline="") as f:
             for row in csv.DictReader(f):
                 if kernel in row["Kernel_Name"]:
-                    ms.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6)
+                    total += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6
+        if total > 0.0:
+            ms.append(total)
     if ms:
         out["kernel_ms"] = sum(ms) / len(ms)
         out["kernel_ms_per_pass"] = [round(x, 3) for x in ms]
