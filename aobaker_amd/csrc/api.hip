@@ -448,10 +448,10 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
         plan.want(&d.perm, cells);
         // a cut per 64-surfel tile of a trace launch (any-hit walk of the quantised 4-ary nodes with the COSINE sampler, trace.hip):
         // every section's last tile may be ragged, hence one tile of slack per mesh; lists that outgrow it are re-allocated
-        if (options->use_any_hit && options->sampler == AOB_SAMPLER_COSINE && options->bvh_quantised && options->bvh_width == 4 && options->trace_cut != 1) {
+        if (options->use_any_hit && options->bvh_quantised && options->bvh_width == 4 && options->trace_cut != 1) {
             // (128 words per record, a record per sample part — 4 coarse + 8 fine with the default schedule; a launch that needs more
             // re-allocates: trace.hip)
-            d.tile_cut_capacity = ((cells / 64 + scene->mesh_count + 1) * 12 + 1) * 128;
+            d.tile_cut_capacity = ((cells / 64 + scene->mesh_count + 1) * (options->sampler == AOB_SAMPLER_COSINE ? 12 : 1) + 1) * 128;
             plan.want(&d.tile_cuts, d.tile_cut_capacity);
         }
         const uint64_t tiles_x = (uint64_t)(d.width + 7) / 8, tiles_y = (uint64_t)(d.height + 7) / 8;

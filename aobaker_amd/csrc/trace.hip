@@ -405,7 +405,9 @@ void k_trace(TraceParams p)
     // the entries a ray entered; the miss counters shrink to 16 bits (a part is at most 65 535 samples: trace_range) and the
     // 128 bytes they free hold the entries' refs.
     constexpr bool CUT = CUTMODE != 0;
-    static_assert(!CUT || (QUANT == 2 && ANYHIT && SAMPLER == AOB_SAMPLER_COSINE), "tile cuts: any-hit walk of the quantised 4-ary nodes, unit weights");
+    static_assert(!CUT || (QUANT == 2 && ANYHIT), "tile cuts: any-hit walk of the quantised 4-ary nodes");
+    // (the table sampler's weight dot(N, d) is made again when the ray is popped — the same expression on the same numbers, for one more
+    // 16-byte load of the surfel's record — and the refs take a stack entry's room: launch_stack)
     __shared__ uint32_t miss_count[COUNT32 ? (CUT ? kWave / 2 : kWave) : 1];
     __shared__ uint32_t cut_refs[CUT ? kCutMax : 1];
     __shared__ uint4 queue[kWave * 2];                  // ray queue: {dir.xyz, slot}, {1/dir.xyz, weight — CUT: the ray's entry mask}
@@ -676,6 +678,11 @@ void k_trace(TraceParams p)
                         dir = make_f3(__uint_as_float(e0.x), __uint_as_float(e0.y), __uint_as_float(e0.z));
                         invdir = make_f3(__uint_as_float(e1.x), __uint_as_float(e1.y), __uint_as_float(e1.z));
                         w = __uint_as_float(e1.w);
+                        if (CUT && !UNITW) {
+                            // the record's last word is the entry mask: the weight again from the surfel's normal, as the generator made it
+                            const float4 a1 = p.frames[4ull * (wave_first + slot) + 1];
+                            w = dot(make_f3(a.w, a1.x, a1.y), dir);
+                        }
                         org = make_f3(fmaf(dir.x, p.bias, a.x), fmaf(dir.y, p.bias, a.y), fmaf(dir.z, p.bias, a.z));   // GenerateRays:47
                         oxinvdir = make_f3(-org.x * invdir.x, -org.y * invdir.y, -org.z * invdir.z);
                         if (QUANT == 2) {
@@ -1051,8 +1058,10 @@ template <int SAMPLER, int ANYHIT, int ACCUM, int MASKED>
 static void launch_stack(int quant, dim3 grid, hipStream_t s, const TraceParams& p)
 {
     constexpr int N = lds_stack_entries(SAMPLER, ANYHIT, ACCUM);
-    constexpr bool CAN_CUT = AOB_TRACE_CUT && SAMPLER == AOB_SAMPLER_COSINE && ANYHIT;
-    if (quant == 2 && CAN_CUT && p.tile_cuts) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 2, MASKED, CAN_CUT ? 1 : 0>), grid, dim3(kWave), 0, s, p);
+    constexpr bool CAN_CUT = AOB_TRACE_CUT && ANYHIT;
+    // (a cut's 32 refs: with unit weights the 16-bit miss counters make their room, otherwise a stack entry does)
+    constexpr int NC = SAMPLER == AOB_SAMPLER_COSINE ? N : N - 1;
+    if (quant == 2 && CAN_CUT && p.tile_cuts) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, NC, 2, MASKED, CAN_CUT ? 1 : 0>), grid, dim3(kWave), 0, s, p);
     else if (quant == 2) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 2, MASKED, 0>), grid, dim3(kWave), 0, s, p);
     else if (quant == 1) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 1, MASKED, 0>), grid, dim3(kWave), 0, s, p);
     else hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 0, MASKED, 0>), grid, dim3(kWave), 0, s, p);
@@ -1146,13 +1155,12 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
         // a lane's stack holds the sentinel plus at most one deferred sibling per tree level
         // (the 4-ary walk defers up to three children per 4-ary level)
         // (a walk that starts below a tile cut holds, besides, up to kCutMax start refs)
-        const bool cut = AOB_TRACE_CUT && o.bvh_quantised && o.bvh_width == 4 && o.use_any_hit && o.sampler == AOB_SAMPLER_COSINE && b->node_count > 0 &&
-                         o.trace_cut != 1;
+        const bool cut = AOB_TRACE_CUT && o.bvh_quantised && o.bvh_width == 4 && o.use_any_hit && b->node_count > 0 && o.trace_cut != 1;
         const int cut_entries = o.trace_cut >= 4 ? min(o.trace_cut, kCutMax) : kCutMax;
         const uint32_t need = ((o.bvh_quantised && o.bvh_width == 4) ? 3u * ((b->bvh_depth + 2) / 2) + 2u : b->bvh_depth + 2) + (cut && !AOB_CUT_LAZY ? (uint32_t)kCutMax : 0u);
         // 8, 10 or 11 stack entries per lane live in LDS (2 KB + 1 KB of sums, 2.5 KB + 512 B of totals, or 2.75 KB + 256 B of counters, + 2 KB of queued
         // rays per wavefront = 32 wavefronts per CU); deeper entries — rare — go to an HBM array.
-        const uint32_t in_lds = (uint32_t)lds_stack_entries(o.sampler, o.use_any_hit, o.accumulate);
+        const uint32_t in_lds = (uint32_t)lds_stack_entries(o.sampler, o.use_any_hit, o.accumulate) - (cut && o.sampler != AOB_SAMPLER_COSINE ? 1u : 0u);
         const uint32_t overflow = need > in_lds ? need - in_lds : 0u;
         TraceParams p;
         if (!o.bvh_quantised) AOB_TRY(ensure_nodes(b));
@@ -1186,11 +1194,13 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
         // (round 4: rays that start below their tile's cut have no top of the tree to share — 16 idle lanes, and 20 parked at a leaf: refill
         // 8 / 16 / 24 / 32 / 48 -> 53.1 / 52.1 / 52.8 / 53.7 / 56.4 ms, leaf wait 16 / 20 / 28 -> 52.6 / 52.1 / 52.5 on BASELINE configs[2];
         // profiles/r04/cuts/)
+        // (the table sampler below its tiles' cuts — the reference's own constants on the terrain: refill 8 / 16 / 24 / 32 -> 43.7 / 43.1 / 42.7 / 42.8 ms,
+        // leaf wait 16 / 20 / 28 -> 43.5 / 43.1 / 42.6; without cuts 46.6)
         p.refill_idle = knob(o.trace_refill_idle, o.use_any_hit ? (o.sampler == AOB_SAMPLER_COSINE ? (cut ? 16 : 42) : 24) : 16);
         // (the leaf section: 16 parked lanes, 24 with any-hit scoring — 12 / 16 / 20 / 24 / 28 -> 59.5 / 58.3 / 57.9 / 57.7 / 57.7 ms on
         // BASELINE configs[2]; the scalar steps: since the vector-memory path is what binds the walk (profiles/r03/roofs/) a step pays
         // for 24 lanes on one node — 16 / 24 / 32 / 36 / 40 -> 56.9 / 56.6 / 56.9 / 57.2 / 57.7 ms — where round 2's kernel wanted 40)
-        p.leaf_wait = knob(o.trace_leaf_wait, o.use_any_hit ? (cut ? 20 : 24) : 16);
+        p.leaf_wait = knob(o.trace_leaf_wait, o.use_any_hit ? (cut && o.sampler == AOB_SAMPLER_COSINE ? 20 : 24) : 16);
         // (the table sampler's rays of one refill point everywhere — a sample index means a different direction for every surfel — and
         // part ways a level or two below the root: there a step pays from 8 lanes, 2 / 4 / 6 / 8 / 12 / 24 -> 49.1 / 48.2 / 47.9 / 47.8 /
         // 48.0 / 49.6 ms on the reference's own constants; profiles/r03/roofs/knobs_other_workloads.jsonl)
@@ -1266,7 +1276,8 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
             // (16-bit miss counters: a part of at most 65 535 samples)
             if (cut && (uint32_t)o.sample_count / p.parts <= 65535u - 1u) {
                 // the cuts of this launch's tiles (a wavefront per tile; kCutMax entries of four words each)
-                const CutWedges wedges = cut_wedges(o.sample_count, p.grid, p.parts, fine_tiles ? p.parts_fine : 0u);
+                const CutWedges wedges = o.sampler == AOB_SAMPLER_COSINE ? cut_wedges(o.sample_count, p.grid, p.parts, fine_tiles ? p.parts_fine : 0u)
+                                                                          : cut_wedges(0, p.grid, 99u, 0u);      // (the table's directions know no parts: one record)
                 p.cut_records = wedges.count > 0 ? (uint32_t)wedges.count : 1u;
                 const uint64_t words = ((uint64_t)p.ntiles * p.cut_records + 1u) * kCutWords;      // (one record of slack: the entry phase fetches 48 bytes past a list)
                 if (words > m.tile_cut_capacity) {
