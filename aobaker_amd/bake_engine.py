@@ -109,6 +109,18 @@ class Baker:
         capi.check(self.lib.aob_bake_copy_nodes4q(self.handle, out.ctypes.data, n.value))
         return out[:n.value]
 
+    def tile_cuts(self, material=0) -> np.ndarray:
+        """The tile cuts of the material's most recent trace launch: uint32 [tiles, records_per_tile, 128] (ref[32], then 32 x {x, y, z}
+        plane words), or an empty array if the launch walked from the root."""
+        tiles, records = C.c_uint32(), C.c_uint32()
+        rc = self.lib.aob_bake_copy_tile_cuts(self.handle, material, None, 0, C.byref(tiles), C.byref(records))
+        if tiles.value == 0:
+            capi.check(rc)
+            return np.zeros((0, 0, 128), dtype=np.uint32)
+        out = np.zeros((tiles.value, records.value, 128), dtype=np.uint32)
+        capi.check(self.lib.aob_bake_copy_tile_cuts(self.handle, material, out.ctypes.data, out.size, C.byref(tiles), C.byref(records)))
+        return out
+
     def surfel_count(self, material=0) -> int:
         n = C.c_uint64()
         capi.check(self.lib.aob_bake_surfel_count(self.handle, material, C.byref(n)))

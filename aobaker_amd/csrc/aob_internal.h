@@ -60,6 +60,7 @@ struct DeviceMaterial {
     uint32_t* perm = nullptr;             // trace order -> row-major rank (per section)
     uint32_t* tile_cuts = nullptr;        // 128 words per 64-surfel tile and sample part of a trace launch: the tile's cut of the tree (trace.hip k_tile_cuts)
     uint64_t  tile_cut_capacity = 0;      // ... in words
+    uint32_t  tile_cut_tiles = 0, tile_cut_records = 0;   // ... of the most recent launch (0 tiles: it walked from the root)
     uint32_t* tile_sums = nullptr;        // scan partials of the tile-order pass
     uint32_t* tile_row_prefix = nullptr;  // covered texels before each 8-texel tile row (first section)
     uint32_t* tile_row_prefix_host = nullptr;   // pinned copy

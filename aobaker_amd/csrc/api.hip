@@ -769,6 +769,20 @@ int aob_bake_copy_nodes4q(AobBake* b, AobBvh4QNode* dst, uint64_t capacity)
     return AOB_OK;
 }
 
+int aob_bake_copy_tile_cuts(AobBake* b, int32_t material, uint32_t* dst, uint64_t capacity_words, uint32_t* tiles, uint32_t* records_per_tile)
+{
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, material, true));
+    DeviceMaterial& m = b->materials[material];
+    if (!tiles || !records_per_tile) { set_error("tiles / records_per_tile is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
+    *tiles = m.tile_cut_tiles; *records_per_tile = m.tile_cut_records;
+    const uint64_t words = (uint64_t)m.tile_cut_tiles * m.tile_cut_records * 128u;
+    if (words == 0) return AOB_OK;
+    if (!dst || capacity_words < words) { set_error("tile cut buffer too small (%llu words needed)", (unsigned long long)words); return AOB_ERR_INVALID_ARGUMENT; }
+    AOB_HIP(hipMemcpyAsync(dst, m.tile_cuts, sizeof(uint32_t) * words, hipMemcpyDeviceToHost, b->stream));
+    AOB_HIP(hipStreamSynchronize(b->stream));
+    return AOB_OK;
+}
+
 int aob_bake_quant_frame(AobBake* b, AobQuantFrame* frame)
 {
     DeviceScope scope; AOB_TRY(check_bake(scope, b, 0, false));

@@ -1273,6 +1273,7 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
             }
             p.gstack = b->gstack;
             p.tile_cuts = nullptr; p.cut_records = 1u;
+            m.tile_cut_tiles = 0; m.tile_cut_records = 0;
             // (16-bit miss counters: a part of at most 65 535 samples)
             if (cut && (uint32_t)o.sample_count / p.parts <= 65535u - 1u) {
                 // the cuts of this launch's tiles (a wavefront per tile; kCutMax entries of four words each)
@@ -1290,6 +1291,7 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
                 hipLaunchKernelGGL(k_tile_cuts, dim3(p.ntiles), dim3(kWave), 0, s, m.frames, sb, se, b->nodes4q, b->quant_frame, p.node_count,
                                    fabsf(o.ray_bias), cut_entries, wedges, m.tile_cuts);
                 p.tile_cuts = m.tile_cuts;
+                m.tile_cut_tiles = p.ntiles; m.tile_cut_records = p.cut_records;
             }
             p.self_shape = m.section_mesh[si] + 1u;
             p.self_hidden = (b->meshes[m.section_mesh[si]].flags & AOB_MESH_HIDDEN_FROM_SELF) ? 1u : 0u;

@@ -350,6 +350,12 @@ int aob_bake_quant_frame(AobBake* bake, AobQuantFrame* frame);
  * index order, refs renumbered accordingly; node4q_count entries of AobBvh4QNode. */
 int aob_bake_node4q_count(AobBake* bake, uint64_t* count);
 int aob_bake_copy_nodes4q(AobBake* bake, AobBvh4QNode* dst, uint64_t capacity);
+/* The tile cuts the material's most recent trace launch walked from (trace_cut; any-hit walk of the quantised 4-ary nodes): per
+ * 64-surfel tile of the launch (trace order: 8x8-texel tiles) `records_per_tile` records of 128 words — ref[32], then the 32 entries'
+ * {x, y, z} plane words as in AobBvh4QNode, the entries in use first (in the cut's breadth-first list order), empty slots (planes
+ * 0x8000ffff) after.  One record per tile, or one per sample part (the coarse parts, then the fine ones) holding the entries that
+ * part's rays can reach.  *tiles = 0 if the launch used no cuts.  For the parity tests (the oracle's orc_tile_cut). */
+int aob_bake_copy_tile_cuts(AobBake* bake, int32_t material, uint32_t* dst, uint64_t capacity_words, uint32_t* tiles, uint32_t* records_per_tile);
 int aob_bake_surfel_count(AobBake* bake, int32_t material, uint64_t* count);
 int aob_bake_copy_surfels(AobBake* bake, int32_t material, AobSurfel* dst, uint64_t capacity);
 int aob_bake_copy_results(AobBake* bake, int32_t material, AobResult* dst, uint64_t capacity);

@@ -2336,6 +2336,220 @@ uint64_t orc_bvh_build_sah(const OrcTriangle* tris, uint64_t n, AobBvhNode* node
     return node_count;
 }
 
+/* A top-down binned-SAH BVH2 WITH SPATIAL SPLITS (Stich et al. 2009, "Spatial Splits in Bounding Volume Hierarchies" — the reference
+ * stack's `bvh.sah.use_splits`, RadeonRays/radeon_rays.h:288-294) in the AobBvhNode layout: a triangle that straddles a spatial split
+ * plane goes to BOTH sides as two references with clipped boxes, so the tree has more leaves than the scene has triangles (a leaf holds
+ * the whole triangle inline: testing it twice changes no answer).  Measurement only (tools/measure_spatial_splits.py): what splits would
+ * buy on long thin triangles.  `alpha`: a spatial split is tried where the object split's children overlap by more than alpha x the
+ * root's area (1e-5 in the paper); `max_refs`: the reference budget (splits stop when it is used up; 0: no splits at all = plain SAH).
+ * `nodes` holds node_capacity records (0 is returned if the tree needs more: the budget is checked before a node is split, and one split may
+ * overshoot it).  Returns the node count (2 * leaves - 1), *leaves_out = references. */
+typedef struct { uint32_t tri; Box box; } SRef;
+typedef struct { int32_t left, right; Box lbox, rbox; uint32_t tri; } STmp;     /* left < 0: a leaf of triangle `tri` */
+typedef struct {
+    const OrcTriangle* tris; STmp* tmp; uint64_t tmp_count, tmp_cap; uint64_t refs_total, max_refs; float alpha_area; uint32_t max_depth;
+} SBuild;
+
+static inline float box_area(const Box* b)
+{
+    const float dx = b->pmax[0] - b->pmin[0], dy = b->pmax[1] - b->pmin[1], dz = b->pmax[2] - b->pmin[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+static inline void box_empty(Box* b) { for (int k = 0; k < 3; k++) { b->pmin[k] = INFINITY; b->pmax[k] = -INFINITY; } }
+
+/* the box of triangle t clipped to lo <= x[axis] <= hi, inside `within` */
+static void clip_triangle_box(const OrcTriangle* t, int axis, float lo, float hi, const Box* within, Box* out)
+{
+    float poly[2][10][3]; int np = 3, cur = 0;
+    for (int i = 0; i < 3; i++) memcpy(poly[0][i], t->v[i], 12);
+    for (int pass = 0; pass < 2; pass++) {
+        const float plane = pass ? hi : lo, sgn = pass ? -1.0f : 1.0f;       /* keep sgn * (x - plane) >= 0 */
+        int nn = 0;
+        for (int i = 0; i < np; i++) {
+            const float* a = poly[cur][i]; const float* b = poly[cur][(i + 1) % np];
+            const float da = sgn * (a[axis] - plane), db = sgn * (b[axis] - plane);
+            if (da >= 0.0f) memcpy(poly[cur ^ 1][nn++], a, 12);
+            if ((da > 0.0f && db < 0.0f) || (da < 0.0f && db > 0.0f)) {
+                const float u = da / (da - db);
+                float* o = poly[cur ^ 1][nn++];
+                for (int k = 0; k < 3; k++) o[k] = a[k] + u * (b[k] - a[k]);
+                o[axis] = plane;
+            }
+        }
+        np = nn; cur ^= 1;
+        if (np == 0) break;
+    }
+    box_empty(out);
+    for (int i = 0; i < np; i++) for (int k = 0; k < 3; k++) { out->pmin[k] = fminf(out->pmin[k], poly[cur][i][k]); out->pmax[k] = fmaxf(out->pmax[k], poly[cur][i][k]); }
+    for (int k = 0; k < 3; k++) { out->pmin[k] = fmaxf(out->pmin[k], within->pmin[k]); out->pmax[k] = fminf(out->pmax[k], within->pmax[k]); }
+}
+
+static int32_t sbvh_node(SBuild* B, SRef* refs, uint32_t cnt, const Box* bounds, uint32_t depth, Box* box_out)
+{
+    enum { BINS = 16 };
+    *box_out = *bounds;
+    if (depth > B->max_depth) B->max_depth = depth;
+    if (B->tmp_count == B->tmp_cap) { B->tmp_cap *= 2; B->tmp = (STmp*)realloc(B->tmp, sizeof(STmp) * B->tmp_cap); }
+    const int32_t me = (int32_t)B->tmp_count++;
+    STmp* T = &B->tmp[me];
+    if (cnt == 1) { T->left = -1; T->right = -1; T->tri = refs[0].tri; *box_out = refs[0].box; return me; }
+    /* ---- object split: bins over the references' box centres ---- */
+    float cmin[3] = { INFINITY, INFINITY, INFINITY }, cmax[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (uint32_t i = 0; i < cnt; i++) for (int k = 0; k < 3; k++) {
+        const float c = 0.5f * (refs[i].box.pmin[k] + refs[i].box.pmax[k]);
+        cmin[k] = fminf(cmin[k], c); cmax[k] = fmaxf(cmax[k], c);
+    }
+    int o_axis = -1, o_split = 0; float o_cost = INFINITY; Box o_l, o_r; box_empty(&o_l); box_empty(&o_r);
+    for (int ax = 0; ax < 3; ax++) {
+        const float ext = cmax[ax] - cmin[ax];
+        if (!(ext > 0.0f)) continue;
+        Box bb[BINS]; uint32_t bc[BINS];
+        for (int q = 0; q < BINS; q++) { bc[q] = 0; box_empty(&bb[q]); }
+        for (uint32_t i = 0; i < cnt; i++) {
+            const float c = 0.5f * (refs[i].box.pmin[ax] + refs[i].box.pmax[ax]);
+            int q = (int)((c - cmin[ax]) / ext * (float)BINS); if (q >= BINS) q = BINS - 1; if (q < 0) q = 0;
+            bc[q]++; box_union(&bb[q], &bb[q], &refs[i].box);
+        }
+        Box rb[BINS]; uint32_t rc[BINS]; Box acc; box_empty(&acc); uint32_t c = 0;
+        for (int q = BINS - 1; q > 0; q--) { c += bc[q]; if (bc[q]) box_union(&acc, &acc, &bb[q]); rb[q] = acc; rc[q] = c; }
+        box_empty(&acc); c = 0;
+        for (int q = 0; q < BINS - 1; q++) {
+            c += bc[q]; if (bc[q]) box_union(&acc, &acc, &bb[q]);
+            if (c == 0 || rc[q + 1] == 0) continue;
+            const float cost = box_area(&acc) * (float)c + box_area(&rb[q + 1]) * (float)rc[q + 1];
+            if (cost < o_cost) { o_cost = cost; o_axis = ax; o_split = q + 1; o_l = acc; o_r = rb[q + 1]; }
+        }
+    }
+    /* ---- spatial split: bins over the node's box, straddlers clipped into every bin they touch ---- */
+    int s_axis = -1; float s_cost = INFINITY, s_plane = 0.0f;
+    int try_spatial = B->refs_total < B->max_refs;
+    if (try_spatial && o_axis >= 0) {
+        Box ov;                                           /* overlap of the object split's children */
+        float a = 1.0f;
+        for (int k = 0; k < 3; k++) { ov.pmin[k] = fmaxf(o_l.pmin[k], o_r.pmin[k]); ov.pmax[k] = fminf(o_l.pmax[k], o_r.pmax[k]); if (!(ov.pmax[k] > ov.pmin[k])) a = 0.0f; }
+        if (a == 0.0f || !(box_area(&ov) > B->alpha_area)) try_spatial = 0;
+    }
+    if (try_spatial) {
+        for (int ax = 0; ax < 3; ax++) {
+            const float lo = bounds->pmin[ax], ext = bounds->pmax[ax] - lo;
+            if (!(ext > 0.0f)) continue;
+            Box bb[BINS]; uint32_t en[BINS], ex[BINS];
+            for (int q = 0; q < BINS; q++) { en[q] = ex[q] = 0; box_empty(&bb[q]); }
+            for (uint32_t i = 0; i < cnt; i++) {
+                int q0 = (int)((refs[i].box.pmin[ax] - lo) / ext * (float)BINS), q1 = (int)((refs[i].box.pmax[ax] - lo) / ext * (float)BINS);
+                if (q0 < 0) q0 = 0; if (q0 >= BINS) q0 = BINS - 1; if (q1 < q0) q1 = q0; if (q1 >= BINS) q1 = BINS - 1;
+                en[q0]++; ex[q1]++;
+                if (q0 == q1) { box_union(&bb[q0], &bb[q0], &refs[i].box); continue; }
+                for (int q = q0; q <= q1; q++) {
+                    Box cb; clip_triangle_box(&B->tris[refs[i].tri], ax, lo + ext * (float)q / (float)BINS, lo + ext * (float)(q + 1) / (float)BINS, &refs[i].box, &cb);
+                    if (cb.pmax[0] >= cb.pmin[0] && cb.pmax[1] >= cb.pmin[1] && cb.pmax[2] >= cb.pmin[2]) box_union(&bb[q], &bb[q], &cb);
+                }
+            }
+            Box rb[BINS]; uint32_t rc[BINS]; Box acc; box_empty(&acc); uint32_t c = 0;
+            for (int q = BINS - 1; q > 0; q--) { c += ex[q]; box_union(&acc, &acc, &bb[q]); rb[q] = acc; rc[q] = c; }
+            box_empty(&acc); c = 0;
+            for (int q = 0; q < BINS - 1; q++) {
+                c += en[q]; box_union(&acc, &acc, &bb[q]);
+                if (c == 0 || rc[q + 1] == 0 || (c == cnt && rc[q + 1] == cnt)) continue;
+                const float cost = box_area(&acc) * (float)c + box_area(&rb[q + 1]) * (float)rc[q + 1];
+                if (cost < s_cost) { s_cost = cost; s_axis = ax; s_plane = lo + ext * (float)(q + 1) / (float)BINS; }
+            }
+        }
+    }
+    SRef* L = NULL; SRef* R = NULL; uint32_t nl = 0, nr = 0; Box lb, rbx; box_empty(&lb); box_empty(&rbx);
+    if (s_axis >= 0 && s_cost < o_cost) {
+        L = (SRef*)malloc(sizeof(SRef) * cnt); R = (SRef*)malloc(sizeof(SRef) * cnt);
+        for (uint32_t i = 0; i < cnt; i++) {
+            const SRef* r = &refs[i];
+            if (r->box.pmax[s_axis] <= s_plane) L[nl++] = *r;
+            else if (r->box.pmin[s_axis] >= s_plane) R[nr++] = *r;
+            else {
+                Box a, b2;
+                clip_triangle_box(&B->tris[r->tri], s_axis, -INFINITY, s_plane, &r->box, &a);
+                clip_triangle_box(&B->tris[r->tri], s_axis, s_plane, INFINITY, &r->box, &b2);
+                const int va = a.pmax[0] >= a.pmin[0] && a.pmax[1] >= a.pmin[1] && a.pmax[2] >= a.pmin[2];
+                const int vb = b2.pmax[0] >= b2.pmin[0] && b2.pmax[1] >= b2.pmin[1] && b2.pmax[2] >= b2.pmin[2];
+                if (va) { L[nl].tri = r->tri; L[nl].box = a; nl++; }
+                if (vb) { R[nr].tri = r->tri; R[nr].box = b2; nr++; }
+                if (va && vb) B->refs_total++;
+                if (!va && !vb) L[nl++] = *r;
+            }
+        }
+        if (nl == 0 || nr == 0 || (nl == cnt && nr == cnt)) { free(L); free(R); L = R = NULL; nl = nr = 0; }      /* the split separated nothing */
+    }
+    if (!L) {
+        L = (SRef*)malloc(sizeof(SRef) * cnt); R = (SRef*)malloc(sizeof(SRef) * cnt);
+        if (o_axis >= 0) {
+            const float ext = cmax[o_axis] - cmin[o_axis];
+            for (uint32_t i = 0; i < cnt; i++) {
+                const float c = 0.5f * (refs[i].box.pmin[o_axis] + refs[i].box.pmax[o_axis]);
+                int q = (int)((c - cmin[o_axis]) / ext * (float)BINS); if (q >= BINS) q = BINS - 1; if (q < 0) q = 0;
+                if (q < o_split) L[nl++] = refs[i]; else R[nr++] = refs[i];
+            }
+        }
+        if (nl == 0 || nr == 0) { nl = cnt / 2; nr = cnt - nl; memcpy(L, refs, sizeof(SRef) * nl); memcpy(R, refs + nl, sizeof(SRef) * nr); }
+    }
+    for (uint32_t i = 0; i < nl; i++) box_union(&lb, &lb, &L[i].box);
+    for (uint32_t i = 0; i < nr; i++) box_union(&rbx, &rbx, &R[i].box);
+    Box got;
+    const int32_t li = sbvh_node(B, L, nl, &lb, depth + 1, &got); T = &B->tmp[me]; T->lbox = got;
+    free(L);
+    const int32_t ri = sbvh_node(B, R, nr, &rbx, depth + 1, &got); T = &B->tmp[me]; T->rbox = got;
+    free(R);
+    T->left = li; T->right = ri; T->tri = 0;
+    box_union(box_out, &T->lbox, &T->rbox);
+    return me;
+}
+
+uint64_t orc_bvh_build_sbvh(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes, uint64_t node_capacity, uint64_t max_refs, float alpha, uint32_t* depth_out, uint64_t* leaves_out)
+{
+    if (depth_out) *depth_out = 0;
+    if (leaves_out) *leaves_out = 0;
+    if (n == 0) return 0;
+    SBuild B; memset(&B, 0, sizeof B);
+    B.tris = tris; B.refs_total = n; B.max_refs = max_refs > n ? max_refs : n;
+    const uint64_t cap = 2 * B.max_refs + 16;
+    B.tmp = (STmp*)malloc(sizeof(STmp) * cap); B.tmp_cap = cap;
+    SRef* refs = (SRef*)malloc(sizeof(SRef) * n);
+    Box root; box_empty(&root);
+    for (uint64_t i = 0; i < n; i++) {
+        refs[i].tri = (uint32_t)i;
+        for (int k = 0; k < 3; k++) {
+            refs[i].box.pmin[k] = fminf(fminf(tris[i].v[0][k], tris[i].v[1][k]), tris[i].v[2][k]);
+            refs[i].box.pmax[k] = fmaxf(fmaxf(tris[i].v[0][k], tris[i].v[1][k]), tris[i].v[2][k]);
+        }
+        box_union(&root, &root, &refs[i].box);
+    }
+    B.alpha_area = alpha * box_area(&root);
+    Box got;
+    sbvh_node(&B, refs, (uint32_t)n, &root, 0, &got);
+    free(refs);
+    /* emit: inner nodes in creation order (root = 0), leaves in depth-first order */
+    const uint64_t total = B.tmp_count, leaves = (total + 1) / 2, leaf_base = leaves - 1;
+    if (total > node_capacity) { free(B.tmp); return 0; }
+    uint32_t* index = (uint32_t*)malloc(4 * total);
+    uint64_t ni = 0, nl2 = 0;
+    /* creation order is depth-first preorder: a leaf's rank among the leaves in that order is its depth-first position */
+    for (uint64_t i = 0; i < total; i++) index[i] = B.tmp[i].left < 0 ? (uint32_t)(leaf_base + nl2++) : (uint32_t)ni++;
+    memset(nodes, 0, sizeof(AobBvhNode) * total);
+    for (uint64_t i = 0; i < total; i++) {
+        const STmp* t = &B.tmp[i];
+        AobBvhNode* nd = &nodes[index[i]];
+        if (t->left < 0) {
+            const OrcTriangle* tr = &tris[t->tri];
+            memcpy(nd->lmin_or_v0, tr->v[0], 12); memcpy(nd->lmax_or_v1, tr->v[1], 12); memcpy(nd->rmin_or_v2, tr->v[2], 12);
+            nd->addr_left = AOB_INVALID_ADDR; nd->addr_right = 0; nd->shape_id = tr->shape_id; nd->prim_id = tr->prim_id;
+        } else {
+            memcpy(nd->lmin_or_v0, t->lbox.pmin, 12); memcpy(nd->lmax_or_v1, t->lbox.pmax, 12); nd->addr_left = index[t->left];
+            memcpy(nd->rmin_or_v2, t->rbox.pmin, 12); memcpy(nd->rmax, t->rbox.pmax, 12); nd->addr_right = index[t->right];
+        }
+    }
+    free(index); free(B.tmp);
+    if (depth_out) *depth_out = B.max_depth;
+    if (leaves_out) *leaves_out = leaves;
+    return total;
+}
+
 /* ------------------------------------------------------------------------ */
 /* resolve + bleed + format conversion                                       */
 

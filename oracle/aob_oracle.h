@@ -197,6 +197,8 @@ int orc_kary_visits(const AobBvhNode* nodes2, uint64_t node_count2, const OrcRay
 uint64_t orc_bvh_build_sah(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes, uint32_t* depth);
 /* the any-hit walk with a tile's entry list (trace.hip, ENTRY mode), counted per phase: tests/measure_entry_lists.py */
 typedef struct OrcEntryStats { uint64_t rays, hits, inner_visits, leaf_visits, entries_tested, mask_bits; } OrcEntryStats;
+/* binned SAH with spatial splits, measurement only (tools/measure_spatial_splits.py) */
+uint64_t orc_bvh_build_sbvh(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes, uint64_t node_capacity, uint64_t max_refs, float alpha, uint32_t* depth, uint64_t* leaves);
 /* tile cuts (trace.hip CUT mode): a cut of the 4-ary tree for a tile's box, and the any-hit walk from it, counted */
 int32_t orc_tile_cut(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const float lo[3], const float hi[3],
                      int32_t max_entries, int32_t rule, uint32_t* out);

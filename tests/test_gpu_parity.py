@@ -811,3 +811,55 @@ def test_row_window_bakes_stitch_to_the_full_bake(engine, orc, name, parts):
             b.rasterize(0, (8, m.height + 8))
     assert n_sum == n_full
     assert np.array_equal(stitched["total_bits"], full["total_bits"]) and np.array_equal(stitched["weight_bits"], full["weight_bits"])
+
+
+# ---- tile cuts: the records k_tile_cuts writes against the oracle's orc_tile_cut, and their culling by sample part ------------
+def test_tile_cuts_match_the_oracle_and_cull_only_what_no_ray_enters(engine, orc):
+    """The cut of every tile is the oracle's (same breadth-first rule, same budget, bit for bit); a part's record holds a subset of
+    it in the same order, and every entry that ANY ray of the part enters (the oracle's slab test on the oracle's rays) is in it —
+    culling by sample part drops only what the part's rays cannot reach."""
+    flat = FlatScene(scenes.terrain_scene(grid=96, atlas=64, seed=3, bpc=4))
+    for sampler, spp in ((capi.SAMPLER_COSINE, 64), (capi.SAMPLER_REFERENCE_COMPAT, 16)):
+        opt = make_options(orc, sample_count=spp, bvh_builder=2, **MODES[2])
+        opt.sampler = sampler
+        if sampler == capi.SAMPLER_REFERENCE_COMPAT:
+            opt.accumulate = capi.ACCUMULATE_QUANTISED
+        with Baker(flat, opt) as b:
+            b.build_bvh(); b.rasterize(0); b.trace(0)
+            cuts = b.tile_cuts(0)
+            n4q, (_, frame) = b.nodes4q(), b.nodes2q()
+            lt = b.leaf_tris()
+            surfels = b.surfels(0)
+        tiles, records, _ = cuts.shape
+        # 8 x 8 tiles; one record per tile, or one per sample part: 4 coarse (+ 8 fine where the queues end in half-length units)
+        assert tiles == 64 and records in ((4, 12) if sampler == capi.SAMPLER_COSINE else (1,))
+        grid = surfels.reshape(64, 64)
+        margin = np.float32(abs(opt.ray_bias))
+        for t in range(tiles):
+            ty, tx = divmod(t, 8)
+            sub = np.ascontiguousarray(grid[8 * ty:8 * ty + 8, 8 * tx:8 * tx + 8].reshape(-1))
+            pos = sub["position"].astype(np.float32)
+            want = orc.tile_cut(n4q, frame, pos.min(axis=0) - margin, pos.max(axis=0) + margin, 32, 1)
+            full = np.concatenate([want[:, :1], want[:, 1:]], axis=1)
+            rays = np.ascontiguousarray(orc.generate_rays(sub, None, opt, 64, hemisphere=orc.compat_table(opt) if sampler == capi.SAMPLER_REFERENCE_COMPAT else None))
+            _, _, masks = orc.cut_walk(n4q, frame, lt, rays, want, want_masks=True)
+            masks = masks.reshape(64, spp)
+            for r in range(records):
+                rec = cuts[t, r]
+                refs, planes = rec[:32], rec[32:].reshape(32, 3)
+                used = int((planes[:, 0] != 0x8000ffff).sum())
+                got = np.concatenate([refs[:used, None], planes[:used]], axis=1)
+                assert (planes[used:] == 0x8000ffff).all()
+                if records == 1:
+                    assert np.array_equal(got, full), (t, r)
+                    continue
+                # a subsequence of the full cut, in its order
+                rows = {tuple(x): i for i, x in enumerate(full.tolist())}
+                idx = [rows[tuple(x)] for x in got.tolist()]
+                assert idx == sorted(idx) and len(set(idx)) == len(idx), (t, r)
+                # the part's samples: coarse part r of 4, or fine part r - 4 of 8
+                parts, q = (4, r) if r < 4 else (8, r - 4)
+                i0, i1 = spp * q // parts, spp * (q + 1) // parts
+                entered = int(np.bitwise_or.reduce(masks[:, i0:i1].reshape(-1)))
+                live = sum(1 << i for i in idx)
+                assert entered & ~live == 0, (t, r, bin(entered), bin(live))
