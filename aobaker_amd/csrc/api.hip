@@ -452,7 +452,10 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
             // (128 words per record, a record per sample part — 4 coarse + 8 fine with the default schedule; a launch that needs more
             // re-allocates: trace.hip)
             d.tile_cut_capacity = ((cells / 64 + scene->mesh_count + 1) * (options->sampler == AOB_SAMPLER_COSINE ? 12 : 1) + 1) * 128;
-            plan.want(&d.tile_cuts, d.tile_cut_capacity);
+            // (96 bytes per texel: planned with everything else up to 8 GiB — a 8192^2 atlas — beyond that allocated by the first launch
+            // that wants them, which walks from the root if they do not fit)
+            if (d.tile_cut_capacity * sizeof(uint32_t) <= (8ull << 30)) plan.want(&d.tile_cuts, d.tile_cut_capacity);
+            else d.tile_cut_capacity = 0;
         }
         const uint64_t tiles_x = (uint64_t)(d.width + 7) / 8, tiles_y = (uint64_t)(d.height + 7) / 8;
         plan.want(&d.tile_sums, (tiles_x * tiles_y * 64 + 2047) / 2048 + 1);

@@ -1281,17 +1281,21 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
                                                                           : cut_wedges(0, p.grid, 99u, 0u);      // (the table's directions know no parts: one record)
                 p.cut_records = wedges.count > 0 ? (uint32_t)wedges.count : 1u;
                 const uint64_t words = ((uint64_t)p.ntiles * p.cut_records + 1u) * kCutWords;      // (one record of slack: the entry phase fetches 48 bytes past a list)
+                bool room = true;
                 if (words > m.tile_cut_capacity) {
                     AOB_HIP(hipStreamSynchronize(s));
                     release_device(b, m.tile_cuts);
                     m.tile_cuts = nullptr; m.tile_cut_capacity = 0;
-                    AOB_HIP(hipMalloc((void**)&m.tile_cuts, sizeof(uint32_t) * words));
-                    m.tile_cut_capacity = words;
+                    // (the cuts are an accelerator, not a result: without the memory for them the launch walks from the root)
+                    if (hipMalloc((void**)&m.tile_cuts, sizeof(uint32_t) * words) == hipSuccess) m.tile_cut_capacity = words;
+                    else { (void)hipGetLastError(); m.tile_cuts = nullptr; room = false; }
                 }
+                if (room) {
                 hipLaunchKernelGGL(k_tile_cuts, dim3(p.ntiles), dim3(kWave), 0, s, m.frames, sb, se, b->nodes4q, b->quant_frame, p.node_count,
                                    fabsf(o.ray_bias), cut_entries, wedges, m.tile_cuts);
                 p.tile_cuts = m.tile_cuts;
                 m.tile_cut_tiles = p.ntiles; m.tile_cut_records = p.cut_records;
+                } else p.cut_records = 1u;
             }
             p.self_shape = m.section_mesh[si] + 1u;
             p.self_hidden = (b->meshes[m.section_mesh[si]].flags & AOB_MESH_HIDDEN_FROM_SELF) ? 1u : 0u;
