@@ -158,15 +158,16 @@ static constexpr uint32_t kEmptyPlanes = 0x8000ffffu;   // an empty slot's inver
 
 // Which entries of its tile's cut can a UNIT's rays reach at all?  A unit traces one part of the samples: with the COSINE
 // sampler's stratification that is a range of rows of the grid, i.e. of the azimuth in every surfel's own frame — rays of part
-// p of 4 leave a surfel inside one quadrant of its tangent plane.  Such a ray stays in the cone {P + a X' + b N + c Z' : a, b, c
-// >= 0} (X', Z' the wedge's two inward boundary normals): an entry whose box — grown by a margin far above the rounding of
+// p of 4 leave a surfel inside one quadrant of its tangent plane.  Such a ray stays in the cone {P + a u0 + b N + c u1 : a, b, c
+// >= 0} (u0, u1 the wedge's two boundary directions in the tangent plane): an entry whose box — grown by a margin far above the rounding of
 // any of this — lies wholly on the negative side of one of the three planes for EVERY surfel of the tile cannot be entered
 // by any ray of the unit, and the entry phase of k_trace skips it for the whole unit (a third of the entries on BASELINE
-// configs[2]; the prototype checked the entered ones against it: tools/measure_tile_cuts.py).
+// configs[2]; tests/test_gpu_parity.py::test_tile_cuts_match_the_oracle_and_cull_only_what_no_ray_enters checks every part's record
+// against the entries the oracle's rays of that part enter).
 struct CutWedges {
-    int32_t count;                          // wedges (0: no culling, live[0] = every entry)
+    int32_t count;                          // wedges = records per tile (0: no culling, one record with every entry)
     int32_t lines;                          // distinct boundary lines
-    float line_s[kCutLines], line_c[kCutLines];      // normal of line l in the surfel's tangent plane: -s X + c Z
+    float line_s[kCutLines], line_c[kCutLines];      // boundary line l in the surfel's tangent plane: direction c X + s Z (its plane through N: normal (c X + s Z) x N)
     uint32_t need_pos[kCutLines];           // wedges whose cone lies on the positive side of line l ...
     uint32_t need_neg[kCutLines];           // ... on the negative side
 };
