@@ -834,12 +834,14 @@ def test_tile_cuts_match_the_oracle_and_cull_only_what_no_ray_enters(engine, orc
         # 8 x 8 tiles; one record per tile, or one per sample part: 4 coarse (+ 8 fine where the queues end in half-length units)
         assert tiles == 64 and records in ((4, 12) if sampler == capi.SAMPLER_COSINE else (1,))
         grid = surfels.reshape(64, 64)
-        margin = np.float32(abs(opt.ray_bias))
+        shrink = np.float32(0.25)                       # k_tile_cuts: the tile's box pulled in by a quarter of its extent on every side
         for t in range(tiles):
             ty, tx = divmod(t, 8)
             sub = np.ascontiguousarray(grid[8 * ty:8 * ty + 8, 8 * tx:8 * tx + 8].reshape(-1))
             pos = sub["position"].astype(np.float32)
-            want = orc.tile_cut(n4q, frame, pos.min(axis=0) - margin, pos.max(axis=0) + margin, 32, 1)
+            pmin, pmax = pos.min(axis=0), pos.max(axis=0)
+            pull = shrink * (pmax - pmin)
+            want = orc.tile_cut(n4q, frame, pmin + pull, pmax - pull, 32, 1)
             full = np.concatenate([want[:, :1], want[:, 1:]], axis=1)
             rays = np.ascontiguousarray(orc.generate_rays(sub, None, opt, 64, hemisphere=orc.compat_table(opt) if sampler == capi.SAMPLER_REFERENCE_COMPAT else None))
             _, _, masks = orc.cut_walk(n4q, frame, lt, rays, want, want_masks=True)

@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--grid", type=int, default=708)
     ap.add_argument("--atlas", type=int, default=2048)
     ap.add_argument("--builder", type=int, default=2)
+    ap.add_argument("--margin", type=float, default=None, help="tile box margin, may be negative (default: |ray bias| + 1e-5)")
+    ap.add_argument("--shrink", type=float, default=0.0, help="the tile box pulled in by this fraction of its extent on every side (k_tile_cuts: kCutShrink)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     from aobaker_amd import capi, scenes
@@ -94,7 +96,7 @@ def main():
            "rays": int(r), "hit_rate": round(plain.hits / r, 4),
            "plain_walk": {"inner_visits_per_ray": round(plain.inner_visits / r, 3), "triangle_tests_per_ray": round(plain.leaf_visits / r, 3)},
            "cuts": []}
-    margin = abs(opt.ray_bias) + 1e-5
+    margin = abs(opt.ray_bias) + 1e-5 if args.margin is None else args.margin
     for rule in [int(x) for x in args.rule.split(",")]:
         for E in [int(x) for x in args.entries.split(",")]:
             es = OrcEntryStats()
@@ -102,8 +104,10 @@ def main():
             cut = np.zeros(4 * 64, dtype=np.uint32)
             for sub, rays in zip(tiles, ray_sets):
                 pos = sub["position"].astype(np.float32)
-                lo = np.ascontiguousarray(pos.min(axis=0) - np.float32(margin), dtype=np.float32)
-                hi = np.ascontiguousarray(pos.max(axis=0) + np.float32(margin), dtype=np.float32)
+                pmin, pmax = pos.min(axis=0), pos.max(axis=0)
+                pull = np.float32(args.shrink) * (pmax - pmin)
+                lo = np.ascontiguousarray((pmin + pull) - np.float32(margin), dtype=np.float32)
+                hi = np.ascontiguousarray((pmax - pull) + np.float32(margin), dtype=np.float32)
                 m = lib.orc_tile_cut(n4q_c.ctypes.data, len(n4q_c), frame_c.ctypes.data, lo.ctypes.data, hi.ctypes.data, E, rule, cut.ctypes.data)
                 lengths.append(m)
                 rc = lib.orc_cut_walk(n4q_c.ctypes.data, len(n4q_c), frame_c.ctypes.data, lt_c.ctypes.data, rays.ctypes.data, len(rays), cut.ctypes.data, m, C.byref(es), None, None)
