@@ -813,13 +813,46 @@ def test_row_window_bakes_stitch_to_the_full_bake(engine, orc, name, parts):
     assert np.array_equal(stitched["total_bits"], full["total_bits"]) and np.array_equal(stitched["weight_bits"], full["weight_bits"])
 
 
-# ---- tile cuts: the records k_tile_cuts writes against the oracle's orc_tile_cut, and their culling by sample part ------------
-def test_tile_cuts_match_the_oracle_and_cull_only_what_no_ray_enters(engine, orc):
-    """The cut of every tile is the oracle's (same breadth-first rule, same budget, bit for bit); a part's record holds a subset of
-    it in the same order, and every entry that ANY ray of the part enters (the oracle's slab test on the oracle's rays) is in it —
-    culling by sample part drops only what the part's rays cannot reach."""
+# ---- tile cuts: the records k_tile_cuts writes against the oracle's orc_tile_cut, and the per-part records against the oracle's rays --
+def _slots_of(n4q16, node):
+    """The non-empty slots of a quantised 4-ary node as cut rows {ref, x, y, z plane words}."""
+    rows = []
+    for j in range(4):
+        c = n4q16[node, 4 * j:4 * j + 4]
+        if c[0] == 0x8000ffff and c[1] == 0x8000ffff and c[2] == 0x8000ffff:
+            continue
+        rows.append((int(c[3]), int(c[0]), int(c[1]), int(c[2])))
+    return rows
+
+
+def _leaf_slots_reached(orc, n4q, n4q16, frame, lt, rays, rows):
+    """The leaf slots ANY of the rays enters below the given slots (the oracle's slab test, level by level; no early exit): what a
+    walk that starts at these slots can ever test."""
+    reached, frontier = set(), list(rows)
+    while frontier:
+        nxt = []
+        for at in range(0, len(frontier), 64):
+            chunk = frontier[at:at + 64]
+            _, _, masks = orc.cut_walk(n4q, frame, lt, rays, np.array(chunk, dtype=np.uint32), want_masks=True)
+            entered = int(np.bitwise_or.reduce(masks))
+            for e, row in enumerate(chunk):
+                if not (entered >> e) & 1:
+                    continue
+                if row[0] & 0x80000000:
+                    reached.add(row[0])
+                else:
+                    nxt += _slots_of(n4q16, row[0])
+        frontier = nxt
+    return reached
+
+
+def test_tile_cuts_match_the_oracle_and_every_part_record_reaches_what_the_root_walk_reaches(engine, orc):
+    """Without sample parts (the table sampler) the cut of every tile is the oracle's (same breadth-first rule, same budget, bit for
+    bit).  With them every part has its own record — the common cut culled by the part's wedge: its entries are slots of the tree,
+    none below another, and the leaf slots the part's rays (the oracle's rays, the oracle's slab test, no early exit) can reach
+    from the record are EXACTLY those they reach from the root (so the test holds for ANY rule that picks a part's entries)."""
     flat = FlatScene(scenes.terrain_scene(grid=96, atlas=64, seed=3, bpc=4))
-    for sampler, spp in ((capi.SAMPLER_COSINE, 64), (capi.SAMPLER_REFERENCE_COMPAT, 16)):
+    for sampler, spp in ((capi.SAMPLER_COSINE, 64), (capi.SAMPLER_COSINE, 256), (capi.SAMPLER_REFERENCE_COMPAT, 16)):
         opt = make_options(orc, sample_count=spp, bvh_builder=2, **MODES[2])
         opt.sampler = sampler
         if sampler == capi.SAMPLER_REFERENCE_COMPAT:
@@ -832,20 +865,26 @@ def test_tile_cuts_match_the_oracle_and_cull_only_what_no_ray_enters(engine, orc
             surfels = b.surfels(0)
         tiles, records, _ = cuts.shape
         # 8 x 8 tiles; one record per tile, or one per sample part: 4 coarse (+ 8 fine where the queues end in half-length units)
-        assert tiles == 64 and records in ((4, 12) if sampler == capi.SAMPLER_COSINE else (1,))
+        want_records = 1 if sampler == capi.SAMPLER_REFERENCE_COMPAT else (12 if spp == 256 else 4)
+        assert tiles == 64 and records == want_records
+        n4q16 = np.ascontiguousarray(n4q).view(np.uint32).reshape(-1, 16)
+        slot_planes, parent = {}, {}
+        for node in range(len(n4q16)):
+            for row in _slots_of(n4q16, node):
+                slot_planes[row[0]] = row[1:]
+                parent[row[0]] = node
         grid = surfels.reshape(64, 64)
         shrink = np.float32(0.25)                       # k_tile_cuts: the tile's box pulled in by a quarter of its extent on every side
-        for t in range(tiles):
+        for t in (range(tiles) if records == 1 else (0, 7, 9, 15, 27, 36, 47, 63)):
             ty, tx = divmod(t, 8)
             sub = np.ascontiguousarray(grid[8 * ty:8 * ty + 8, 8 * tx:8 * tx + 8].reshape(-1))
             pos = sub["position"].astype(np.float32)
             pmin, pmax = pos.min(axis=0), pos.max(axis=0)
             pull = shrink * (pmax - pmin)
             want = orc.tile_cut(n4q, frame, pmin + pull, pmax - pull, 32, 1)
-            full = np.concatenate([want[:, :1], want[:, 1:]], axis=1)
+            common = {int(x) for x in want[:, 0]}
             rays = np.ascontiguousarray(orc.generate_rays(sub, None, opt, 64, hemisphere=orc.compat_table(opt) if sampler == capi.SAMPLER_REFERENCE_COMPAT else None))
-            _, _, masks = orc.cut_walk(n4q, frame, lt, rays, want, want_masks=True)
-            masks = masks.reshape(64, spp)
+            rays = rays.reshape(64, spp)
             for r in range(records):
                 rec = cuts[t, r]
                 refs, planes = rec[:32], rec[32:].reshape(32, 3)
@@ -853,15 +892,22 @@ def test_tile_cuts_match_the_oracle_and_cull_only_what_no_ray_enters(engine, orc
                 got = np.concatenate([refs[:used, None], planes[:used]], axis=1)
                 assert (planes[used:] == 0x8000ffff).all()
                 if records == 1:
-                    assert np.array_equal(got, full), (t, r)
+                    assert np.array_equal(got, want), (t, r)
                     continue
-                # a subsequence of the full cut, in its order
-                rows = {tuple(x): i for i, x in enumerate(full.tolist())}
-                idx = [rows[tuple(x)] for x in got.tolist()]
-                assert idx == sorted(idx) and len(set(idx)) == len(idx), (t, r)
+                # slots of the tree, each once, none an ancestor of another
+                rows = [tuple(int(v) for v in x) for x in got.tolist()]
+                mine = {row[0] for row in rows}
+                assert len(mine) == len(rows), (t, r)
+                for row in rows:
+                    assert slot_planes[row[0]] == row[1:], (t, r, row)
+                    node = parent[row[0]]
+                    while node != 0:
+                        assert node not in mine, (t, r, row, node)
+                        node = parent[node]
+                assert mine <= common, (t, r)
                 # the part's samples: coarse part r of 4, or fine part r - 4 of 8
                 parts, q = (4, r) if r < 4 else (8, r - 4)
-                i0, i1 = spp * q // parts, spp * (q + 1) // parts
-                entered = int(np.bitwise_or.reduce(masks[:, i0:i1].reshape(-1)))
-                live = sum(1 << i for i in idx)
-                assert entered & ~live == 0, (t, r, bin(entered), bin(live))
+                part_rays = np.ascontiguousarray(rays[:, spp * q // parts:spp * (q + 1) // parts].reshape(-1))
+                from_root = _leaf_slots_reached(orc, n4q, n4q16, frame, lt, part_rays, _slots_of(n4q16, 0))
+                from_record = _leaf_slots_reached(orc, n4q, n4q16, frame, lt, part_rays, rows)
+                assert from_record == from_root, (t, r, len(from_root), len(from_record))
