@@ -83,6 +83,9 @@ __device__ __forceinline__ uint4 as_uint4(v4u v) { return make_uint4(v.x, v.y, v
 #ifndef AOB_CUT_SHRINK_PCT
 #define AOB_CUT_SHRINK_PCT 25        // k_tile_cuts opens the slots that meet the tile's box PULLED IN by this share of its extent on every side
 #endif
+#ifndef AOB_GEN_ORDER
+#define AOB_GEN_ORDER 1             // 1: the COSINE sampler's units generate their samples from the last to the first; 0: in index order
+#endif
 #ifndef AOB_CUT_SCALAR
 #define AOB_CUT_SCALAR 0           // CUT mode: scalar steps after a refill, from the node its first ray starts on (measured: slower)
 #endif
@@ -529,7 +532,15 @@ void k_trace(TraceParams p)
     const int32_t gen_begin = (int32_t)((int64_t)p.spp * part / nparts);
     const int32_t gen_end = n_valid ? (int32_t)((int64_t)p.spp * (part + 1u) / nparts) : gen_begin;
     int32_t gen_next = gen_begin;    // wave-uniform: next sample index
-    int32_t gen_cy = gen_begin / p.grid.sx, gen_cx = gen_begin - gen_cy * p.grid.sx;     // ... and its cell of the COSINE sampler's grid
+    // The ORDER in which a unit's samples are generated is free: a sample's ray depends on its index alone, and the sums do not care.  The COSINE
+    // sampler's units go through their samples from the LAST to the first: every row of the stratified grid from its last cell — the most grazing
+    // directions, the longest walks — to its first, the steepest and shortest.  The last rays of a unit, which the wavefront drains with most of its
+    // lanes idle before it takes the next unit, are then its cheapest.  Inner sections after a unit's last ray was generated: 5.8 % of all at 10.8
+    // lanes -> 2.0 % at 5.0; 44.0 -> 43.1 ms on BASELINE configs[2], 3.58 -> 3.42 on configs[1], closest hit (configs[4]'s scene) 177.2 -> 173.1
+    // (profiles/r04/cuts/generation_order_ab.jsonl; column-major and alternating orders: no better).
+    constexpr bool GEN_DOWN = AOB_GEN_ORDER == 1 && SAMPLER == AOB_SAMPLER_COSINE;
+    const int32_t gen_first = GEN_DOWN && gen_end > gen_begin ? gen_end - 1 : gen_begin;
+    int32_t gen_cy = gen_first / p.grid.sx, gen_cx = gen_first - gen_cy * p.grid.sx;     // the next sample's cell of the COSINE sampler's grid
     uint32_t q_head = 0, q_count = 0;                   // wave-uniform: the queue is a ring of 64 rays
 
     // ---- the ray a lane is tracing ----
@@ -751,10 +762,12 @@ void k_trace(TraceParams p)
                 // rays left in the queue: every idle lane was served
                 if (pass == 1 || q_count != 0u || gen_next >= gen_end) break;
                 // the queue is empty: sample gen_next of all 64 surfels, one per lane
-                const int32_t i = gen_next++;
+                const int32_t i = GEN_DOWN ? gen_end - 1 - (gen_next - gen_begin) : gen_next;
+                gen_next++;
                 AOB_STAT(7, 1);
                 const int32_t cell_x = gen_cx, cell_y = gen_cy;
-                if (++gen_cx == p.grid.sx) { gen_cx = 0; gen_cy++; }
+                if (GEN_DOWN) { if (gen_cx-- == 0) { gen_cx = p.grid.sx - 1; gen_cy--; } }
+                else if (++gen_cx == p.grid.sx) { gen_cx = 0; gen_cy++; }
                 if (valid) {
                     const float4* fr = p.frames + 4ull * (wave_first + lane);
                     const float4 a = fr[0], b = fr[1], c = fr[2];
@@ -929,7 +942,7 @@ void k_trace(TraceParams p)
         }
 
         // ---- inner section: intersect_bvh2_lds.cl:108-160 ----
-        if (inner_m) { AOB_STAT(1, 1); AOB_STAT(2, __popcll(inner_m)); }
+        if (inner_m) { AOB_STAT(1, 1); AOB_STAT(2, __popcll(inner_m)); if (!more) AOB_STAT(10, (1ull << 40) + (unsigned long long)__popcll(inner_m)); }
         if (inner) {
           if (QUANT == 2) {
             // ---- 4-ary node: four slab tests per visit, children ranked only when the order matters ----

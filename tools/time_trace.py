@@ -89,15 +89,20 @@ def child(modes, reps, knobs):
                 b.clear_results(0); b.trace(0); b.sync()
                 b.lib.aob_debug_trace_stats(buf)
                 names = ("loop_iterations", "inner_sections", "inner_lanes", "leaf_sections", "leaf_lanes", "refill_sections", "pops", "generation_batches",
-                         "cut_entries_tested", "cut_entries_entered", "unused10", "deep_stack_visits")
+                         "cut_entries_tested", "cut_entries_entered", "drain_packed", "deep_stack_visits")
                 stats = {k: int(buf[i]) for i, k in enumerate(names)}
+                # (inner sections run after the unit's last ray was generated: sections << 40 | lanes)
+                stats["drain_inner_sections"], stats["drain_inner_lanes"] = stats["drain_packed"] >> 40, stats["drain_packed"] & ((1 << 40) - 1)
+                del stats["drain_packed"]
                 rays = n * spp
                 stats["per_ray"] = {"loop_iterations": round(stats["loop_iterations"] / rays, 4), "inner_visits": round(stats["inner_lanes"] / rays, 3),
                                     "leaf_visits": round(stats["leaf_lanes"] / rays, 3),
                                     "lanes_per_inner_section": round(stats["inner_lanes"] / max(1, stats["inner_sections"]), 2),
                                     "lanes_per_leaf_section": round(stats["leaf_lanes"] / max(1, stats["leaf_sections"]), 2),
                                     "pops_per_refill": round(stats["pops"] / max(1, stats["refill_sections"]), 2),
-                                    "inner_sections_with_a_deep_stack": round(stats["deep_stack_visits"] / max(1, stats["inner_sections"]), 4)}
+                                    "inner_sections_with_a_deep_stack": round(stats["deep_stack_visits"] / max(1, stats["inner_sections"]), 4),
+                                    "inner_sections_in_the_drain": round(stats["drain_inner_sections"] / max(1, stats["inner_sections"]), 4),
+                                    "lanes_per_inner_section_in_the_drain": round(stats["drain_inner_lanes"] / max(1, stats["drain_inner_sections"]), 2)}
         best = min(ms[1:])
         print(json.dumps({"lib": os.path.relpath(lib, ROOT) if lib != "-" else "in-tree", "mode": mode, "knobs": knobs, "trace_ms": round(best, 3),
                           "all_ms": [round(x, 3) for x in ms], "grays_per_s": round(n * spp / best / 1e6, 3), "results_crc32": crc,
