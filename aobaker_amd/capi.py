@@ -12,7 +12,7 @@ import importlib.util
 import os
 import sys
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # ---- enums (include/aobaker.h) ------------------------------------------------
 AOB_OK = 0
@@ -118,7 +118,7 @@ class AobStats(C.Structure):
         ("surfel_count", C.c_uint64),
         ("ray_count", C.c_uint64),
         ("bvh_depth", C.c_uint32),
-        ("reserved0", C.c_uint32),
+        ("trace_cuts", C.c_uint32),
         ("ms_upload", C.c_float),
         ("ms_bvh_build", C.c_float),
         ("ms_rasterize", C.c_float),
@@ -167,7 +167,7 @@ def result_dtype():
 # built library exports exactly these
 EXPORTED_SYMBOLS = [
     "aob_init", "aob_shutdown", "aob_default_options", "aob_bake", "aob_last_error",
-    "aob_abi_version",
+    "aob_abi_version", "aob_resolve_bvh_builder",
     "aob_bake_create", "aob_bake_destroy", "aob_bake_build_bvh", "aob_bake_rasterize",
     "aob_bake_trace", "aob_bake_resolve", "aob_bake_download", "aob_bake_run_device",
     "aob_bake_sync", "aob_bake_get_stats", "aob_bake_clear_results",
@@ -225,6 +225,7 @@ def load() -> C.CDLL:
         "aob_bake": (C.c_int, [P(AobSceneDesc), P(AobOptions), P(AobStats)]),
         "aob_last_error": (C.c_char_p, []),
         "aob_abi_version": (C.c_int, []),
+        "aob_resolve_bvh_builder": (C.c_int, [P(AobOptions), u64, u64]),
         "aob_bake_create": (C.c_int, [P(AobSceneDesc), P(AobOptions), P(vp)]),
         "aob_bake_destroy": (None, [vp]),
         "aob_bake_build_bvh": (C.c_int, [vp]),

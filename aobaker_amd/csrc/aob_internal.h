@@ -154,7 +154,8 @@ int ensure_nodes(AobBake* b);                                // the fp32 BVH2 no
 int ensure_nodes2q(AobBake* b);                              // the quantised BVH2 node array (`nodes2q`)
 int rasterize_material(AobBake* b, int32_t material, int32_t row_begin, int32_t row_end);   // raster.hip (syncs once per section)
 int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end);   // trace.hip
+void reserve_tile_cuts(AobBake* b, int32_t material);        // trace.hip: the tile cuts of the material's launches, sized by what was rasterised
+int reserve_trace_stack(AobBake* b);                         // trace.hip: the walk's HBM overflow stack, sized by the tree's depth
 int resolve_material(AobBake* b, int32_t material);          // resolve.hip
-int trace4_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end);  // trace4.hip
 uint64_t chunk_texel_max(const AobOptions& opt);             // trace.hip (BakeEngine.cpp:359-364)
 }

@@ -108,8 +108,10 @@ static int validate_options(const AobOptions* o)
     if (o->raster_layers == AOB_LAYERS_ALL && o->raster_mode == AOB_RASTER_CONSERVATIVE) { set_error("raster_layers ALL needs raster_mode REFERENCE"); return AOB_ERR_UNSUPPORTED; }
     if (o->morton_adaptive != 0 && o->morton_adaptive != 1) { set_error("morton_adaptive %d: must be 0 or 1", o->morton_adaptive); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->material_ranges != 0 && o->material_ranges != 1) { set_error("material_ranges %d: must be 0 or 1", o->material_ranges); return AOB_ERR_INVALID_ARGUMENT; }
-    if (o->bvh_builder < 0 || o->bvh_builder > 2) { set_error("bvh_builder %d: must be 0 (LBVH), 1 (PLOC) or 2 (PLOC clusters under a binned-SAH top)", o->bvh_builder); return AOB_ERR_INVALID_ARGUMENT; }
+    if (o->bvh_builder < -1 || o->bvh_builder > 2) { set_error("bvh_builder %d: must be -1 (by workload), 0 (LBVH), 1 (PLOC) or 2 (PLOC clusters under a binned-SAH top)", o->bvh_builder); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->bvh_width != 0 && o->bvh_width != 2 && o->bvh_width != 4) { set_error("bvh_width %d: must be 0, 2 or 4", o->bvh_width); return AOB_ERR_INVALID_ARGUMENT; }
+    // (the quad-per-ray walk of the fp32 4-ary nodes was an experiment, 2.7x slower than the default; retired in round 5: tools/experiments/trace4.hip)
+    if (o->bvh_width == 4 && !o->bvh_quantised) { set_error("bvh_width 4 needs bvh_quantised 1 (the fp32 4-ary walk is retired: tools/experiments/trace4.hip); the fp32 nodes are walked with bvh_width 2"); return AOB_ERR_UNSUPPORTED; }
     if (o->trace_refill_idle < 0 || o->trace_refill_idle > 64 || o->trace_leaf_wait < 0 || o->trace_leaf_wait > 64) { set_error("trace_refill_idle %d / trace_leaf_wait %d: must be 0 (default) or 1..64", o->trace_refill_idle, o->trace_leaf_wait); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->trace_parts < 0 || o->trace_parts > 64 || o->trace_part_min < 0 || o->trace_fine_div < 0) { set_error("trace_parts %d (0..64), trace_part_min %d, trace_fine_div %d: must not be negative", o->trace_parts, o->trace_part_min, o->trace_fine_div); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->trace_scalar_min < 0 || o->trace_scalar_min > 64) { set_error("trace_scalar_min %d: must be 0 (default) or 1..64", o->trace_scalar_min); return AOB_ERR_INVALID_ARGUMENT; }
@@ -200,7 +202,8 @@ static int ensure_depth(AobBake* b)
     AOB_HIP(hipStreamSynchronize(b->stream));
     b->bvh_depth = b->node_count > 1 ? b->pinned[1] : 0;
     b->depth_known = true;
-    return AOB_OK;
+    // the walk's HBM overflow stack, for the deepest walk this tree allows: allocated here, once per tree, not by a trace launch
+    return reserve_trace_stack(b);
 }
 
 } // namespace aob
@@ -223,6 +226,19 @@ int aob_abi_version(void) { return AOB_ABI_VERSION; }
 
 const char* aob_last_error(void) { return g_error; }
 
+// bvh_builder -1: the builder by workload.  The SAH top costs 0.35 .. 0.64 ms more build than PLOC alone and takes 5 % of the node visits off
+// any-hit rays on the terrain (61.0 -> 58.3 ms of trace at 1.07 G rays — BASELINE configs[2] —, about even at 67 M —
+// configs[1]); closest-hit rays do not gain (configs[4]: 1.7 .. 2.5 % slower); and a scene of at most kSahTopClusters triangles would get a
+// full top-down tree over triangle centres, which long thin triangles punish (hairball: +57 % visits) — there PLOC stays.
+// The ray count is not known before the rasterisation: texels x samples bounds it from above.
+int aob_resolve_bvh_builder(const AobOptions* options, uint64_t texels, uint64_t triangles)
+{
+    if (!options) return 1;
+    if (options->bvh_builder >= 0) return options->bvh_builder;
+    const uint64_t rays = texels * (uint64_t)(options->sample_count > 0 ? options->sample_count : 0);
+    return (options->use_any_hit && rays >= (1ull << 28) && triangles > 131072ull) ? 2 : 1;
+}
+
 void aob_default_options(AobOptions* o)
 {
     if (!o) return;
@@ -244,7 +260,7 @@ void aob_default_options(AobOptions* o)
     // measured fastest on MI355X (profiles/): lane-per-ray walk of the 64-byte quantised 4-ary nodes
     o->bvh_width = 4;
     o->bvh_quantised = 1;
-    o->bvh_builder = 1;           // PLOC (2, the SAH top, pays from a few hundred million rays per bake on: include/aobaker.h)
+    o->bvh_builder = AOB_BVH_BUILDER_AUTO;   // by workload: PLOC, or PLOC under the binned-SAH top where the bake is long enough to pay for it (aob_resolve_bvh_builder)
     o->morton_adaptive = 1;
     o->raster_mode = AOB_RASTER_REFERENCE;
     o->raster_layers = AOB_LAYERS_LAST;
@@ -384,6 +400,12 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
     }
     b->triangle_count = tri_total;
     const uint64_t n = tri_total;
+    {
+        // bvh_builder -1: the builder by workload, settled here for the life of the handle
+        uint64_t texels = 0;
+        for (uint32_t i = 0; i < scene->material_count; i++) texels += (uint64_t)scene->materials[i].width * (uint64_t)scene->materials[i].height;
+        b->opt.bvh_builder = aob_resolve_bvh_builder(options, texels, tri_total);
+    }
     // shape ids start at 1 (RadeonRays/radeon_rays.h:238): bit s of the set is mesh s - 1
     std::vector<uint32_t> bits((scene->mesh_count + 1 + 31) / 32 + 1, 0u);
     for (uint32_t i = 0; i < scene->mesh_count; i++)
@@ -446,17 +468,10 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
         plan.want(&d.section_index, cells);
         plan.want(&d.frames, 4 * cells);
         plan.want(&d.perm, cells);
-        // a cut per 64-surfel tile of a trace launch (any-hit walk of the quantised 4-ary nodes with the COSINE sampler, trace.hip):
-        // every section's last tile may be ragged, hence one tile of slack per mesh; lists that outgrow it are re-allocated
-        if (options->use_any_hit && options->bvh_quantised && options->bvh_width == 4 && options->trace_cut != 1) {
-            // (128 words per record, a record per sample part — 4 coarse + 8 fine with the default schedule; a launch that needs more
-            // re-allocates: trace.hip)
-            d.tile_cut_capacity = ((cells / 64 + scene->mesh_count + 1) * (options->sampler == AOB_SAMPLER_COSINE ? 12 : 1) + 1) * 128;
-            // (96 bytes per texel: planned with everything else up to 8 GiB — a 8192^2 atlas — beyond that allocated by the first launch
-            // that wants them, which walks from the root if they do not fit)
-            if (d.tile_cut_capacity * sizeof(uint32_t) <= (8ull << 30)) plan.want(&d.tile_cuts, d.tile_cut_capacity);
-            else d.tile_cut_capacity = 0;
-        }
+        // (The tile cuts of a trace launch — 512 B per 64-surfel tile and sample part, up to 96 B per covered texel with the COSINE
+        // sampler's default schedule — are NOT part of the arena: they are an accelerator, sized by what a rasterisation actually covered
+        // (a rank of a multi-GPU bake covers 1/N of the rows), allocated when the rasterisation ends (trace.hip ensure_tile_cuts), and a
+        // bake that cannot have them still bakes: it walks from the root and says so, AobStats::trace_cuts = 2.)
         const uint64_t tiles_x = (uint64_t)(d.width + 7) / 8, tiles_y = (uint64_t)(d.height + 7) / 8;
         plan.want(&d.tile_sums, (tiles_x * tiles_y * 64 + 2047) / 2048 + 1);
         plan.want(&d.tile_row_prefix, tiles_y + 1);

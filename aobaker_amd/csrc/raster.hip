@@ -548,6 +548,10 @@ int rasterize_material(AobBake* b, int32_t material, int32_t row_begin, int32_t 
     }
     AOB_HIP(hipGetLastError());
     m.rasterized = true;
+    // the tile cuts of this material's trace launches, sized by what was covered (a strip of rows: a strip's worth) — here, so that no trace
+    // launch carries an allocation; without the memory the launches walk from the root and the bake says so (trace.hip ensure_tile_cuts)
+    b->stats.trace_cuts = 0u;
+    reserve_tile_cuts(b, material);
     return AOB_OK;
 }
 

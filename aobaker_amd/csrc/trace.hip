@@ -168,8 +168,8 @@ static constexpr uint32_t kEmptyPlanes = 0x8000ffffu;   // an empty slot's inver
 // >= 0} (u0, u1 the wedge's two boundary directions in the tangent plane): an entry whose box — grown by a margin far above the rounding of
 // any of this — lies wholly on the negative side of one of the three planes for EVERY surfel of the tile cannot be entered
 // by any ray of the unit, and the entry phase of k_trace skips it for the whole unit (a third of the entries on BASELINE
-// configs[2]; tests/test_gpu_parity.py::test_tile_cuts_match_the_oracle_and_cull_only_what_no_ray_enters checks every part's record
-// against the entries the oracle's rays of that part enter).
+// configs[2]; tests/test_gpu_parity.py::test_tile_cuts_match_the_oracle_and_every_part_record_reaches_what_the_root_walk_reaches checks
+// that the leaf slots a part's rays reach from its record are exactly those they reach from the root).
 struct CutWedges {
     int32_t count;                          // wedges = records per tile (0: no culling, one record with every entry)
     int32_t lines;                          // distinct boundary lines
@@ -180,7 +180,7 @@ struct CutWedges {
 
 __global__ __launch_bounds__(64)
 void k_tile_cuts(const float4* __restrict__ frames, uint64_t begin, uint64_t end, const uint4* __restrict__ nodes4q,
-                 const float* __restrict__ quant_frame, uint32_t node_count, float shrink, int max_entries, CutWedges W,
+                 const float* __restrict__ quant_frame, uint32_t node_count, float shrink, int max_entries, float reach2, CutWedges W,
                  uint32_t* __restrict__ out)
 {
     __shared__ uint4 list[kCutList];
@@ -216,6 +216,25 @@ void k_tile_cuts(const float4* __restrict__ frames, uint64_t begin, uint64_t end
         glo[q] = sc > 0.0f ? ((lo[q] + pull) - o) / sc : -INFINITY;
         ghi[q] = sc > 0.0f ? ((hi[q] - pull) - o) / sc : INFINITY;
     }
+    // Rays of bounded REACH (round 5: closest-hit scoring with tmax clamped to the falloff distance, a material range): the tile's rays start at
+    // the surfels' positions — inside the box [lo, hi] — and end within `reach` of them, so a slot whose box lies farther than that from the box
+    // holds no triangle any of them can hit.  Such a slot never joins the list (not when the root's slots start it, not when an opened entry's
+    // slots are appended), and an opened entry counts only the slots it appends against the budget: the cut spends its entries on the part of
+    // the tree the rays can reach.  The distance in float, exactly as the oracle's cut_within_reach computes it (orc_tile_cut_reach).
+    const float flo[3] = { lo[0], lo[1], lo[2] }, fhi[3] = { hi[0], hi[1], hi[2] };
+    auto kept = [&](const uint4& c) -> bool {
+        if (c.x == kEmptyPlanes && c.y == kEmptyPlanes && c.z == kEmptyPlanes) return false;
+        if (!(reach2 > 0.0f)) return true;
+        const uint32_t w[3] = { c.x, c.y, c.z };
+        float d2 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const float bmin = fmaf((float)(w[q] & 0x7fffu), qs[q], qo[q]), bmax = fmaf((float)((w[q] >> 16) & 0x7fffu), qs[q], qo[q]);
+            const float gap = fmaxf(fmaxf(bmin - fhi[q], flo[q] - bmax), 0.0f);
+            d2 = fmaf(gap, gap, d2);
+        }
+        return d2 <= reach2;
+    };
     // Breadth first, a level at a time: every lane looks at one entry of the level — an inner slot whose box meets the tile's box is
     // a candidate and fetches its node — then the candidates are admitted IN LIST ORDER while the cut still fits (the same cut as
     // opening them one by one, orc_tile_cut: a candidate's children go to the end of the list, behind the whole level), and the
@@ -225,7 +244,7 @@ void k_tile_cuts(const float4* __restrict__ frames, uint64_t begin, uint64_t end
         {
             uint4 c = make_uint4(0u, 0u, 0u, 0u);
             bool there = false;
-            if (lane < 4u) { c = nodes4q[lane]; there = !(c.x == kEmptyPlanes && c.y == kEmptyPlanes && c.z == kEmptyPlanes); }
+            if (lane < 4u) { c = nodes4q[lane]; there = kept(c); }
             const uint64_t m0 = __ballot(there);
             if (there) { const int at = __popcll(m0 & ((1ull << lane) - 1ull)); list[at] = make_uint4(c.w, c.x, c.y, c.z); dead[at] = 0u; }
             n = live = __popcll(m0);
@@ -249,8 +268,7 @@ void k_tile_cuts(const float4* __restrict__ frames, uint64_t begin, uint64_t end
                 if (cand) {
                     const uint4* np = nodes4q + 4ull * en.x;
                     k0 = np[0]; k1 = np[1]; k2 = np[2]; k3 = np[3];
-                    auto empty = [](const uint4& c) { return c.x == kEmptyPlanes && c.y == kEmptyPlanes && c.z == kEmptyPlanes; };
-                    present = (empty(k0) ? 0u : 1u) | (empty(k1) ? 0u : 2u) | (empty(k2) ? 0u : 4u) | (empty(k3) ? 0u : 8u);
+                    present = (kept(k0) ? 1u : 0u) | (kept(k1) ? 2u : 0u) | (kept(k2) ? 4u : 0u) | (kept(k3) ? 8u : 0u);
                 }
                 const int kids = __popc(present);
                 // admit in list order (wave-uniform loop over the candidates)
@@ -339,7 +357,7 @@ void k_tile_cuts(const float4* __restrict__ frames, uint64_t begin, uint64_t end
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) ok |= __shfl_xor(ok, off);
-            if ((ok >> lane) & 1u) mine |= 1u << e;
+            if (lane < (uint32_t)W.count && ((ok >> lane) & 1u)) mine |= 1u << e;
         }
     }
     // one record per part: its live entries in list order, then empty slots
@@ -385,6 +403,20 @@ __device__ __forceinline__ bool slab4q_anyhit(const uint4& c, const f3& invdir, 
     return tn <= fminf(fminf(tfx, tfy), tfz);
 }
 
+// ... and of the closest-hit walk (intersect_bvh2_lds.cl:54-63 on the plane floats), for the entry phase of a ray that has no hit yet:
+// near clamped at 0, far at the ray's span.  The expressions of visit4's closest-hit slab, on plain FMAs (the same values).
+__device__ __forceinline__ bool slab4q_closest(const uint4& c, const f3& invdir, const f3& oxinvdir, const uint3& nsel, const uint3& fsel, float bound)
+{
+    constexpr uint32_t kHalf = 0x3f000000u;
+    const float nx = __uint_as_float(__builtin_amdgcn_perm(kHalf, c.x, nsel.x)), fx = __uint_as_float(__builtin_amdgcn_perm(kHalf, c.x, fsel.x));
+    const float ny = __uint_as_float(__builtin_amdgcn_perm(kHalf, c.y, nsel.y)), fy = __uint_as_float(__builtin_amdgcn_perm(kHalf, c.y, fsel.y));
+    const float nz = __uint_as_float(__builtin_amdgcn_perm(kHalf, c.z, nsel.z)), fz = __uint_as_float(__builtin_amdgcn_perm(kHalf, c.z, fsel.z));
+    const float tnx = fmaf(nx, invdir.x, oxinvdir.x), tfx = fmaf(fx, invdir.x, oxinvdir.x);
+    const float tny = fmaf(ny, invdir.y, oxinvdir.y), tfy = fmaf(fy, invdir.y, oxinvdir.y);
+    const float tnz = fmaf(nz, invdir.z, oxinvdir.z), tfz = fmaf(fz, invdir.z, oxinvdir.z);
+    const float tn = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), 0.0f);
+    return tn <= fminf(fminf(fminf(tfx, tfy), tfz), bound);
+}
 
 // exact float -> Q32.32 (a float times 2^32 is exact; the conversion truncates)
 __device__ __forceinline__ long long f2fix(float v)
@@ -421,7 +453,13 @@ void k_trace(TraceParams p)
     // the entries a ray entered; the miss counters shrink to 16 bits (a part is at most 65 535 samples: trace_range) and the
     // 128 bytes they free hold the entries' refs.
     constexpr bool CUT = CUTMODE != 0;
-    static_assert(!CUT || (QUANT == 2 && ANYHIT), "tile cuts: any-hit walk of the quantised 4-ary nodes");
+    static_assert(!CUT || QUANT == 2, "tile cuts: the walk of the quantised 4-ary nodes");
+    // Closest-hit rays below a cut (round 5): the entries a ray entered are walked one after the other, the LAST of the list first — the
+    // deepest, the small boxes around the tile, where a short ray's nearest hit is — each in the usual near-first order, the closest hit
+    // carried from one to the next.  The cut's subtrees partition the tree, so the triangles a ray can reach are those of the walk from the
+    // root; the minimum over the hits does not depend on the order they are found in, except where a hit lies within rounding of a box
+    // face that a nearer hit has already culled — the oracle walks the product's own cuts in the same order (orc_cut_walk_closest,
+    // tests/test_gpu_parity.py::test_closest_hit_below_tile_cuts_is_the_oracles_walk_of_the_same_cuts) and the walk from the root besides.
     // (the table sampler's weight dot(N, d) is made again when the ray is popped — the same expression on the same numbers, for one more
     // 16-byte load of the surfel's record — and the refs take a stack entry's room: launch_stack)
     __shared__ uint32_t miss_count[COUNT32 ? (CUT ? kWave / 2 : kWave) : 1];
@@ -795,15 +833,17 @@ void k_trace(TraceParams p)
                         f3 ox = make_f3(-go.x * gi.x, -go.y * gi.y, -go.z * gi.z);
                         ox = make_f3(fmaf(q_origin.x, gi.x, ox.x), fmaf(q_origin.y, gi.y, ox.y), fmaf(q_origin.z, gi.z, ox.z));
                         f3 iv = make_f3(q_scale.x * gi.x, q_scale.y * gi.y, q_scale.z * gi.z);
-                        iv = make_f3(iv.x * p.inv_tmax, iv.y * p.inv_tmax, iv.z * p.inv_tmax);
-                        ox = make_f3(ox.x * p.inv_tmax, ox.y * p.inv_tmax, ox.z * p.inv_tmax);
+                        if (ANYHIT) {
+                            iv = make_f3(iv.x * p.inv_tmax, iv.y * p.inv_tmax, iv.z * p.inv_tmax);
+                            ox = make_f3(ox.x * p.inv_tmax, ox.y * p.inv_tmax, ox.z * p.inv_tmax);
+                        }
                         constexpr uint32_t kLow = 0x0701000cu, kHigh = 0x0703020cu;
                         const uint3 ns = make_uint3((__float_as_uint(gi.x) >> 31) ? kHigh : kLow, (__float_as_uint(gi.y) >> 31) ? kHigh : kLow, (__float_as_uint(gi.z) >> 31) ? kHigh : kLow);
                         const uint3 fs = make_uint3(ns.x ^ (kLow ^ kHigh), ns.y ^ (kLow ^ kHigh), ns.z ^ (kLow ^ kHigh));
                         // mask = 2 * mask + (the ray enters the box): the compare's carry goes in with one v_addc_co_u32
                         auto shift_in = [&](const uint4& bx) {
                             float tn;
-                            const bool h = slab4q_anyhit(bx, iv, ox, ns, fs, tn);
+                            const bool h = ANYHIT ? slab4q_anyhit(bx, iv, ox, ns, fs, tn) : slab4q_closest(bx, iv, ox, ns, fs, p.tmax);
                             asm("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(entry_mask) : "s"(__ballot(h)) : "vcc");
                         };
                         {
@@ -879,9 +919,16 @@ void k_trace(TraceParams p)
         // boxes far from the tile: 51.9 -> 50.3 ms on BASELINE configs[2] against deepest first) ----
         if (CUT && AOB_CUT_LAZY) {
             if (addr == kInvalid && pending != 0u) {
-                const uint32_t hb = (uint32_t)__clz((int)pending);
-                addr = cut_refs[hb - cut_shift];
-                pending &= ~(0x80000000u >> hb);
+                if (ANYHIT) {
+                    const uint32_t hb = (uint32_t)__clz((int)pending);
+                    addr = cut_refs[hb - cut_shift];
+                    pending &= ~(0x80000000u >> hb);
+                } else {
+                    // closest hit: the deepest entry first (bit 0 of the mask is the list's last entry)
+                    const uint32_t lb = (uint32_t)__builtin_ctz(pending);
+                    addr = cut_refs[cut_count - 1u - lb];
+                    pending &= pending - 1u;
+                }
                 spa = sp_first;                     // (the pop that found the sentinel left the stack top below entry 1)
             }
         }
@@ -1091,9 +1138,9 @@ template <int SAMPLER, int ANYHIT, int ACCUM, int MASKED>
 static void launch_stack(int quant, dim3 grid, hipStream_t s, const TraceParams& p)
 {
     constexpr int N = lds_stack_entries(SAMPLER, ANYHIT, ACCUM);
-    constexpr bool CAN_CUT = AOB_TRACE_CUT && ANYHIT;
-    // (a cut's 32 refs: with unit weights the 16-bit miss counters make their room, otherwise a stack entry does)
-    constexpr int NC = SAMPLER == AOB_SAMPLER_COSINE ? N : N - 1;
+    constexpr bool CAN_CUT = AOB_TRACE_CUT != 0;
+    // (a cut's 32 refs: with unit weights and any-hit scoring the 16-bit miss counters make their room, otherwise a stack entry does)
+    constexpr int NC = (SAMPLER == AOB_SAMPLER_COSINE && ANYHIT) ? N : N - 1;
     if (quant == 2 && CAN_CUT && p.tile_cuts) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, NC, 2, MASKED, CAN_CUT ? 1 : 0>), grid, dim3(kWave), 0, s, p);
     else if (quant == 2) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 2, MASKED, 0>), grid, dim3(kWave), 0, s, p);
     else if (quant == 1) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 1, MASKED, 0>), grid, dim3(kWave), 0, s, p);
@@ -1174,6 +1221,84 @@ uint64_t chunk_texel_max(const AobOptions& opt)
 // a schedule field of AobOptions: 0 means the default aob_default_options writes
 static int knob(int32_t value, int fallback) { return value > 0 ? value : fallback; }
 
+// The tile cuts of a material's trace launches: 128 words per 64-surfel tile and record (a record per sample part with the COSINE sampler).
+// They are an accelerator, not a result: allocated on their own (not in the bake's arena), sized by what the rasterisation covered, when the
+// rasterisation ends (rasterize_material -> reserve_tile_cuts) — so a rank that rasterised a strip holds a strip's worth — and again by a
+// launch whose schedule wants more.  Without the memory the launch walks from the root: same cells, slower — and NOT silently:
+// AobStats::trace_cuts becomes 2 and aob_last_error() holds a warning.
+static bool ensure_tile_cuts(AobBake* b, DeviceMaterial& m, uint64_t words)
+{
+    if (words <= m.tile_cut_capacity) return true;
+    (void)hipStreamSynchronize(b->stream);
+    release_device(b, m.tile_cuts);
+    m.tile_cuts = nullptr; m.tile_cut_capacity = 0;
+    if (hipMalloc((void**)&m.tile_cuts, sizeof(uint32_t) * words) == hipSuccess) { m.tile_cut_capacity = words; return true; }
+    (void)hipGetLastError();
+    m.tile_cuts = nullptr;
+    b->stats.trace_cuts = 2u;
+    set_error("warning: %.1f MiB for the tile cuts of a %dx%d material could not be allocated: its rays walk from the root (same results, slower; AobStats::trace_cuts = 2)",
+              (double)(sizeof(uint32_t) * words) / 1048576.0, m.width, m.height);
+    return false;
+}
+
+static bool cuts_apply(const AobBake* b)
+{
+    const AobOptions& o = b->opt;
+    return AOB_TRACE_CUT && o.bvh_quantised && o.bvh_width == 4 && o.trace_cut != 1;
+}
+
+// the sample parts per tile of a launch (and whether the last tiles of a queue are cut finer): trace_range's schedule
+static uint32_t schedule_parts(const AobOptions& o)
+{
+    return (uint32_t)max(1, min(o.trace_parts > 0 ? o.trace_parts : 4, o.sample_count / (o.trace_part_min > 0 ? o.trace_part_min : 16)));
+}
+
+void reserve_tile_cuts(AobBake* b, int32_t material)
+{
+    if (!cuts_apply(b)) return;
+    DeviceMaterial& m = b->materials[material];
+    if (m.surfel_count == 0) return;
+    const uint32_t parts = schedule_parts(b->opt);
+    const uint64_t records = b->opt.sampler == AOB_SAMPLER_COSINE ? 3ull * parts : 1ull;       // coarse parts + twice as many fine ones
+    const uint64_t tiles = m.surfel_count / 64 + m.section_offsets.size() + 1;
+    (void)ensure_tile_cuts(b, m, (tiles * records + 1) * (uint64_t)kCutWords);
+}
+
+// The overflow stack of the walk (entries beyond those a lane keeps in LDS): sized when the tree is built (build_bvh -> reserve_gstack) for
+// the deepest walk any mode of this bake makes, so that no trace launch carries an allocation; a failure is an error, not a fallback.
+int reserve_gstack(AobBake* b, uint64_t words)
+{
+    if (words <= b->gstack_words) return AOB_OK;
+    AOB_HIP(hipStreamSynchronize(b->stream));
+    if (b->gstack) AOB_HIP(hipFree(b->gstack));
+    b->gstack = nullptr; b->gstack_words = 0;
+    AOB_HIP(hipMalloc((void**)&b->gstack, sizeof(uint32_t) * words));
+    b->gstack_words = words;
+    return AOB_OK;
+}
+
+static uint32_t stack_overflow_entries(const AobBake* b, bool cut)
+{
+    const AobOptions& o = b->opt;
+    // a lane's stack holds the sentinel plus at most one deferred sibling per tree level
+    // (the 4-ary walk defers up to three children per 4-ary level)
+    const uint32_t need = ((o.bvh_quantised && o.bvh_width == 4) ? 3u * ((b->bvh_depth + 2) / 2) + 2u : b->bvh_depth + 2) + (cut && !AOB_CUT_LAZY ? (uint32_t)kCutMax : 0u);
+    // 8, 10 or 11 stack entries per lane live in LDS (2 KB + 1 KB of sums, 2.5 KB + 512 B of totals, or 2.75 KB + 256 B of counters, + 2 KB of queued
+    // rays per wavefront = 32 wavefronts per CU); a launch below tile cuts gives one of them to the cut's refs unless the 16-bit miss counters make
+    // their room (COSINE sampler, any hit); deeper entries — rare — go to an HBM array.
+    const uint32_t in_lds = (uint32_t)lds_stack_entries(o.sampler, o.use_any_hit, o.accumulate) - (cut && !(o.sampler == AOB_SAMPLER_COSINE && o.use_any_hit) ? 1u : 0u);
+    return need > in_lds ? need - in_lds : 0u;
+}
+
+int reserve_trace_stack(AobBake* b)
+{
+    if (b->node_count == 0) return AOB_OK;
+    // (with and without cuts: a launch that cannot have its cuts keeps one more entry in LDS, never fewer)
+    const uint32_t overflow = max(stack_overflow_entries(b, cuts_apply(b)), stack_overflow_entries(b, false));
+    if (!overflow) return AOB_OK;
+    return reserve_gstack(b, (uint64_t)(32u * (uint32_t)b->cu_count) * kWave * overflow);
+}
+
 int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
 {
     DeviceMaterial& m = b->materials[material];
@@ -1181,20 +1306,10 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
     if (end > m.surfel_count) end = m.surfel_count;
     hipStream_t s = b->stream;
     AOB_HIP(hipEventRecord(b->ev_trace[0], s));
-    if (begin < end && o.bvh_width == 4 && !o.bvh_quantised) {
-        if (b->any_mesh_flags) { set_error("section visibility flags need a lane-per-ray structure (bvh_quantised 1 or bvh_width 2)"); return AOB_ERR_UNSUPPORTED; }
-        AOB_TRY(trace4_range(b, material, begin, end));        // quad-per-ray, 4-ary nodes (trace4.hip)
-    } else if (begin < end) {
-        // a lane's stack holds the sentinel plus at most one deferred sibling per tree level
-        // (the 4-ary walk defers up to three children per 4-ary level)
-        // (a walk that starts below a tile cut holds, besides, up to kCutMax start refs)
-        const bool cut = AOB_TRACE_CUT && o.bvh_quantised && o.bvh_width == 4 && o.use_any_hit && b->node_count > 0 && o.trace_cut != 1;
+    if (begin < end) {
+        const bool cut = cuts_apply(b) && b->node_count > 0;
         const int cut_entries = o.trace_cut >= 4 ? min(o.trace_cut, kCutMax) : kCutMax;
-        const uint32_t need = ((o.bvh_quantised && o.bvh_width == 4) ? 3u * ((b->bvh_depth + 2) / 2) + 2u : b->bvh_depth + 2) + (cut && !AOB_CUT_LAZY ? (uint32_t)kCutMax : 0u);
-        // 8, 10 or 11 stack entries per lane live in LDS (2 KB + 1 KB of sums, 2.5 KB + 512 B of totals, or 2.75 KB + 256 B of counters, + 2 KB of queued
-        // rays per wavefront = 32 wavefronts per CU); deeper entries — rare — go to an HBM array.
-        const uint32_t in_lds = (uint32_t)lds_stack_entries(o.sampler, o.use_any_hit, o.accumulate) - (cut && o.sampler != AOB_SAMPLER_COSINE ? 1u : 0u);
-        const uint32_t overflow = need > in_lds ? need - in_lds : 0u;
+        if (!cut && b->stats.trace_cuts != 2u) b->stats.trace_cuts = 0u;
         TraceParams p;
         if (!o.bvh_quantised) AOB_TRY(ensure_nodes(b));
         else if (o.bvh_width != 4) AOB_TRY(ensure_nodes2q(b));
@@ -1258,7 +1373,7 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
             // Adding the parts is exact with integer cells and with float cells that hold whole numbers (unit weights, any hit); float
             // cells that hold fractions go through 64-bit accumulators and are rounded once after the launch (k_acc_to_cells).
             const bool split_direct = o.accumulate == AOB_ACCUMULATE_QUANTISED || (o.sampler == AOB_SAMPLER_COSINE && o.use_any_hit);
-            p.parts = (uint32_t)max(1, min(knob(o.trace_parts, 4), o.sample_count / knob(o.trace_part_min, 16)));
+            p.parts = schedule_parts(o);
             const bool through_acc = !split_direct && p.parts > 1u;
             if (through_acc) {
                 const uint64_t cells = (uint64_t)m.width * m.height;
@@ -1296,15 +1411,6 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
             dim3 grid(min(resident, (p.units_per_xcd * 8u + 7u) / 8u * 8u));
             AOB_HIP(hipMemsetAsync(b->trace_unit_next, 0, 8 * sizeof(uint32_t), s));
             p.unit_next = b->trace_unit_next;
-            const uint64_t words = (uint64_t)grid.x * kWave * (overflow ? overflow : 1u);
-            if (overflow && words > b->gstack_words) {
-                AOB_HIP(hipStreamSynchronize(s));
-                if (b->gstack) AOB_HIP(hipFree(b->gstack));
-                b->gstack = nullptr; b->gstack_words = 0;
-                AOB_HIP(hipMalloc((void**)&b->gstack, sizeof(uint32_t) * words));
-                b->gstack_words = words;
-            }
-            p.gstack = b->gstack;
             p.tile_cuts = nullptr; p.cut_records = 1u;
             m.tile_cut_tiles = 0; m.tile_cut_records = 0;
             // (16-bit miss counters: a part of at most 65 535 samples)
@@ -1314,22 +1420,24 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
                                                                           : cut_wedges(0, p.grid, 99u, 0u);      // (the table's directions know no parts: one record)
                 p.cut_records = wedges.count > 0 ? (uint32_t)wedges.count : 1u;
                 const uint64_t words = ((uint64_t)p.ntiles * p.cut_records + 1u) * kCutWords;      // (one record of slack: the entry phase fetches 48 bytes past a list)
-                bool room = true;
-                if (words > m.tile_cut_capacity) {
-                    AOB_HIP(hipStreamSynchronize(s));
-                    release_device(b, m.tile_cuts);
-                    m.tile_cuts = nullptr; m.tile_cut_capacity = 0;
-                    // (the cuts are an accelerator, not a result: without the memory for them the launch walks from the root)
-                    if (hipMalloc((void**)&m.tile_cuts, sizeof(uint32_t) * words) == hipSuccess) m.tile_cut_capacity = words;
-                    else { (void)hipGetLastError(); m.tile_cuts = nullptr; room = false; }
-                }
-                if (room) {
-                hipLaunchKernelGGL(k_tile_cuts, dim3(p.ntiles), dim3(kWave), 0, s, m.frames, sb, se, b->nodes4q, b->quant_frame, p.node_count,
-                                   (float)AOB_CUT_SHRINK_PCT * 0.01f, cut_entries, wedges, m.tile_cuts);
-                p.tile_cuts = m.tile_cuts;
-                m.tile_cut_tiles = p.ntiles; m.tile_cut_records = p.cut_records;
+                // (reserved when the rasterisation ended: only a schedule set afterwards allocates here; without the memory the launch walks
+                // from the root and the bake says so — ensure_tile_cuts)
+                if (ensure_tile_cuts(b, m, words)) {
+                    // rays of bounded reach (closest-hit scoring with tmax clamped to the falloff distance, a material range): a slot farther from the
+                    // tile than any of its rays goes never joins the cut (k_tile_cuts).  One per cent and the bias on top of the span: directions are
+                    // unit vectors to within the rounding of the surfel's frame (an fp16 normal: 5e-4).
+                    const float reach = (p.tmax + fabsf(p.bias)) * 1.01f;
+                    hipLaunchKernelGGL(k_tile_cuts, dim3(p.ntiles), dim3(kWave), 0, s, m.frames, sb, se, b->nodes4q, b->quant_frame, p.node_count,
+                                       (float)AOB_CUT_SHRINK_PCT * 0.01f, cut_entries, reach * reach, wedges, m.tile_cuts);
+                    p.tile_cuts = m.tile_cuts;
+                    m.tile_cut_tiles = p.ntiles; m.tile_cut_records = p.cut_records;
+                    if (b->stats.trace_cuts != 2u) b->stats.trace_cuts = 1u;
                 } else p.cut_records = 1u;
             }
+            // the HBM overflow stack (reserved when the tree was built; a launch whose schedule or mode was set later re-sizes it here)
+            const uint32_t overflow = stack_overflow_entries(b, p.tile_cuts != nullptr);
+            if (overflow) AOB_TRY(reserve_gstack(b, (uint64_t)grid.x * kWave * overflow));
+            p.gstack = b->gstack;
             p.self_shape = m.section_mesh[si] + 1u;
             p.self_hidden = (b->meshes[m.section_mesh[si]].flags & AOB_MESH_HIDDEN_FROM_SELF) ? 1u : 0u;
             if (o.sampler == AOB_SAMPLER_REFERENCE_COMPAT) launch_masked<AOB_SAMPLER_REFERENCE_COMPAT>(b->any_mesh_flags, o.use_any_hit, o.accumulate, quant, grid, s, p);

@@ -66,9 +66,9 @@ def parse_args():
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--bvh-width", type=int, default=0, help="0 = library default (4), 2 = BVH2 nodes, 4 = 4-ary nodes")
     ap.add_argument("--bvh-quantised", type=int, default=-1, help="-1 = library default (1); 1 = 15-bit quantised boxes, lane per ray; 0 = fp32 boxes")
-    ap.add_argument("--bvh-builder", type=int, default=2,
-                    help="2 (the benchmark's choice: PLOC clusters under a binned-SAH top — it pays from a few hundred million rays per bake on), "
-                         "1 = PLOC (the library's default), 0 = LBVH, -1 = the library's default")
+    ap.add_argument("--bvh-builder", type=int, default=-1,
+                    help="-1 = the library's default: by workload (aob_resolve_bvh_builder: PLOC under a binned-SAH top for this one); "
+                         "2 = PLOC clusters under a binned-SAH top, 1 = PLOC, 0 = LBVH")
     ap.add_argument("--no-balance", action="store_true", help="N>1: keep the equal strips (no re-cut during warm-up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpp-host", action="store_true")
@@ -246,6 +246,12 @@ def main():
         opts.bvh_quantised = args.bvh_quantised
     if args.bvh_builder >= 0:
         opts.bvh_builder = args.bvh_builder
+    builder_by = "asked for" if opts.bvh_builder >= 0 else "the library's default for this workload"
+    # (what the library settles on for this scene — aob_bake_create does the same — written out so that the line, the C++ host leg and the
+    # oracle's visit count all name the builder that ran)
+    import ctypes
+    opts.bvh_builder = capi.load().aob_resolve_bvh_builder(ctypes.byref(opts), W * H, flat.triangle_count())
+    args.bvh_builder_resolved = int(opts.bvh_builder)
 
     wallclock = None
     if world == 1 and not args.no_wallclock:
@@ -331,20 +337,6 @@ def main():
         elapsed = float(t.item())
 
     stats = baker.stats()
-    # what a caller who leaves the library's default builder gets on the same workload (the headline asks for bvh_builder 2:
-    # --bvh-builder): a few steps after the timed region, reported beside the value, never as it
-    default_builder = None
-    if world == 1 and opts.bvh_builder != capi.default_options().bvh_builder and not args.no_wallclock:
-        o1 = capi.AobOptions.from_buffer_copy(opts)
-        o1.bvh_builder = capi.default_options().bvh_builder
-        with Baker(flat, o1) as b1:
-            ms1 = []
-            for _ in range(4):
-                t = time.perf_counter()
-                b1.build_bvh(); b1.rasterize(0); b1.trace(0, 0, b1.surfel_count(0)); b1.resolve(0); b1.sync()
-                ms1.append((time.perf_counter() - t) * 1e3)
-            default_builder = {"bvh_builder": int(o1.bvh_builder), "ms_per_step": round(min(ms1[1:]), 3),
-                               "rays_per_s": counts["mine"] * args.spp / (min(ms1[1:]) * 1e-3), "trace_kernel_ms": round(b1.last_trace_ms(), 3)}
     image_crc = None
     if rank == 0:
         import zlib
@@ -395,7 +387,7 @@ def main():
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"terrain {flat.triangle_count()} tris, {W}x{H} atlas, {args.spp} spp, "
-                                   f"cosine sampler, any-hit, float accumulate, {('LBVH', 'PLOC', 'PLOC + binned-SAH top (bvh_builder 2)')[opts.bvh_builder]} bvh_width {opts.bvh_width or 2}"
+                                   f"cosine sampler, any-hit, float accumulate, {('LBVH', 'PLOC', 'PLOC + binned-SAH top (bvh_builder 2)')[opts.bvh_builder]} ({builder_by}) bvh_width {opts.bvh_width or 2}"
                                    f"{' quantised' if opts.bvh_quantised else ''} — "
                                    + ("BASELINE configs[2]" if world == 1 else
                                       ("BASELINE configs[3]: one fixed atlas in N strips of texel rows" if strong else "configs[2] scaled: N x 2048^2 texels")),
@@ -412,7 +404,7 @@ def main():
             "stage_ms": {"bvh_build": round(stats.ms_bvh_build, 3), "trace_kernel": round(kernel_ms, 3),
                          "rank_build_raster_trace": [round(v, 3) for v in rank_ms]},
             "bake_wallclock_ms": dict(wallclock or {}, device_step_ms=round(ms_per_step, 3)),
-            "roofline": roofline, "cpu_baseline": cpu, "cpp_host": cpp, "library_default_builder": default_builder,
+            "roofline": roofline, "cpu_baseline": cpu, "cpp_host": cpp,
         }
         if world > 1:
             line["balance"] = {"enabled": not args.no_balance, "warmup_history": history}
@@ -440,7 +432,7 @@ def cpp_host_leg(scene, world, args):
             path = os.path.join(tmp, "scene.aobs")
             scenefile.write_scene(scene, path)
             cmd = [exe, "--scene", path, "--gpus", str(world), "--steps", str(max(1, min(args.steps, 5))), "--warmup", str(max(2, min(args.warmup, 3))),
-                   "--spp", str(args.spp), "--sampler", "1", "--accumulate", "1", "--seed", "3", "--any-hit", "1", "--normal-fp16", "0", "--builder", str(args.bvh_builder)]
+                   "--spp", str(args.spp), "--sampler", "1", "--accumulate", "1", "--seed", "3", "--any-hit", "1", "--normal-fp16", "0", "--builder", str(args.bvh_builder_resolved)]
             if args.no_balance:
                 cmd.append("--no-balance")
             out = subprocess.run(cmd, capture_output=True, text=True, timeout=180)

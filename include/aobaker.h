@@ -23,7 +23,8 @@
 extern "C" {
 #endif
 
-#define AOB_ABI_VERSION 5
+#define AOB_ABI_VERSION 6
+#define AOB_BVH_BUILDER_AUTO (-1)
 
 typedef enum AobStatus {
     AOB_OK = 0,
@@ -93,9 +94,10 @@ typedef struct AobOptions {
                                      0 = quad-per-ray walk of the fp32 AobBvh4Node.  With bvh_width 2:  0: 64-byte fp32 nodes (the reference layout);
                                      1: 32-byte nodes, child boxes as 15-bit fixed point on the scene
                                      box, rounded outward (AobBvh2QNode)                            */
-    int32_t  bvh_builder;         /* 0: LBVH, the reference stack's GPU builder (kernels/CL/build_hlbvh.cl);
+    int32_t  bvh_builder;         /* -1 (AOB_BVH_BUILDER_AUTO, the default): 1 or 2 by workload, see aob_resolve_bvh_builder;
+                                     0: LBVH, the reference stack's GPU builder (kernels/CL/build_hlbvh.cl);
                                      1: PLOC (locally-ordered agglomerative clustering over the same Morton
-                                     order) — same node layouts, cheaper trees, ~0.5 ms more build time — the default;
+                                     order) — same node layouts, cheaper trees, ~0.5 ms more build time;
                                      2: PLOC until 131 072 clusters are left, the tree above them top-down by binned SAH
                                      (the reference stack's "sah" builder, RadeonRays/radeon_rays.h:286-294): 5 % fewer
                                      node visits per ray on the 1 M-triangle terrain for 0.6 ms more build — worth it
@@ -201,7 +203,10 @@ typedef struct AobStats {
     uint64_t surfel_count;        /* covered texels summed over sections and materials */
     uint64_t ray_count;           /* surfel_count * sample_count */
     uint32_t bvh_depth;
-    uint32_t reserved0;
+    uint32_t trace_cuts;          /* the trace launches since the last rasterisation — 0: walked from the root by design (a mode without tile
+                                     cuts, trace_cut 1); 1: started their rays below tile cuts (AobOptions::trace_cut); 2: at least one wanted
+                                     cuts and walked from the root because their memory could not be allocated — the same cells, slower;
+                                     aob_last_error() then holds a line that starts with "warning:" (ABI 6; was reserved0)           */
     float ms_upload;
     float ms_bvh_build;
     float ms_rasterize;
@@ -292,6 +297,11 @@ void aob_default_options(AobOptions* out);
 int aob_bake(const AobSceneDesc* scene, const AobOptions* options, AobStats* stats);
 const char* aob_last_error(void);
 int aob_abi_version(void);
+/* AobOptions::bvh_builder -1 (the default since ABI 6) lets the library choose by workload: 2 — PLOC under the binned-SAH top — for an
+ * any-hit bake of at least 2^28 rays (texels x sample_count, the bound known before the rasterisation) over more than 131 072 triangles,
+ * else 1 (PLOC).  aob_bake_create settles it for the handle; this returns what it would settle on (an explicit 0 / 1 / 2 comes back
+ * unchanged).  `texels`: width x height summed over the scene's materials. */
+int aob_resolve_bvh_builder(const AobOptions* options, uint64_t texels, uint64_t triangles);
 
 /* ---- staged API ------------------------------------------------------------
  * The same path cut at the reference's own stage boundaries (S1..S6 in

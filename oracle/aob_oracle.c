@@ -500,6 +500,7 @@ uint64_t orc_bvh_build(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes, u
 
 uint64_t orc_bvh_build_ex(const OrcTriangle* tris, uint64_t n, AobBvhNode* nodes, uint32_t* depth_out, int builder, int adaptive)
 {
+    if (builder < 0) builder = 1;      /* "by workload" without a workload: PLOC (orc_resolve_bvh_builder settles it for a bake) */
     if (depth_out) *depth_out = 0;
     if (n == 0) return 0;
     Box* pb = (Box*)malloc(sizeof(Box) * n);
@@ -1113,6 +1114,9 @@ uint64_t orc_bvh4q_build(const AobBvh4Node* nodes4, uint64_t count4, const AobQu
 }
 
 #define ORC_STACK4 512
+/* measurement only (tools/measure_closest_cuts.py): closest-hit rays follow their hit children in SLOT order, as any-hit rays do */
+static int g_measure_slot_order = 0;
+void orc_measure_slot_order(int on) { g_measure_slot_order = on; }
 
 /* bytes {0x3f, hi, lo, 0x00}: what one v_perm_b32 makes of a stored plane */
 static inline float plane_float(uint32_t half) { uint32_t u = 0x3f000000u | (half & 0xffffu) << 8; float f; memcpy(&f, &u, 4); return f; }
@@ -1188,7 +1192,7 @@ static inline int traverse4q_from(const AobBvh4QNode* nq, uint64_t count4, const
             uint32_t first = AOB_INVALID_ADDR;
             /* any hit: the answer does not depend on the order — the kernel follows the first hit child and defers the rest
              * in index order; closest hit: nearest first, the others deferred farthest first, ties by child index */
-            if (any_hit) for (int j = 0; j < 4; j++) key[j] = chit[j] ? (float)j : INFINITY;
+            if (any_hit || g_measure_slot_order) for (int j = 0; j < 4; j++) key[j] = chit[j] ? (float)j : INFINITY;
             for (int j = 0; j < 4; j++) {
                 if (!chit[j]) continue;
                 int rank = 0;
@@ -1953,6 +1957,25 @@ int orc_walk4q(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr,
     return error;
 }
 
+/* ... and every ray's closest distance (t_max where it hit nothing): what a closest-hit walk from a tile's cut must reproduce */
+int orc_walk4q_t(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const AobLeafTri* tris,
+                 const OrcRay* rays, uint64_t n, int32_t any_hit, OrcTraceStats* all, float* t_out)
+{
+    int error = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const OrcRay* r = &rays[i];
+        t_out[i] = r->o[3];
+        if (r->extra[1] == 0) continue;
+        OrcTraceStats st; memset(&st, 0, sizeof st);
+        float t;
+        const int hit = traverse4q(nq, count4, fr, tris, f3_make(r->o[0], r->o[1], r->o[2]), f3_make(r->d[0], r->d[1], r->d[2]),
+                                   r->o[3], any_hit, &t, &st, &error, NULL);
+        all->rays++; all->inner_visits += st.inner_visits; all->leaf_visits += st.leaf_visits; all->hits += (uint64_t)hit;
+        t_out[i] = t;
+    }
+    return error;
+}
+
 /* The same walk started from a list of refs instead of the root (tests/measure_region_cut.py: what starting every ray of a tile
  * below the nodes its rays cannot leave would save); t_sum: the hit distances added up in double, to compare with the plain walk. */
 int orc_walk4q_from(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const AobLeafTri* tris,
@@ -2227,6 +2250,127 @@ int orc_cut_walk(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* f
         }
         out->hits += (uint64_t)hit;
         if (hit_out) hit_out[i] = hit;
+    }
+    return 0;
+}
+
+/* Round 5: a tile's cut for rays of bounded REACH (closest-hit scoring with tmax clamped to the falloff distance, a material range):
+ * the twin of trace.hip k_tile_cuts with `reach` > 0.  The tile's rays start at the surfels' positions — inside the FULL box
+ * [flo, fhi] — and end within `reach` of them, so a slot whose box lies farther than that from the full box holds no triangle any of
+ * them can hit: such a slot is never appended (not when the root's slots start the list, not when an opened entry's slots join it), and
+ * an opened entry counts only the slots it appends against the budget.  Everything else is orc_tile_cut's rule 1: breadth first, a level
+ * at a time in list order, an inner slot whose box meets the opening box [lo, hi] (the tile's box pulled in) is replaced by its slots
+ * while the list fits max_entries.  `grow2` >= 0 adds a second sweep when the first has ended with room to spare: the live inner entries, in
+ * list order again, whose box meets the full box grown by grow2 * reach are opened too, level by level as before (with bounded rays most of
+ * the first sweep's siblings are dropped, and the budget they free is spent on the tree around the tile, where its rays end).
+ * The distance is computed in float exactly as below (both sides; no contraction). */
+static inline int cut_within_reach(const AobQuantFrame* fr, const uint32_t* planes, const float flo[3], const float fhi[3], float reach2)
+{
+    float d2 = 0.0f;
+    for (int k = 0; k < 3; k++) {
+        const float bmin = fmaf((float)(planes[k] & 0x7fffu), fr->scale[k], fr->origin[k]);
+        const float bmax = fmaf((float)((planes[k] >> 16) & 0x7fffu), fr->scale[k], fr->origin[k]);
+        const float gap = fmaxf(fmaxf(bmin - fhi[k], flo[k] - bmax), 0.0f);
+        d2 = fmaf(gap, gap, d2);
+    }
+    return d2 <= reach2;
+}
+int32_t orc_tile_cut_reach(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const float lo[3], const float hi[3],
+                           const float flo[3], const float fhi[3], float reach, int32_t max_entries, float grow2, uint32_t* out)
+{
+    if (count4 == 0 || max_entries < 4) return 0;
+    const int bounded = reach > 0.0f && reach < INFINITY;
+    const float reach2 = reach * reach;
+    uint32_t list[4 * 128]; uint8_t dead[128]; int n = 0, live = 0;
+    #define SLOT_EMPTY(c_) ((c_)[0] == 0x8000ffffu && (c_)[1] == 0x8000ffffu && (c_)[2] == 0x8000ffffu)
+    #define SLOT_KEPT(c_) (!SLOT_EMPTY(c_) && (!bounded || cut_within_reach(fr, (c_), flo, fhi, reach2)))
+    #define CUT_APPEND(node) do { for (int j_ = 0; j_ < 4; j_++) { const uint32_t* c_ = &nq[node].w[4 * j_]; \
+        if (!SLOT_KEPT(c_)) continue; \
+        list[4 * n] = c_[3]; list[4 * n + 1] = c_[0]; list[4 * n + 2] = c_[1]; list[4 * n + 3] = c_[2]; dead[n] = 0; n++; live++; } } while (0)
+    CUT_APPEND(0);
+    for (int sweep = 0; sweep < (grow2 >= 0.0f && bounded ? 2 : 1); sweep++) {
+        float glo[3], ghi[3];
+        for (int k = 0; k < 3; k++) {
+            const float a = sweep ? flo[k] - grow2 * reach : lo[k], b = sweep ? fhi[k] + grow2 * reach : hi[k];
+            glo[k] = fr->scale[k] > 0.0f ? (a - fr->origin[k]) / fr->scale[k] : -INFINITY;
+            ghi[k] = fr->scale[k] > 0.0f ? (b - fr->origin[k]) / fr->scale[k] : INFINITY;
+        }
+        for (int e = 0; e < n; e++) {
+            const uint32_t ref = list[4 * e];
+            if (dead[e] || (ref & AOB_LEAF_FLAG)) continue;
+            int ok = 1;
+            for (int k = 0; k < 3; k++) {
+                const float qmin = (float)(list[4 * e + 1 + k] & 0x7fffu), qmax = (float)((list[4 * e + 1 + k] >> 16) & 0x7fffu);
+                ok &= qmin <= ghi[k] && qmax >= glo[k];
+            }
+            if (!ok) continue;
+            int kids = 0;
+            for (int j = 0; j < 4; j++) { const uint32_t* c = &nq[ref].w[4 * j]; kids += SLOT_KEPT(c); }
+            if (live - 1 + kids > max_entries || n + kids > 128) continue;
+            dead[e] = 1; live--;
+            CUT_APPEND(ref);
+        }
+    }
+    #undef CUT_APPEND
+    #undef SLOT_KEPT
+    #undef SLOT_EMPTY
+    int m = 0;
+    for (int e = 0; e < n; e++) if (!dead[e]) { memcpy(&out[4 * m], &list[4 * e], 16); m++; }
+    return m;
+}
+
+/* The closest-hit walk of a batch of rays from a tile's cut (trace.hip, CUT mode with closest-hit scoring), counted.  A ray tests the
+ * boxes of all entries against its full span (closest_t = t_max: it is generated then) and walks the subtrees of those it entered
+ * one after the other, each in traverse4q's near-first order, carrying its closest hit from one to the next — `order` 1: the LAST entry
+ * of the list first (the deepest: the small boxes around the tile, where a short ray's nearest hit is), 0: the first first.
+ * t_out[i] = the ray's closest hit distance or t_max.  The cut's subtrees partition the tree, so the triangles a ray can reach are
+ * those of the walk from the root; which of them it TESTS depends on the order, the minimum over those within reach does not — except
+ * where a hit lies within rounding of a box face, which is why the product and this oracle walk the same cut in the same order. */
+int orc_cut_walk_closest(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const AobLeafTri* tris,
+                         const OrcRay* rays, uint64_t n, const uint32_t* cut, int32_t n_cut, int32_t order, OrcEntryStats* out, float* t_out)
+{
+    if (count4 == 0 || n_cut < 0 || n_cut > 64) return AOB_ERR_INVALID_ARGUMENT;
+    for (uint64_t i = 0; i < n; i++) {
+        const OrcRay* rr = &rays[i];
+        if (t_out) t_out[i] = rr->o[3];
+        if (rr->extra[1] == 0) continue;
+        const f3 o = f3_make(rr->o[0], rr->o[1], rr->o[2]), d = f3_make(rr->d[0], rr->d[1], rr->d[2]);
+        const float t_max = rr->o[3];
+        Ray4q r; ray4q_prepare(&r, fr, o, d, t_max, 0);
+        out->rays++;
+        uint64_t entered = 0;
+        float near_t[64]; int by_near[64], n_in = 0;
+        for (int e = 0; e < n_cut; e++) {
+            out->entries_tested++;
+            if (ray4q_box(&r, &cut[4 * e + 1], t_max)) {
+                out->mask_bits++; entered |= 1ull << e;
+                /* (order 2, measurement only: the entry's near distance, as the slab test computes it) */
+                float tn[3];
+                for (int k = 0; k < 3; k++) { const uint32_t w = cut[4 * e + 1 + k]; tn[k] = fmaf(plane_float(r.down[k] ? w >> 16 : w & 0xffffu), r.fa[k], r.fb[k]); }
+                near_t[e] = fmaxf(max3n(tn[0], tn[1], tn[2]), 0.0f);
+                int at = n_in++;
+                while (at > 0 && near_t[by_near[at - 1]] > near_t[e]) { by_near[at] = by_near[at - 1]; at--; }
+                by_near[at] = e;
+            }
+        }
+        float closest_t = t_max;
+        int hit = 0;
+        for (int q = 0; q < (order == 2 ? n_in : n_cut); q++) {
+            const int e = order == 2 ? by_near[q] : (order ? n_cut - 1 - q : q);
+            if (!((entered >> e) & 1ull)) continue;
+            if (order == 3 && !ray4q_box(&r, &cut[4 * e + 1], closest_t)) continue;      /* (measurement: the entry's box again, against the hit so far) */
+            if (order == 3) out->entries_tested++;
+            OrcTraceStats st; memset(&st, 0, sizeof st);
+            int error = 0;
+            float t = closest_t;
+            const uint32_t ref = cut[4 * e];
+            hit |= traverse4q_from(nq, count4, fr, tris, o, d, closest_t, 0, &t, &st, &error, NULL, &ref, 1);
+            if (error) return error;
+            closest_t = t;
+            out->inner_visits += st.inner_visits; out->leaf_visits += st.leaf_visits;
+        }
+        out->hits += (uint64_t)hit;
+        if (t_out) t_out[i] = closest_t;
     }
     return 0;
 }
@@ -2645,10 +2789,27 @@ void orc_resolve(const AobResult* results, int32_t W, int32_t H, const AobOption
 /* ------------------------------------------------------------------------ */
 /* end to end                                                                */
 
-int orc_bake(const AobSceneDesc* scene, const AobOptions* opt, int32_t threads, OrcTraceStats* stats)
+/* AobOptions::bvh_builder -1 (include/aobaker.h aob_resolve_bvh_builder): PLOC under the binned-SAH top for an any-hit bake of at least
+ * 2^28 rays (texels x samples) over more than 131 072 triangles, else PLOC. */
+int32_t orc_resolve_bvh_builder(const AobOptions* opt, uint64_t texels, uint64_t triangles)
 {
-    if (!scene || !opt || opt->sample_count <= 0) return AOB_ERR_INVALID_ARGUMENT;
+    if (opt->bvh_builder >= 0) return opt->bvh_builder;
+    const uint64_t rays = texels * (uint64_t)(opt->sample_count > 0 ? opt->sample_count : 0);
+    return (opt->use_any_hit && rays >= (1ull << 28) && triangles > 131072ull) ? 2 : 1;
+}
+
+int orc_bake(const AobSceneDesc* scene, const AobOptions* opt_in, int32_t threads, OrcTraceStats* stats)
+{
+    if (!scene || !opt_in || opt_in->sample_count <= 0) return AOB_ERR_INVALID_ARGUMENT;
     uint64_t ntri = orc_scene_triangle_count(scene);
+    AobOptions opt_v = *opt_in;
+    {
+        uint64_t texels = 0;
+        for (uint32_t mi = 0; mi < scene->material_count; mi++)
+            if (scene->materials[mi].width > 0 && scene->materials[mi].height > 0) texels += (uint64_t)scene->materials[mi].width * (uint64_t)scene->materials[mi].height;
+        opt_v.bvh_builder = orc_resolve_bvh_builder(opt_in, texels, ntri);
+    }
+    const AobOptions* opt = &opt_v;
     OrcTriangle* tris = (OrcTriangle*)malloc(sizeof(OrcTriangle) * (ntri ? ntri : 1));
     orc_scene_triangles(scene, tris);
     AobBvhNode* nodes = (AobBvhNode*)malloc(sizeof(AobBvhNode) * (ntri ? 2 * ntri : 1));

@@ -204,6 +204,14 @@ int32_t orc_tile_cut(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFram
                      int32_t max_entries, int32_t rule, uint32_t* out);
 int orc_cut_walk(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const AobLeafTri* tris,
                  const OrcRay* rays, uint64_t n, const uint32_t* cut, int32_t n_cut, OrcEntryStats* out, int32_t* hit_out, uint64_t* mask_out);
+int orc_walk4q_t(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const AobLeafTri* tris,
+                 const OrcRay* rays, uint64_t n, int32_t any_hit, OrcTraceStats* all, float* t_out);
+int32_t orc_resolve_bvh_builder(const AobOptions* opt, uint64_t texels, uint64_t triangles);
+/* round 5: cuts for rays of bounded reach, and the closest-hit walk from a cut (trace.hip CUT mode, closest-hit scoring) */
+int32_t orc_tile_cut_reach(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const float lo[3], const float hi[3],
+                           const float flo[3], const float fhi[3], float reach, int32_t max_entries, float grow2, uint32_t* out);
+int orc_cut_walk_closest(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const AobLeafTri* tris,
+                         const OrcRay* rays, uint64_t n, const uint32_t* cut, int32_t n_cut, int32_t order, OrcEntryStats* out, float* t_out);
 int orc_entry_walk(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* fr, const AobLeafTri* tris,
                    const OrcRay* rays, uint64_t n, const uint32_t* entries, int32_t n_entries, OrcEntryStats* out);
 

@@ -163,6 +163,8 @@ def bvh_build(tris, builder=None, adaptive=None):
     lib = load()
     if builder is None:
         builder = default_options().bvh_builder
+    if builder < 0:
+        builder = 1            # "by workload" resolves to PLOC below 2^28 rays (resolve_builder); a caller that means the SAH top says 2
     if adaptive is None:
         adaptive = default_options().morton_adaptive
     n = len(tris)
@@ -467,6 +469,56 @@ def tile_cut(nodes4q, frame, lo, hi, max_entries=32, rule=1):
     return out[:m].copy()
 
 
+def tile_cut_reach(nodes4q, frame, lo, hi, full_lo, full_hi, reach, max_entries=32, grow2=-1.0):
+    """A tile's cut for rays of bounded reach (trace.hip k_tile_cuts with reach2 > 0): slots farther than `reach` from the tile's full
+    box never join the list.  reach 0: orc_tile_cut's rule 1."""
+    nodes4q = np.ascontiguousarray(nodes4q, dtype=np.uint32)
+    frame = np.ascontiguousarray(frame, dtype=np.float32)
+    lo, hi = np.ascontiguousarray(lo, dtype=np.float32), np.ascontiguousarray(hi, dtype=np.float32)
+    flo, fhi = np.ascontiguousarray(full_lo, dtype=np.float32), np.ascontiguousarray(full_hi, dtype=np.float32)
+    out = np.zeros((128, 4), dtype=np.uint32)
+    lib = load()
+    lib.orc_tile_cut_reach.restype = C.c_int32
+    m = lib.orc_tile_cut_reach(C.c_void_p(nodes4q.ctypes.data), C.c_uint64(len(nodes4q)), C.c_void_p(frame.ctypes.data), C.c_void_p(lo.ctypes.data),
+                               C.c_void_p(hi.ctypes.data), C.c_void_p(flo.ctypes.data), C.c_void_p(fhi.ctypes.data), C.c_float(reach),
+                               C.c_int32(max_entries), C.c_float(grow2), C.c_void_p(out.ctypes.data))
+    return out[:m].copy()
+
+
+def cut_walk_closest(nodes4q, frame, leaf_tris, rays, cut, order=1):
+    """(stats, per-ray closest distance) of the closest-hit walk that starts below a tile's cut, the entered entries in `order`
+    (1: the list's last first — what trace.hip does)."""
+    nodes4q = np.ascontiguousarray(nodes4q, dtype=np.uint32)
+    frame = np.ascontiguousarray(frame, dtype=np.float32)
+    leaf_tris, rays, cut = np.ascontiguousarray(leaf_tris), np.ascontiguousarray(rays), np.ascontiguousarray(cut, dtype=np.uint32)
+    st = OrcEntryStats()
+    t = np.zeros(max(1, len(rays)), dtype=np.float32)
+    lib = load()
+    lib.orc_cut_walk_closest.restype = C.c_int
+    rc = lib.orc_cut_walk_closest(C.c_void_p(nodes4q.ctypes.data), C.c_uint64(len(nodes4q)), C.c_void_p(frame.ctypes.data), C.c_void_p(leaf_tris.ctypes.data),
+                                  C.c_void_p(rays.ctypes.data), C.c_uint64(len(rays)), C.c_void_p(cut.ctypes.data), C.c_int32(len(cut)), C.c_int32(order),
+                                  C.byref(st), C.c_void_p(t.ctypes.data))
+    if rc != 0:
+        raise RuntimeError(f"orc_cut_walk_closest failed: {rc}")
+    return st, t[:len(rays)]
+
+
+def walk4q_t(nodes4q, frame, leaf_tris, rays, any_hit=False):
+    """(stats, per-ray closest distance — t_max where nothing was hit) of traverse4q from the root."""
+    nodes4q = np.ascontiguousarray(nodes4q, dtype=np.uint32)
+    frame = np.ascontiguousarray(frame, dtype=np.float32)
+    leaf_tris, rays = np.ascontiguousarray(leaf_tris), np.ascontiguousarray(rays)
+    a = OrcTraceStats()
+    t = np.zeros(max(1, len(rays)), dtype=np.float32)
+    lib = load()
+    lib.orc_walk4q_t.restype = C.c_int
+    rc = lib.orc_walk4q_t(C.c_void_p(nodes4q.ctypes.data), C.c_uint64(len(nodes4q)), C.c_void_p(frame.ctypes.data), C.c_void_p(leaf_tris.ctypes.data),
+                          C.c_void_p(rays.ctypes.data), C.c_uint64(len(rays)), C.c_int32(int(bool(any_hit))), C.byref(a), C.c_void_p(t.ctypes.data))
+    if rc != 0:
+        raise RuntimeError(f"orc_walk4q_t failed: {rc}")
+    return a, t[:len(rays)]
+
+
 def cut_walk(nodes4q, frame, leaf_tris, rays, cut, want_masks=False):
     """(stats, per-ray hit flags) of the any-hit walk that starts below a tile's cut."""
     nodes4q = np.ascontiguousarray(nodes4q, dtype=np.uint32)
@@ -525,7 +577,7 @@ def default_options():
     o.clamp_tmax_to_falloff = 0
     o.bvh_width = 4
     o.bvh_quantised = 1
-    o.bvh_builder = 1
+    o.bvh_builder = -1         # by workload (orc_resolve_bvh_builder / aob_resolve_bvh_builder)
     o.morton_adaptive = 1
     # the schedule of the library's trace kernel (no meaning for the oracle; stated so that the two defaults compare equal)
     o.trace_refill_idle, o.trace_leaf_wait, o.trace_parts, o.trace_part_min, o.trace_fine_div, o.trace_bands, o.trace_scalar_min, o.trace_cut = 0, 0, 4, 16, 8, 1, 0, 0

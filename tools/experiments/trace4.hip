@@ -1,7 +1,9 @@
-// trace4.hip — quad-per-ray traversal of the 4-ary BVH (gfx950); selected with bvh_width = 4.
-// An experiment kept in the tree: parity-green, but slower than trace.hip (2.35 vs 6.4 Grays/s on
-// BASELINE configs[2]) because 16 rays per wave cost 2.3x the VALU instructions per ray, and VALU
-// issue — not L1 — is what bounds the lane-per-ray kernel once its nodes are quantised.
+// trace4.hip — quad-per-ray traversal of the fp32 4-ary BVH (gfx950).  A RETIRED EXPERIMENT (round 5): not compiled into
+// libaobaker_hip.so, not in the parity matrices; `bvh_width 4, bvh_quantised 0` is rejected by aob_bake_create.  It was
+// parity-green through round 4 and 2.7x slower than trace.hip (2.35 vs 6.4 Grays/s on BASELINE configs[2] in round 1, when it was
+// last competitive) because 16 rays per wave cost 2.3x the VALU instructions per ray, and VALU issue — not L1 — is what bounds the
+// lane-per-ray kernel once its nodes are quantised (the A/B record: tools/experiments/README.md).  To build it again:
+// add it to SRCS in aobaker_amd/csrc/Makefile, declare trace4_range in aob_internal.h and call it from trace_range.
 //
 // Same fused stage as trace.hip (ray generation + traversal + scoring + accumulation, replacing
 // BakeEngine.cpp:598-675 / GenerateRaysComputeShader.hlsl / QueryIntersection /
