@@ -295,9 +295,12 @@ int aob_init(const AobDeviceConfig* config)
     g_initialised = true;
     g_process_device.store(dev);
     // the first time on this device: one throw-away bake of a triangle (include/aobaker.h, AOB_INIT_NO_WARMUP)
-    static std::atomic<uint64_t> warmed[4];            // one bit per device ordinal
+    static std::atomic<uint64_t> warmed[4];            // one bit per device ordinal, set when the warm-up bake has FINISHED
+    static std::mutex warm_mutex;                      // (a second thread's aob_init on the same device waits for it instead of starting a cold bake beside it)
     const uint64_t bit = 1ull << (dev & 63);
-    if (!(config && (config->flags & AOB_INIT_NO_WARMUP)) && dev < 256 && !(warmed[dev >> 6].fetch_or(bit) & bit)) {
+    std::unique_lock<std::mutex> warm_lock(warm_mutex, std::defer_lock);
+    if (!(config && (config->flags & AOB_INIT_NO_WARMUP)) && dev < 256 && !(warmed[dev >> 6].load() & bit)) warm_lock.lock();
+    if (warm_lock.owns_lock() && !(warmed[dev >> 6].load() & bit)) {
         const float pos[9] = { 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f }, nrm[9] = { 0.f, 1.f, 0.f, 0.f, 1.f, 0.f, 0.f, 1.f, 0.f };
         const float uv[6] = { 0.1f, 0.1f, 0.9f, 0.1f, 0.1f, 0.9f };
         const uint32_t idx[3] = { 0u, 1u, 2u };
@@ -305,7 +308,7 @@ int aob_init(const AobDeviceConfig* config)
         mesh.positions = pos; mesh.normals = nrm; mesh.uvs = uv; mesh.position_stride = 12; mesh.normal_stride = 12; mesh.uv_stride = 8;
         mesh.indices = idx; mesh.vertex_count = 3; mesh.index_count = 3; mesh.material = 0;
         mesh.model[0] = mesh.model[5] = mesh.model[10] = mesh.model[15] = 1.0f;
-        uint8_t texels[16 * 16];
+        uint8_t texels[16 * 16] = { 0 };
         AobMaterialDesc mat; memset(&mat, 0, sizeof mat);
         mat.width = 16; mat.height = 16; mat.channels = 1; mat.bytes_per_channel = 1; mat.data = texels;
         AobSceneDesc scene; memset(&scene, 0, sizeof scene);
@@ -313,7 +316,8 @@ int aob_init(const AobDeviceConfig* config)
         AobOptions o; aob_default_options(&o);
         o.sample_count = 16; o.sampler = AOB_SAMPLER_COSINE;      // (no hemisphere table to fill)
         const int rc = aob_bake(&scene, &o, nullptr);
-        if (rc != AOB_OK) { warmed[dev >> 6].fetch_and(~bit); aob_shutdown(); return rc; }
+        if (rc != AOB_OK) { aob_shutdown(); return rc; }
+        warmed[dev >> 6].fetch_or(bit);
     }
     return AOB_OK;
 }
@@ -325,7 +329,13 @@ void aob_shutdown(void)
 {
     if (!g_initialised) return;
     g_initialised = false;
-    if (g_process_inits.fetch_sub(1) == 1) g_process_device.store(-1);
+    if (g_process_inits.fetch_sub(1) == 1) {
+        g_process_device.store(-1);
+        // the last thread out: the process-wide hemisphere table (REFERENCE_COMPAT bakes: up to 200 MB of host memory) goes too; a bake that
+        // is still uploading from it keeps its own reference
+        std::lock_guard<std::mutex> lock(g_table_mutex);
+        g_table.reset();
+    }
 }
 
 int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBake** out)

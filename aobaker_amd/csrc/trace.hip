@@ -80,6 +80,10 @@ __device__ __forceinline__ uint4 as_uint4(v4u v) { return make_uint4(v.x, v.y, v
 #ifndef AOB_LEAF_BOTH
 #define AOB_LEAF_BOTH 1             // any hit: both triangles of a leaf pair fetched in one go (one memory round trip per leaf section instead of two)
 #endif
+#ifndef AOB_LEAF_HELPERS
+#define AOB_LEAF_HELPERS 1          // leaf pairs (QUANT 2): the second triangle of a parked lane's pair is tested by a lane that is NOT parked at a leaf
+                                    // — one Möller–Trumbore pass per leaf section instead of two (round 5); 0: the parked lane tests both itself
+#endif
 #ifndef AOB_CUT_SHRINK_PCT
 #define AOB_CUT_SHRINK_PCT 25        // k_tile_cuts opens the slots that meet the tile's box PULLED IN by this share of its extent on every side
 #endif
@@ -942,6 +946,75 @@ void k_trace(TraceParams p)
         // (any hit; closest-hit scoring — configs[4] — loses 1.5 % with it and keeps "nobody left walking")
         if (__popcll(__ballot(at_leaf)) >= p.leaf_wait || (uint32_t)__popcll(inner_m) < (ANYHIT ? 16u : 1u)) {
             { const uint64_t leaf_m_ = __ballot(at_leaf); AOB_STAT(3, 1); AOB_STAT(4, __popcll(leaf_m_)); (void)leaf_m_; }
+            if (AOB_LEAF_HELPERS && QUANT == 2) {
+                // ---- helper lanes (round 5) ----
+                // A leaf section runs with ~20 of 64 lanes parked, and a parked lane's PAIR costs two Möller–Trumbore passes (with an IEEE division
+                // each) that the other 44 lanes sit out.  Here the pair with rank j among the parked pairs hands its second triangle to the lane with
+                // rank j among the lanes that are NOT parked at a leaf (walking, idle or ended: their own state stays in its registers): the helper
+                // pulls the ray (origin, direction, bound, ref) across with ds_bpermute, both test ONE triangle in the same pass, the parked lane
+                // pulls the helper's distance back and keeps the smaller — the same two tests on the same numbers, so the same answer, bit for bit.
+                // Who serves whom: every pair pushes its lane number to lane `rank` (ds_permute), every free lane likewise, and each side pulls the
+                // other's number from there.  Pairs beyond the free lanes (more than half of the wavefront parked) test their second triangle
+                // themselves, afterwards.  Twelve cross-lane moves for one pass of ~70 vector instructions.
+                const uint32_t lref = addr - leaf_base;
+                const bool pairL = at_leaf && (lref & 0x40000000u) != 0u;
+                const uint64_t leaf_m = __ballot(at_leaf), pair_m = __ballot(pairL), free_m = ~leaf_m;
+                const uint32_t n_pairs = (uint32_t)__popcll(pair_m), n_free = (uint32_t)__popcll(free_m);
+                const uint32_t n_help = min(n_pairs, n_free);
+                const uint32_t prank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pair_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pair_m, 0u));
+                const uint32_t frank = __builtin_amdgcn_mbcnt_hi((uint32_t)(free_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)free_m, 0u));
+                const bool helper = !at_leaf && frank < n_help, served = pairL && prank < n_help;
+                uint32_t from = lane, back = lane;
+                if (n_help) {           // (wave-uniform)
+                    // (lane 63 is nobody's rank unless every lane is a pair / free — and then nobody writes a dummy)
+                    const int pair_lane = __builtin_amdgcn_ds_permute((int)((pairL ? prank : 63u) << 2), (int)lane);
+                    const int free_lane = __builtin_amdgcn_ds_permute((int)((!at_leaf ? frank : 63u) << 2), (int)lane);
+                    const int a = __builtin_amdgcn_ds_bpermute((int)((helper ? frank : lane) << 2), pair_lane);
+                    const int h = __builtin_amdgcn_ds_bpermute((int)((served ? prank : lane) << 2), free_lane);
+                    if (helper) from = (uint32_t)a;
+                    if (served) back = (uint32_t)h;
+                }
+                auto pull = [&](float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute((int)(from << 2), (int)__float_as_uint(v))); };
+                f3 to = org, td = dir;
+                uint32_t tref = lref;
+                float tbound = ANYHIT ? p.tmax : closest_t;
+                if (n_help) {
+                    to = make_f3(pull(org.x), pull(org.y), pull(org.z));
+                    td = make_f3(pull(dir.x), pull(dir.y), pull(dir.z));
+                    tref = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from << 2), (int)lref);
+                    if (!ANYHIT) tbound = pull(closest_t);
+                }
+                float t = tbound;
+                auto masked_out = [&](uint32_t shape) -> bool {
+                    return shape == p.self_shape ? p.self_hidden != 0u : ((p.hidden_from_others[shape >> 5] >> (shape & 31u)) & 1u) != 0u;
+                };
+                if (at_leaf || helper) {
+                    const float4* np = p.leaf_tris + 3ull * ((tref & 0x3fffffffu) + (helper ? 1u : 0u));
+                    const float4 n0 = np[0], n1 = np[1], n2 = np[2];
+                    t = intersect_triangle(to, td, make_f3(n0.x, n0.y, n0.z), make_f3(n1.x, n1.y, n1.z), make_f3(n2.x, n2.y, n2.z), tbound);
+                    // the ray mask of intersect_bvh2_lds.cl:163-166, by section — the SERVED ray's section: a launch traces one section's surfels,
+                    // so self_shape is the same for every ray of the wavefront
+                    if (MASKED && masked_out(__float_as_uint(n0.w))) t = tbound;
+                }
+                if (n_help) {
+                    const float t2 = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute((int)(back << 2), (int)__float_as_uint(t)));
+                    if (served) t = fminf(t, t2);
+                }
+                if (n_pairs > n_help) {          // (wave-uniform: more pairs than free lanes)
+                    if (pairL && !served) {
+                        const float4* np = p.leaf_tris + 3ull * ((lref & 0x3fffffffu) + 1u);
+                        const float4 m0 = np[0], m1 = np[1], m2 = np[2];
+                        float t2 = intersect_triangle(org, dir, make_f3(m0.x, m0.y, m0.z), make_f3(m1.x, m1.y, m1.z), make_f3(m2.x, m2.y, m2.z), tbound);
+                        if (MASKED && masked_out(__float_as_uint(m0.w))) t2 = tbound;
+                        t = fminf(t, t2);
+                    }
+                }
+                if (at_leaf) {
+                    const bool closer = t < tbound;
+                    if (!ANYHIT && closer) closest_t = t;
+                    addr = (ANYHIT && closer) ? kEndHit : pop();
+                }
+            } else
             if (at_leaf) {
                 // QUANT 2: the ref may name a PAIR of triangles, p and p + 1 (AOB_PAIR_FLAG): both are fetched in one go
                 const float bound = ANYHIT ? p.tmax : closest_t;

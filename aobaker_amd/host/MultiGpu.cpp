@@ -269,7 +269,7 @@ int AobMultiGpuBake::Step(AobMultiStepStats* stats)
 	if (d.broken) { set_error("an earlier exchange failed and the RCCL communicators were aborted: create the bake again"); return AOB_ERR_DEVICE; }
 	const int n = d.n;
 	const size_t nmat = d.materials.size();
-	std::vector<double> rank_ms((size_t)n, 0.0);
+	std::vector<double> rank_ms((size_t)n, 0.0), gather_ms((size_t)n, 0.0);
 	std::vector<float> trace_ms((size_t)n, 0.0f);
 	std::vector<uint64_t> rank_surfels((size_t)n, 0);
 	std::vector<std::vector<double>> mat_ms(nmat, std::vector<double>((size_t)n, 0.0));
@@ -411,6 +411,7 @@ int AobMultiGpuBake::Step(AobMultiStepStats* stats)
 					}
 					std::this_thread::sleep_for(std::chrono::microseconds(20));
 				}
+				gather_ms[(size_t)r] += now_ms() - t;
 			}
 			int s = AOB_OK;
 			if (r == 0) s = aob_bake_resolve(b, (int32_t)i);
@@ -424,6 +425,9 @@ int AobMultiGpuBake::Step(AobMultiStepStats* stats)
 	{
 		stats->wall_ms = wall;
 		stats->trace_ms = trace_ms; stats->rank_ms = rank_ms; stats->rank_surfels = rank_surfels;
+		stats->rank_gather_ms = gather_ms;
+		stats->rank_bvh_build_ms.assign((size_t)n, 0.f);
+		for (int r = 0; r < n; r++) { AobStats s1; if (aob_bake_get_stats(d.bakes[(size_t)r], &s1) == AOB_OK) stats->rank_bvh_build_ms[(size_t)r] = s1.ms_bvh_build; }
 		stats->surfels = 0;
 		for (uint64_t c : rank_surfels) stats->surfels += c;
 		stats->rays = stats->surfels * (uint64_t)d.opt.sample_count;

@@ -188,6 +188,69 @@ def sphere_scene(n=187, atlas=1024, seed=2, **kw):
     return _scene_with([sphere_mesh(n, seed)], atlas, **kw)
 
 
+def torus_knot_mesh(n_u=700, n_v=50, p=2, q=3, seed=2, tube=0.11, displacement=0.25):
+    """A bunny-CLASS mesh for BASELINE configs[1] that is NOT star-shaped (the displaced sphere has no concavities a ray can
+    see into, no handles): a (p, q) torus knot — a closed tube that winds p times round the axis and q times through the hole, passing
+    over and under itself — with seeded fBm bumps on the tube radius.  2 * n_u * n_v triangles (700 x 50 -> 70 000), one chart: u along
+    the knot, v round the tube.  Returns (positions, normals, uvs, indices) like sphere_mesh."""
+    u = np.linspace(0.0, 1.0, n_u + 1)
+    v = np.linspace(0.0, 1.0, n_v + 1)
+    t = 2.0 * np.pi * u
+    # the knot's centre line (on a torus of radii 0.5 / 0.2) and its moving frame
+    r = 0.5 + 0.2 * np.cos(q * t)
+    c = np.stack([r * np.cos(p * t), 0.2 * np.sin(q * t), r * np.sin(p * t)], axis=-1)
+    dr = -0.2 * q * np.sin(q * t)
+    tan = np.stack([dr * np.cos(p * t) - r * p * np.sin(p * t), 0.2 * q * np.cos(q * t), dr * np.sin(p * t) + r * p * np.cos(p * t)], axis=-1)
+    tan /= np.linalg.norm(tan, axis=-1, keepdims=True)
+    up = np.array([0.0, 1.0, 0.0])
+    b1 = np.cross(tan, up); b1 /= np.linalg.norm(b1, axis=-1, keepdims=True)
+    b2 = np.cross(tan, b1)
+    uu, vv = np.meshgrid(u, v, indexing="xy")                      # [n_v + 1, n_u + 1]
+    phi = 2.0 * np.pi * vv
+    # periodic in both parameters so that the tube closes on itself
+    bump = fbm(0.5 + 0.5 * np.cos(2 * np.pi * uu) + 0.3 * np.cos(phi), 0.5 + 0.5 * np.sin(2 * np.pi * uu) + 0.3 * np.sin(phi), seed, base_freq=6.0)
+    rad = tube * (1.0 + displacement * bump)
+    pos = c[None, :, :] + rad[..., None] * (np.cos(phi)[..., None] * b1[None, :, :] + np.sin(phi)[..., None] * b2[None, :, :])
+    dpu = np.gradient(pos, axis=1)
+    dpv = np.gradient(pos, axis=0)
+    nrm = np.cross(dpv, dpu)
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=-1, keepdims=True), 1e-12)
+    # outward: away from the centre line
+    flip = np.sign((nrm * (pos - c[None, :, :])).sum(-1, keepdims=True))
+    nrm = nrm * np.where(flip == 0, 1.0, flip)
+    pad = 0.01
+    uv = np.stack([pad + uu * (1 - 2 * pad), pad + vv * (1 - 2 * pad)], axis=-1)
+    return (pos.reshape(-1, 3).astype(np.float32), nrm.reshape(-1, 3).astype(np.float32),
+            uv.reshape(-1, 2).astype(np.float32), _grid_indices(n_u + 1, n_v + 1))
+
+
+def write_obj(path, positions, uvs, indices, normals=None, name="mesh", material="AO"):
+    """A triangle mesh as Wavefront OBJ text (what BakeObject::LoadFromFile / assets.load_obj import): v / vt (/ vn) and 1-based f."""
+    idx = np.asarray(indices, dtype=np.int64).reshape(-1, 3) + 1
+    with open(path, "w") as f:
+        f.write(f"o {name}\nusemtl {material}\n")
+        for p in np.asarray(positions, dtype=np.float32):
+            f.write(f"v {p[0]:.9g} {p[1]:.9g} {p[2]:.9g}\n")
+        for t in np.asarray(uvs, dtype=np.float32):
+            f.write(f"vt {t[0]:.9g} {t[1]:.9g}\n")
+        if normals is not None:
+            for n in np.asarray(normals, dtype=np.float32):
+                f.write(f"vn {n[0]:.9g} {n[1]:.9g} {n[2]:.9g}\n")
+            for a, b, c in idx:
+                f.write(f"f {a}/{a}/{a} {b}/{b}/{b} {c}/{c}/{c}\n")
+        else:
+            for a, b, c in idx:
+                f.write(f"f {a}/{a} {b}/{b} {c}/{c}\n")
+    return path
+
+
+def torus_knot_obj(path, n_u=700, n_v=50, seed=2):
+    """The 70 000-triangle displaced torus knot as an OBJ file (no normals: the importer generates them, as assimp does for the
+    reference, BakeObject.cpp:183) — `AOB_CFG2_OBJ=<this file>` makes it BASELINE configs[1]'s mesh."""
+    p, _, uv, idx = torus_knot_mesh(n_u, n_v, seed=seed)
+    return write_obj(path, p, uv, idx, name="torus_knot")
+
+
 def config2_scene(atlas=1024, seed=2, bpc=4):
     """BASELINE configs[1]'s mesh: returns (scene, mesh name).  The Stanford bunny is not in the image (no network), so the
     stand-in is the 69 938-triangle displaced sphere; AOB_CFG2_OBJ=/path/to/mesh.obj bakes that file instead (imported as

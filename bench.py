@@ -17,16 +17,14 @@ touches the GPU); under `python -m torch.distributed.run --nproc-per-node N benc
 used.  One process per GPU, RCCL (`nccl`) for the gather, one JSON line from rank 0.
 
 The JSON line also carries
-  roofline      the trace kernel: ALGORITHMIC bytes per SURVEY.md §8(d) — B_ray = 64 (n_inner + n_leaf) + 40 / spp, node
-                fetches counted by the CPU oracle on a texel subsample of the same rays — over the kernel's time from HIP
-                events on the library's own stream, against HBM peak.  `frac` can exceed 1: the model counts every node
-                fetch as memory traffic although L1 / L2 / Infinity Cache serve most of them; a fraction above 1 means
-                "cache-served", not "faster than HBM".  `bound` / `roof` name the roof that binds THIS kernel — the CU's
-                vector-memory path: `roof.frac` is the busy fraction of its data-return unit, with the marginal cost of one
-                more load and of one more vector instruction per visit from the slope builds —
-                `traffic` / `hbm_counter_frac` are what the memory-side counters saw; these and the instruction counts per
-                ray come from the committed rocprofv3 PMC passes and A/B builds of THIS kernel source and THIS
-                configuration (profiles/k_trace_counters.json) and are null when either differs.
+  roofline      the trace kernel against its roofs, every fraction physically bounded: `frac` = the bytes its lanes REQUEST from the CU's
+                vector L1 (node, triangle and surfel-record fetches, counted live by the oracle walking the product's own schedule — tile
+                cuts included — on a sample of tiles) / the kernel's time (HIP events on the library's stream) / (64 B per clock and CU): the
+                binding roof, as the slope builds say (`roofs`); beside it the L1 -> L2 request rate against L2 peak, the fabric-side bytes
+                (FETCH_SIZE: Infinity-Cache hits included) against HBM peak, the compulsory footprint and how many times over it was fetched
+                — those from the committed rocprofv3 PMC passes of THIS kernel source and configuration (profiles/k_trace_counters.json),
+                null when either differs.  SURVEY.md §8(d)'s contract figure — 64 B x the oracle's node visits FROM THE ROOT + 40 / spp per
+                ray against HBM peak — is kept as `algorithmic_frac`: a cache-oblivious demand figure that may exceed 1.
   cpu_baseline  the CPU oracle (a port, oracle/) timed on this box's host cores on a bounded texel subsample (N = 1 only).
   bake_wallclock_ms  the PCIe-inclusive `aob_bake` (allocation + upload + device step + download), first call of the
                 process (cold) and second (warm), beside the device step (N = 1 only) — SURVEY.md §8(d)(ii).
@@ -51,6 +49,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # float): what every builder, schedule and host must produce (the cells are oracle-exact, and an any-hit answer does not depend on
 # the tree).  tests/test_gpu_fullsize.py asserts it for bvh_builder 1 and 2; the line carries it as config.image_crc32_expected.
 CONFIG2_IMAGE_CRC32 = 259823415
+# ... and of BASELINE configs[3]'s atlas — the same terrain at 4096^2, 256 spp, what `--gpus N` (N > 1, strong scaling) bakes in N strips: the
+# first real multi-GPU line proves its own image (measured on one GPU in round 5, profiles/r05/bench_4096_single_gpu.json; the strips of a
+# COSINE-sampler bake add up to the single-device cells exactly, tests/test_gpu_configs.py, so every N must print this number).
+CONFIG3_IMAGE_CRC32 = 3632858360
 # what k_trace's time depends on: the kernel, and the builder whose tree it walks
 KERNEL_SOURCES = ("aobaker_amd/csrc/trace.hip", "aobaker_amd/csrc/aob_math.h", "aobaker_amd/csrc/aob_internal.h", "aobaker_amd/csrc/bvh_build.hip")
 
@@ -271,7 +273,7 @@ def main():
 
     baker = Baker(flat, opts)           # uploads the scene: inputs resident in HBM from here on
     cells = aod.alias_results(baker, 0, as_float=True) if world > 1 else None
-    trace_ms, step_ms = [], []
+    trace_ms, step_ms, gather_ms, build_raster_ms = [], [], [], []
     counts = {}
     bounds = aod.equal_rows(H, world)   # every rank rasterises and traces its own strip of texel rows; the BVH is built by all
 
@@ -280,11 +282,13 @@ def main():
         rows = (bounds[rank], bounds[rank + 1])
         baker.build_bvh()
         baker.rasterize(0, rows if world > 1 else None)
+        build_raster_ms.append((time.perf_counter() - t) * 1e3)     # (the rasteriser reads its counts back: the host has waited for the build and for it)
         n = baker.surfel_count(0)
         baker.trace(0, 0, n)
         if world > 1:
             baker.sync()
             mine = (time.perf_counter() - t) * 1e3
+            tg = time.perf_counter()
             all_cells = [(bounds[r] * W, bounds[r + 1] * W - 1) for r in range(world)]
             if rehearsal:
                 # through host memory: a copy of the whole cell array, the same gather on it, rank 0's strips copied back
@@ -297,6 +301,7 @@ def main():
             else:
                 aod.gather_strips(cells, all_cells[rank], rank, world, 0, False, all_cells)
             torch.cuda.synchronize()
+            gather_ms.append((time.perf_counter() - tg) * 1e3)      # (rank 0: until the last strip has arrived; a peer: until its send has left)
         if rank == 0:
             baker.resolve(0)
         baker.sync()
@@ -325,6 +330,8 @@ def main():
             bounds = aod.rebalance_rows(bounds, ms, H)
     trace_ms.clear()
     step_ms.clear()
+    gather_ms.clear()
+    build_raster_ms.clear()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -337,6 +344,18 @@ def main():
         elapsed = float(t.item())
 
     stats = baker.stats()
+    # every buffer one trace launch reads, once (the compulsory footprint the fabric-side traffic is read against)
+    footprint = None
+    try:
+        import ctypes as C
+        n4q, tiles_c, recs_c = C.c_uint64(), C.c_uint32(), C.c_uint32()
+        capi.check(baker.lib.aob_bake_node4q_count(baker.handle, C.byref(n4q)))
+        baker.lib.aob_bake_copy_tile_cuts(baker.handle, 0, None, 0, C.byref(tiles_c), C.byref(recs_c))
+        parts = {"nodes4q": int(n4q.value) * 64, "leaf_tris": int(stats.triangle_count) * 48, "frames": int(counts["mine"]) * 64,
+                 "tile_cuts": int(tiles_c.value) * int(recs_c.value) * 512, "result_cells": int(counts["mine"]) * 8}
+        footprint = {"bytes": sum(parts.values()), "of_which": parts}
+    except Exception as e:
+        print(f"bench: footprint failed: {e!r}", file=sys.stderr)
     image_crc = None
     if rank == 0:
         import zlib
@@ -354,8 +373,16 @@ def main():
         every = [torch.zeros(1, dtype=torch.float64, device=comm_device) for _ in range(world)]
         dist.all_gather(every, t)
         rank_ms = [float(v.item()) for v in every]
+        # every rank's own stages of the last step (each builds the whole tree — redundantly — and rasterises and traces its strip) and what
+        # it spent in the gather: the redundant build's share of a rank's step is visible here, not inferred
+        mine4 = torch.tensor([stats.ms_bvh_build, sum(build_raster_ms) / len(build_raster_ms) - stats.ms_bvh_build, sum(trace_ms) / len(trace_ms), sum(gather_ms) / max(1, len(gather_ms))],
+                             dtype=torch.float64, device=comm_device)
+        every4 = [torch.zeros(4, dtype=torch.float64, device=comm_device) for _ in range(world)]
+        dist.all_gather(every4, mine4)
+        rank_stages = [[float(x) for x in v.tolist()] for v in every4]
     else:
         counts["surfels"] = counts["mine"]
+        rank_stages = [[stats.ms_bvh_build, sum(build_raster_ms) / len(build_raster_ms) - stats.ms_bvh_build, sum(trace_ms) / len(trace_ms), 0.0]]
     total_rays = counts["surfels"] * args.spp                  # all ranks together
     ms_per_step = elapsed / args.steps * 1e3
     value = total_rays / (elapsed / args.steps)
@@ -380,7 +407,13 @@ def main():
             cpu, visits = cpu_baseline(flat, opts, W, H, args.cpu_seconds)
         if visits is None:
             visits = visits_per_ray(flat, opts, W, H)
-        roofline = roofline_record(opts, args, W, H, world, visits, my_rays, kernel_ms)
+        requested = None
+        try:
+            requested = requested_per_ray(flat, opts, W, H)
+        except Exception as e:                       # (a report, never a reason to lose the bench line)
+            requested = None
+            print(f"bench: requested_per_ray failed: {e!r}", file=sys.stderr)
+        roofline = roofline_record(opts, args, W, H, world, visits, my_rays, kernel_ms, requested, footprint)
         line = {
             "metric": "AO rays/sec", "value": value, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -398,11 +431,20 @@ def main():
                        "rows": [[bounds[r], bounds[r + 1]] for r in range(world)],
                        "bvh_nodes": stats.node_count, "bvh_depth": stats.bvh_depth,
                        "image_crc32": image_crc,
-                       "image_crc32_expected": CONFIG2_IMAGE_CRC32 if (world == 1 and (W, H, args.spp, args.grid) == (2048, 2048, 256, 708)) else None,
+                       "image_crc32_expected": (CONFIG2_IMAGE_CRC32 if (W, H, args.spp, args.grid) == (2048, 2048, 256, 708) else
+                                                CONFIG3_IMAGE_CRC32 if (W, H, args.spp, args.grid) == (4096, 4096, 256, 708) else None),
+                       "image_crc32_ok": None if image_crc is None or (W, H, args.spp, args.grid) not in ((2048, 2048, 256, 708), (4096, 4096, 256, 708)) else
+                                         bool(image_crc == (CONFIG2_IMAGE_CRC32 if W == 2048 else CONFIG3_IMAGE_CRC32)),
                        "host": ("REHEARSAL: ranks share devices, strips gathered with gloo through host memory" if rehearsal else
                                 "python ranks, one process per GPU, torch.distributed nccl (= RCCL) point-to-point gather to rank 0")},
             "stage_ms": {"bvh_build": round(stats.ms_bvh_build, 3), "trace_kernel": round(kernel_ms, 3),
-                         "rank_build_raster_trace": [round(v, 3) for v in rank_ms]},
+                         "rank_build_raster_trace": [round(v, 3) for v in rank_ms],
+                         # per rank: the tree's build (HIP events, last step), the rasterisation of its strip (host clock up to the rasteriser's read-back,
+                         # less the build), its trace kernel (HIP events, mean), and the host time it spent in the gather (N > 1)
+                         "rank_bvh_build": [round(v[0], 3) for v in rank_stages], "rank_rasterize": [round(v[1], 3) for v in rank_stages],
+                         "rank_trace_kernel": [round(v[2], 3) for v in rank_stages],
+                         "gather_ms": round(rank_stages[0][3], 3) if world > 1 else None,
+                         "rank_gather_ms": [round(v[3], 3) for v in rank_stages] if world > 1 else None},
             "bake_wallclock_ms": dict(wallclock or {}, device_step_ms=round(ms_per_step, 3)),
             "roofline": roofline, "cpu_baseline": cpu, "cpp_host": cpp,
         }
@@ -490,40 +532,117 @@ def counter_record(opts, args, W, H, world, path=None):
     return rec, None
 
 
-def roofline_record(opts, args, W, H, world, visits, my_rays, kernel_ms):
+L1_PEAK_GBS = 64.0 * 256 * 2.4           # the vector L1 returns 64 B per clock and CU: 256 CUs at 2.4 GHz = 39.3 TB/s (the floor tools/l1_probe.hip measures:
+                                         # a wave64 16-byte-per-lane load takes 16 CU cycles whatever its lanes touch)
+L2_PEAK_GBS = 34500.0                    # MI355X_MICROARCH.md "L2 (per XCD)": 34.5 TB/s aggregate
+
+
+def requested_per_ray(flat, opts, W, H, tiles=96):
+    """What ONE ray asks the vector-memory path for, counted by the oracle walking the product's schedule on `tiles` random tiles of the trace
+    order: every ray of a tile tests its tile's cut (orc_tile_cut_reach: k_tile_cuts' rule) and walks below the entries it entered
+    (orc_cut_walk).  Returns node fetches, triangle fetches, entries tested / entered per ray — the counts the kernel's own loop counters
+    give (tools/time_trace.py on the -DAOB_TRACE_STATS build; profiles/): the oracle's are live, on this very run's scene and options."""
+    import numpy as np
+    from oracle import oracle as orc
+    tris = orc.scene_triangles(flat.desc)
+    nodes2, _ = orc.bvh_build(tris, opts.bvh_builder, opts.morton_adaptive)
+    n4, lt = orc.bvh4_build(nodes2, pairs=True)
+    _, frame = orc.bvh2q_build(nodes2)
+    n4q = orc.bvh4q_build(n4, frame)
+    surfels, _ = orc.rasterize(flat.desc, 0, opts)
+    x, y = surfels["texel_x"].astype(np.int64), surfels["texel_y"].astype(np.int64)
+    key = ((y // 8) * ((W + 7) // 8) + x // 8) * 64 + (y % 8) * 8 + x % 8
+    ordered = surfels[np.argsort(key, kind="stable")]
+    nt = len(ordered) // 64
+    picks = np.random.default_rng(7).choice(nt, size=min(tiles, nt), replace=False)
+    reach = float((np.float32(opts.ray_tmax) + np.float32(abs(opts.ray_bias))) * np.float32(1.01))
+    rays_n = inner = leaf = tested = entered = 0
+    for t in picks:
+        sub = np.ascontiguousarray(ordered[64 * t:64 * t + 64])
+        rays = np.ascontiguousarray(orc.generate_rays(sub, None, opts, W))
+        pos = sub["position"].astype(np.float32)
+        pmin, pmax = pos.min(axis=0), pos.max(axis=0)
+        pull = np.float32(0.25) * (pmax - pmin)
+        cut = orc.tile_cut_reach(n4q, frame, pmin + pull, pmax - pull, pmin, pmax, reach, 32)
+        st, _ = orc.cut_walk(n4q, frame, lt, rays, cut)
+        rays_n += st.rays; inner += st.inner_visits; leaf += st.leaf_visits; tested += st.entries_tested; entered += st.mask_bits
+    r = float(max(1, rays_n))
+    return {"node_fetches": inner / r, "triangle_fetches": leaf / r, "cut_entries_tested": tested / r, "cut_entries_entered": entered / r,
+            "counted_on": f"{len(picks)} random tiles of 64 surfels ({rays_n} rays), the oracle walking the tiles' cuts (32 entries; the kernel tests fewer: its "
+                          "records are culled by sample part, which changes no walk)"}
+
+
+def roofline_record(opts, args, W, H, world, visits, my_rays, kernel_ms, requested=None, footprint=None):
+    """The trace kernel against its roofs, every fraction physically bounded (<= 1):
+      frac / achieved / peak   the BINDING roof: the CU's vector-memory (L1) request path — bytes the kernel's lanes ask it for (node, triangle,
+                               surfel-record and frame fetches, counted live by the oracle walking the product's schedule) / kernel time /
+                               (64 B per clock and CU).  Why this one binds: the slope builds (roofs.vmem / roofs.valu below).
+      l2 / fabric              the same for the L1 -> L2 requests and for what leaves the L2s (FETCH_SIZE: Infinity-Cache hits INCLUDED,
+                               MI355X_MICROARCH.md "HBM": this is fabric-side traffic, an upper bound on HBM's) — from the committed PMC passes
+                               of THIS kernel source and configuration, null when either differs.
+      algorithmic_frac         SURVEY §8(d)'s contract figure: 64 B x the node visits of the oracle's walk FROM THE ROOT + 40 / spp per ray,
+                               against HBM peak.  A cache-oblivious DEMAND figure — it can exceed 1 (the kernel starts below tile cuts and
+                               fetches 6 nodes where that walk visits 16, and L1 / L2 / MALL serve most fetches); it is not a distance from a roof.
+      compulsory_bytes / refetch_ratio   every buffer the launch reads, once, and how many times over the fabric side moved it."""
     n_inner, n_leaf = visits
-    # SURVEY §8(d) as written: 64 B per node packet fetched (the quantised 4-ary node is 64 B; a leaf visit is counted as one
-    # packet too) + (32 B surfel + 8 B result cell) / spp
+    seconds = kernel_ms * 1e-3
+    # SURVEY §8(d) as written: 64 B per node packet fetched (a leaf visit is counted as one packet too) + (32 B surfel + 8 B result cell) / spp
     b_ray = 64.0 * (n_inner + n_leaf) + 40.0 / args.spp
-    # the build's own accounting, kept beside it: the real packet sizes (64-B quantised 4-ary node, 48 B per leaf triangle
-    # fetched), 64 B of the surfel's trace record per ray and the 8-B cell per surfel
-    inner_bytes = ((64.0 if opts.bvh_quantised else 128.0) if opts.bvh_width == 4 else (32.0 if opts.bvh_quantised else 64.0))
-    b_ray_build = inner_bytes * n_inner + 48.0 * n_leaf + 64.0 + 8.0 / args.spp
-    achieved = my_rays * b_ray / (kernel_ms * 1e-3) / 1e9
+    algorithmic = my_rays * b_ray / seconds / 1e9
     rec, why = counter_record(opts, args, W, H, world)
-    traffic = hbm_frac = None
-    roof = None
+    # ---- the L1 request path: what the lanes ask for ----
+    req = None
+    if requested:
+        # per ray: 64 B per node fetched below the cut, 48 B per triangle fetched, 16 B of the surfel's record when a lane takes the ray off the
+        # queue, 48 B of its frame when the sample is generated, the 8-B cell per surfel
+        b_req = 64.0 * requested["node_fetches"] + 48.0 * requested["triangle_fetches"] + 16.0 + 48.0 + 8.0 / args.spp
+        req = {"bytes_per_ray": round(b_req, 1), "per_ray": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in requested.items()},
+               "GBps": round(my_rays * b_req / seconds / 1e9, 1)}
+    l1_frac = round(req["GBps"] / L1_PEAK_GBS, 4) if req else None
+    l2 = fabric = None
+    roofs = None
     if rec:
-        traffic = rec["hbm_side_bytes_per_launch"]
-        hbm_frac = round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-        roof = rec.get("roof")
-    return {"bound": (roof or {}).get("bound", "vmem"), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "frac_note": "achieved / peak / frac: SURVEY §8(d)'s algorithmic node bytes against HBM peak — > 1 means the fetches are cache-served "
-                         "(hbm_counter_frac is what the memory-side counters saw).  HBM is not what binds k_trace: `bound` and `roof` name the "
-                         "roof that the slope measurements on this kernel point to (DESIGN.md §3.1, profiles/r03/roofs/)",
-            "hbm_counter_frac": hbm_frac,
-            # the binding roof, from the committed measurements of THIS kernel source (profiles/k_trace_counters.json): which unit,
-            # how busy the counters say it is, and what one more instruction of either kind per inner visit costs
-            "roof": roof,
+        c = rec.get("counters", {})
+        if c.get("TCP_TCC_READ_REQ_sum"):
+            l2_bytes = c["TCP_TCC_READ_REQ_sum"] * 64.0
+            l2 = {"bytes_per_launch": l2_bytes, "GBps": round(l2_bytes / seconds / 1e9, 1), "peak": L2_PEAK_GBS, "frac": round(l2_bytes / seconds / 1e9 / L2_PEAK_GBS, 4),
+                  "note": "TCP_TCC_READ_REQ_sum x 64 B (the request size is not calibrated on gfx950: 128-B requests would double it; below the roof either way)",
+                  "L2_hit_rate": rec.get("L2_hit_rate")}
+        fb = rec.get("fabric_side_bytes_per_launch", rec.get("hbm_side_bytes_per_launch"))
+        if fb:
+            fabric = {"bytes_per_launch": fb, "GBps": round(fb / seconds / 1e9, 1), "peak": HBM_PEAK_GBS, "frac": round(fb / seconds / 1e9 / HBM_PEAK_GBS, 4),
+                      "note": "FETCH_SIZE + WRITE_SIZE, corrected by the known-byte kernel k_gather64 (tools/fetch_calib.hip): requests leaving the L2s — Infinity-Cache "
+                              "hits are counted in (MI355X_MICROARCH.md, HBM section), so this bounds HBM traffic from above"}
+        roofs = rec.get("roof")
+    refetch = None
+    if footprint and fabric:
+        refetch = round(fabric["bytes_per_launch"] / footprint["bytes"], 1)
+    fracs = {"l1_request_path": l1_frac, "l2": (l2 or {}).get("frac"), "fabric": (fabric or {}).get("frac")}
+    known = {k: v for k, v in fracs.items() if v is not None}
+    binding = max(known, key=known.get) if known else None
+    return {"bound": "vmem", "bound_is": "the CU's vector-memory request path (TA / L1 / TD): of the byte-rate fractions below the largest, and the unit the slope builds point to "
+                                         "(one more 4-byte load per visit costs 20 CU cycles, one more v_xor 1.4 SIMD cycles: roofs)",
+            "achieved": (req or {}).get("GBps"), "peak": round(L1_PEAK_GBS, 1), "unit": "GB/s", "frac": l1_frac,
+            "frac_is": "bytes the kernel's lanes request from the vector L1 / kernel time / (64 B x 256 CUs x 2.4 GHz); <= 1 by construction",
+            "byte_rate_fractions": fracs, "largest_byte_rate_fraction": binding,
+            "requested": req, "l2": l2, "fabric": fabric,
+            "traffic": (fabric or {}).get("bytes_per_launch"),
+            "traffic_is": "fabric-side bytes per launch (see fabric.note); null when the committed counters are of another kernel source or configuration",
+            "compulsory": footprint, "refetch_ratio": refetch,
+            "refetch_ratio_is": "fabric-side bytes / the bytes of every buffer the launch reads once: how many times the L2s fetched the working set",
+            "algorithmic_GBps": round(algorithmic, 1), "algorithmic_frac": round(algorithmic / HBM_PEAK_GBS, 4),
+            "algorithmic_frac_is": "SURVEY §8(d): 64 B x node visits of the oracle's walk from the root + 40 / spp per ray, against HBM peak — a cache-oblivious demand "
+                                   "figure that may exceed 1; not a roofline fraction",
+            "bytes_per_ray_algorithmic": round(b_ray, 1),
+            "node_visits_per_ray_from_the_root": round(n_inner + n_leaf, 3), "inner_visits_per_ray_from_the_root": round(n_inner, 3), "leaf_visits_per_ray_from_the_root": round(n_leaf, 3),
+            # the two instruction-rate roofs from the committed measurements of THIS kernel source (profiles/k_trace_counters.json): which unit,
+            # how full, and what one more instruction of either kind per inner visit costs
+            "roofs": roofs,
             "valu_lane_occupancy": (rec or {}).get("valu_lane_occupancy"),
             "valu_wave_instr_per_ray": (rec or {}).get("valu_wave_instr_per_ray"), "vmem_wave_instr_per_ray": (rec or {}).get("vmem_wave_instr_per_ray"),
             "counters": (rec or {}).get("provenance") or why,
             "kernel": "k_trace", "kernel_ms": round(kernel_ms, 3), "kernel_source_sha256_16": kernel_source_hash(),
-            "bytes_per_ray": round(b_ray, 1), "bytes_per_ray_build": round(b_ray_build, 1),
-            "frac_build": round(my_rays * b_ray_build / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "node_visits_per_ray": round(n_inner + n_leaf, 3), "inner_visits_per_ray": round(n_inner, 3), "leaf_visits_per_ray": round(n_leaf, 3),
-            "inner_packet_bytes": inner_bytes, "rays_per_launch": my_rays, "counter_key": counter_key(opts, args, W, H, world)}
+            "rays_per_launch": my_rays, "counter_key": counter_key(opts, args, W, H, world)}
 
 
 def host_cores():

@@ -126,12 +126,16 @@ typedef struct AobOptions {
     int32_t  trace_scalar_min;    /* any-hit walk of the quantised 4-ary nodes: lanes that must stand on ONE node for it to be
                                      visited from scalar registers (after a refill): 1..64; 0 (default) = by sampler: 24
                                      with the COSINE sampler, 8 with the table sampler (its rays part ways sooner)          */
-    int32_t  trace_cut;           /* any-hit walk of the quantised 4-ary nodes with the COSINE sampler: every 8x8-texel tile gets a
-                                     CUT of the tree — the siblings of the chain of nodes its rays start inside, at most this many
-                                     entries — which a new ray tests in one go when it is generated, starting its walk below the
-                                     entries it entered instead of at the root (trace.hip k_tile_cuts).  0 (default)
-                                     = 32 entries, 4..32 = that many, 1 = off (the walk from the root).  Like the knobs above it
-                                     moves work and never changes a result cell.  (ABI 5)                                        */
+    int32_t  trace_cut;           /* walk of the quantised 4-ary nodes (both samplers; any-hit and, since ABI 6, closest-hit scoring): every
+                                     tile of 64 surfels gets a CUT of the tree — the siblings of the chain of nodes its rays start inside,
+                                     at most this many entries, none farther away than its rays reach — which a new ray tests in one go
+                                     when it is generated, starting its walk below the entries it entered instead of at the root
+                                     (trace.hip k_tile_cuts).  The COSINE sampler's units get one record per sample part,
+                                     culled by the part's azimuth wedge; the table sampler one record per tile, no wedge culling.
+                                     0 (default) = 32 entries, 4..32 = that many, 1 = off (the walk from the root).  Like the knobs above
+                                     it moves work and never changes a result cell.  The cuts take 512 B per tile and record of device
+                                     memory (up to 96 B per covered texel), allocated when a material is rasterised; a bake that cannot
+                                     have them walks from the root and says so (AobStats::trace_cuts).  (ABI 5)                        */
 } AobOptions;
 
 /* ---- scene description ----------------------------------------------------
@@ -282,12 +286,17 @@ typedef struct AobResult { uint32_t total_bits, weight_bits; } AobResult;
  * its own device); a thread that never called aob_init creates its handles on the device of the most recent aob_init of
  * any thread.  A handle stays on the device it was created on: every aob_bake_* entry point selects that device for the
  * duration of the call and restores the calling thread's current device before it returns, so a handle may be driven from
- * any thread — one call at a time — and a thread that shares HIP with other code keeps its own current device.  It acquires nothing: streams, events and buffers belong to the AobBake handles (the reference's
- * Init allocates ~3 GB of fixed buffers here, BakeEngine.cpp:163-212; this library sizes them per scene). */
+ * any thread — one call at a time — and a thread that shares HIP with other code keeps its own current device.  It KEEPS nothing:
+ * streams, events and buffers belong to the AobBake handles (the reference's Init allocates ~3 GB of fixed buffers here,
+ * BakeEngine.cpp:163-212; this library sizes them per scene).  Unless AOB_INIT_NO_WARMUP is set, the first aob_init of the process on a
+ * device does RUN one throw-away bake of a triangle there (a 16x16 atlas, 16 samples: every stage's kernels, k_trace included, are
+ * launched once and show up in a profile of the process); a second thread's aob_init on the same device waits for it to finish. */
 int aob_init(const AobDeviceConfig* config);
-/* Replaces BakeEngine::Dispose (BakeEngine.cpp:215-279).  Since aob_init acquires nothing there is nothing to release
- * beyond the device selection (the calling thread's, and the process-wide one threads without their own fall back to);
- * handles still alive stay valid until aob_bake_destroy. */
+/* Replaces BakeEngine::Dispose (BakeEngine.cpp:215-279).  Since aob_init keeps nothing there is nothing to release beyond the device
+ * selection (the calling thread's, and the process-wide one threads without their own fall back to) and — when the LAST thread that called
+ * aob_init shuts down — the process-wide hemisphere table of REFERENCE_COMPAT bakes (host memory: 12 bytes per entry a chunk can index,
+ * 200 MB with the reference's constants; kept between bakes because a prefix of the sequence is the same for every bake).  Handles still
+ * alive stay valid until aob_bake_destroy. */
 void aob_shutdown(void);
 /* Fills `out` with the reference's constants (BakeEngine.cpp:13-18). */
 void aob_default_options(AobOptions* out);

@@ -21,6 +21,8 @@ struct AobMultiStepStats
 	std::vector<float>    trace_ms;         // per device: its trace launches (HIP events on the device's stream)
 	std::vector<double>   rank_ms;          // per device: build + rasterise + trace, host clock of its thread (gather excluded)
 	std::vector<uint64_t> rank_surfels;
+	std::vector<float>    rank_bvh_build_ms; // per device: the tree's build (every device builds the whole tree — redundantly; HIP events)
+	std::vector<double>   rank_gather_ms;   // per device: host time from posting its side of the exchange until its stream had drained (device 0: the last strip has arrived)
 	std::vector<int32_t>  row_begin, row_end;   // material 0's strip of every device in this step
 };
 

@@ -2223,7 +2223,9 @@ int orc_cut_walk(const AobBvh4QNode* nq, uint64_t count4, const AobQuantFrame* f
         uint32_t stack[ORC_STACK4]; int sp = 0;
         out->rays++;
         uint64_t entered = 0;
-        for (int e = 0; e < n_cut; e++) {
+        /* (the kernel walks the entries a ray entered shallowest first — the list's first entry first: pushed last, popped first — so that the
+         * visits counted here are the kernel's; the answer does not depend on it) */
+        for (int e = n_cut - 1; e >= 0; e--) {
             out->entries_tested++;
             if (ray4q_box(&r, &cut[4 * e + 1], t_max)) { stack[sp++] = cut[4 * e]; out->mask_bits++; entered |= 1ull << e; }
         }

@@ -207,3 +207,27 @@ def test_config2_scene_honours_the_obj_override(tmp_path, monkeypatch):
     assert name == "quad.obj" and FlatScene(sc).triangle_count() == 2
     tex = sc.GetMaterial(0).GetAOTexture()
     assert (tex.GetWidth(), tex.GetHeight(), tex.GetBytesPerChannel()) == (64, 64, 4)
+
+
+def test_torus_knot_is_a_closed_non_star_shaped_mesh_and_survives_the_obj_round_trip(tmp_path):
+    """scenes.torus_knot_mesh (BASELINE configs[1]'s second mesh, tests/test_gpu_fullsize.py): 2 n_u n_v triangles, one chart inside the
+    unit square, a closed tube (first and last ring / column coincide) — and NOT star-shaped: from its centroid some directions cross
+    the surface more than once (the displaced sphere never does).  Written as OBJ and imported it has the same triangles."""
+    from aobaker_amd import scenes
+    from aobaker_amd.scene import FlatScene
+    p, n, uv, idx = scenes.torus_knot_mesh(n_u=120, n_v=16, seed=2)
+    assert len(idx) == 3 * 2 * 120 * 16 and len(p) == 121 * 17
+    assert uv.min() >= 0.0 and uv.max() <= 1.0
+    grid = p.reshape(17, 121, 3)
+    assert np.allclose(grid[:, 0], grid[:, -1], atol=1e-5) and np.allclose(grid[0], grid[-1], atol=1e-5)
+    assert np.allclose(np.linalg.norm(n, axis=1), 1.0, atol=1e-4)
+    # star-shaped about c <=> every surface point is visible from c <=> the outward normal never faces away from c
+    c = p.mean(axis=0)
+    facing = ((p - c) * n).sum(axis=1)
+    assert (facing < -1e-3).mean() > 0.1                    # a good part of the surface looks back at the centroid: not star-shaped
+    # (the displaced sphere is star-shaped by construction: every vertex is its own direction from the centre times a radius)
+    path = scenes.torus_knot_obj(str(tmp_path / "knot.obj"), 120, 16, seed=2)
+    sc = Scene()
+    assets.load_obj(path, sc, atlas=(64, 64), channelCount=1, bytesPerChannel=4)
+    flat = FlatScene(sc)
+    assert flat.triangle_count() == 2 * 120 * 16 and sc.GetMaterialCount() == 1

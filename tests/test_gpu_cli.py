@@ -1,5 +1,6 @@
-"""The C++ host side (include/BakeEngine.h + aobaker_amd/host) produces the same bytes as the
-Python host side: both are thin callers of the same C ABI."""
+"""The C++ host side (include/BakeEngine.h + aobaker_amd/host: BakeEngine::Bake, the OBJ importer, the PNG / EXR writers, the CLI) produces
+the ORACLE's bytes — orc.bake on the same scene, imported by the Python twin of the importer — and, besides, the same bytes as the Python
+host side (both are thin callers of the same C ABI; that alone would compare the HIP path with itself: VERDICT r4, rows f1 / f2)."""
 import os
 import subprocess
 
@@ -7,6 +8,7 @@ import numpy as np
 import pytest
 
 from aobaker_amd import capi, scenes
+from aobaker_amd.scene import FlatScene
 from aobaker_amd.scenefile import write_scene
 
 pytestmark = pytest.mark.gpu
@@ -15,7 +17,7 @@ CLI = os.path.join(ROOT, "aobaker_amd", "host", "aobake_cli")
 
 
 @pytest.mark.parametrize("mode", ["compat", "cosine"])
-def test_cpp_bake_engine_matches_python_host(engine, tmp_path, mode):
+def test_cpp_bake_engine_matches_the_oracle_and_the_python_host(engine, orc, tmp_path, mode):
     assert os.path.exists(CLI), "build the C++ host side: make -C aobaker_amd/host"
     bpc = 1 if mode == "compat" else 4
     mk = lambda: scenes.terrain_scene(grid=64, atlas=128, bpc=bpc)
@@ -36,7 +38,10 @@ def test_cpp_bake_engine_matches_python_host(engine, tmp_path, mode):
     assert r.returncode == 0, r.stderr
     assert "surfels 16384" in r.stdout
     raw = np.fromfile(str(out) + "_0.raw", dtype=np.uint8)
-    assert np.array_equal(raw, sc.GetMaterial(0).GetAOTexture().GetData())
+    cpu = mk()
+    orc.bake(FlatScene(cpu).desc, opts, threads=8)
+    assert np.array_equal(raw, cpu.GetMaterial(0).GetAOTexture().GetData())            # the C++ host's image is the oracle's
+    assert np.array_equal(raw, sc.GetMaterial(0).GetAOTexture().GetData())             # ... and the Python host's
     if bpc == 1:
         pgm = open(str(out) + "_0.pgm", "rb").read()
         assert pgm.startswith(b"P5\n128 128\n255\n") and pgm[15:] == raw.tobytes()
@@ -61,8 +66,10 @@ def _grid_obj(n=24):
 
 
 @pytest.mark.parametrize("bpc", [1, 4])
-def test_cli_obj_to_png_matches_python_host(engine, tmp_path, bpc):
-    """OBJ -> BakeObject::LoadFromFile -> Bake -> BakeTexture::SavePNG / SaveEXR in C++ == the same chain in Python, byte for byte."""
+def test_cli_obj_to_png_matches_the_oracle_and_the_python_host(engine, orc, tmp_path, bpc):
+    """OBJ -> BakeObject::LoadFromFile -> Bake -> BakeTexture::SavePNG / SaveEXR in C++: the baked bytes are the ORACLE's bake of the
+    imported scene (the importer's conventions — triangulation, generated normals, handedness, V flip — are checked on the CPU in
+    tests/test_assets.py; here they carry a bake), and the files are the Python chain's, byte for byte."""
     from aobaker_amd import assets
     from aobaker_amd.scene import Scene
     assert os.path.exists(CLI), "build the C++ host side: make -C aobaker_amd/host"
@@ -83,7 +90,13 @@ def test_cli_obj_to_png_matches_python_host(engine, tmp_path, bpc):
                         "--spp", "32", "--seed", "5", "--sampler", "1", "--accumulate", "1", "--normal-fp16", "0"],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    assert np.array_equal(np.fromfile(str(out) + "_0.raw", dtype=np.uint8), tex.GetData())
+    cli_raw = np.fromfile(str(out) + "_0.raw", dtype=np.uint8)
+    cpu = Scene()
+    assets.load_obj(str(obj), cpu, atlas=(96, 96), channelCount=1, bytesPerChannel=bpc)
+    st = orc.bake(FlatScene(cpu).desc, opts, threads=8)
+    assert st.rays > 0 and 0.0 < st.hits / st.rays < 1.0
+    assert np.array_equal(cli_raw, cpu.GetMaterial(0).GetAOTexture().GetData())        # OBJ -> C++ importer -> HIP bake == OBJ -> oracle bake
+    assert np.array_equal(cli_raw, tex.GetData())
     assert open(str(out) + "_0.png", "rb").read() == assets.png_bytes(tex)
     img = assets.read_png(str(out) + "_0.png")
     assert img.shape == (96, 96, 1) and img.dtype == (np.uint8 if bpc == 1 else np.uint16)

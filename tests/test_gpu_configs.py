@@ -89,6 +89,14 @@ def test_config4_fixed_atlas_in_8_row_windows(engine, orc):
     assert np.array_equal(full["total_bits"][cells], ref["total_bits"][cells])
     assert np.array_equal(full["weight_bits"][cells], ref["weight_bits"][cells])
     print(f"configs[3] on one GPU: trace {ms_full:.1f} ms, {W * H * 256 / ms_full / 1e6:.2f} Grays/s")
+    # ... and the resolved image is the one `bench.py --gpus N` (N > 1) checks its own against (config.image_crc32_expected)
+    import zlib
+    import bench
+    with Baker(flat, opt) as b:
+        b.build_bvh(); b.rasterize(0); b.trace(0); b.resolve(0)
+        img = np.zeros(W * H * 4, dtype=np.uint8)
+        b.download(0, img)
+    assert zlib.crc32(img.tobytes()) == bench.CONFIG3_IMAGE_CRC32
 
 
 def run_mgpu(args, timeout=900):
@@ -142,6 +150,11 @@ def test_cpp_multi_gpu_host_config4_shape(engine, tmp_path):
     rec = run_mgpu(["--scene", path, "--devices", "0,0,0,0,0,0,0,0", "--steps", 2, "--warmup", 3, "--spp", 256, "--sampler", 1,
                     "--accumulate", 1, "--seed", 3, "--normal-fp16", 0, "--check-single"])
     assert rec["matches_single_device"] is True and rec["rays"] == 4096 * 4096 * 256 and rec["triangles"] == 999698
+    import bench
+    assert rec["image_crc32"] == [bench.CONFIG3_IMAGE_CRC32]
+    # the step's anatomy is in the record: every rank's redundant tree build, its trace kernel, and what the gather cost rank 0
+    assert len(rec["rank_bvh_build_ms"]) == 8 and all(0.0 < v < 50.0 for v in rec["rank_bvh_build_ms"]) and len(rec["rank_trace_kernel_ms"]) == 8
+    assert rec["gather_ms"] >= 0.0 and len(rec["rank_gather_ms"]) == 8
     print("aobake_mgpu 8 ranks on one device:", json.dumps({k: rec[k] for k in ("ms_per_step", "rank_ms", "rows")}))
 
 

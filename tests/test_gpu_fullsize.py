@@ -34,9 +34,15 @@ def terrain():
     return scenes.terrain_scene(grid=708, atlas=2048, seed=3, bpc=4)
 
 
-def test_config2_complete_bake(engine, orc):
+@pytest.mark.parametrize("mesh", ["stand-in", "torus knot OBJ"])
+def test_config2_complete_bake(engine, orc, mesh, tmp_path, monkeypatch):
     """configs[1], every material of it, GPU == oracle.  The mesh is scenes.config2_scene's: the displaced sphere standing in
-    for the bunny, or — AOB_CFG2_OBJ=/path/to.obj — the mesh in that file (imported like BakeObject::LoadFromFile)."""
+    for the bunny, or — AOB_CFG2_OBJ=/path/to.obj — the mesh in that file (imported like BakeObject::LoadFromFile).  Second
+    parametrisation (round 5): a 70 000-triangle displaced (2, 3) torus knot written as OBJ by scenes.torus_knot_obj and baked THROUGH
+    that override — a mesh of the bunny's class that, unlike the sphere, is not star-shaped: concavities, a handle, strands that pass
+    over and shadow each other (a quarter of its rays are occluded)."""
+    if mesh == "torus knot OBJ" and not os.environ.get("AOB_CFG2_OBJ"):
+        monkeypatch.setenv("AOB_CFG2_OBJ", scenes.torus_knot_obj(str(tmp_path / "torus_knot_70k.obj"), 700, 50, seed=2))
     (gpu, name), (cpu, _) = scenes.config2_scene(atlas=1024, seed=2, bpc=4), scenes.config2_scene(atlas=1024, seed=2, bpc=4)
     opt = cosine_options(orc, 64)
     opt.seed = 2
@@ -47,6 +53,8 @@ def test_config2_complete_bake(engine, orc):
     assert engine.LastStats.ray_count == st.rays and st.rays > 0
     if "stand-in" in name:
         assert engine.LastStats.triangle_count == 69938
+    if "torus_knot_70k" in name:
+        assert engine.LastStats.triangle_count == 70000 and 0.15 < st.hits / st.rays < 0.4        # it shadows itself
     for i in range(1, gpu.GetMaterialCount()):
         assert np.array_equal(gpu.GetMaterial(i).GetAOTexture().GetData(), cpu.GetMaterial(i).GetAOTexture().GetData())
     g, c = gpu.GetMaterial(0).GetAOTexture(), cpu.GetMaterial(0).GetAOTexture()

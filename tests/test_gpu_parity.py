@@ -979,7 +979,7 @@ def test_closest_hit_below_tile_cuts_is_the_oracles_walk_of_the_same_cuts(engine
         sub = ordered[64 * t:64 * t + 64]
         rays = np.ascontiguousarray(rays_all[64 * t:64 * t + 64].reshape(-1))
         # k_tile_cuts takes the box of the surfels that have a tangent frame: a surfel without one casts no ray (inactive records)
-        active = rays.reshape(len(sub), spp)["extra"][:, 1] != 0
+        active = rays.reshape(len(sub), spp)["extra"][:, 0, 1] != 0
         pos = sub["position"].astype(np.float32)[active]
         if len(pos) == 0:
             continue

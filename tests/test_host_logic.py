@@ -117,14 +117,14 @@ def test_bench_helpers_and_committed_counters():
     import bench
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     opts = capi.default_options()
-    opts.bvh_builder = 2                                           # the benchmark's builder (bench.py --bvh-builder)
+    opts.bvh_builder = 2                                           # what the library's default (-1: by workload) settles on for BASELINE configs[2]
     args = types.SimpleNamespace(spp=256, grid=708)
     rec, why = bench.counter_record(opts, args, 2048, 2048, 1)
     path = os.path.join(root, "profiles", "k_trace_counters.json")
     if os.path.exists(path):
         committed = json.load(open(path))
         if committed["source_sha256_16"] == bench.kernel_source_hash():
-            assert rec is not None and 1e9 < rec["hbm_side_bytes_per_launch"] < 1e12
+            assert rec is not None and 1e9 < rec.get("fabric_side_bytes_per_launch", rec.get("hbm_side_bytes_per_launch")) < 1e12
             roof = rec["roof"]                                     # BOTH roofs as throughput fractions, the larger one named
             assert roof["bound"] in ("vmem", "valu") and 0 < roof["frac"] <= 1.3
             assert roof["frac"] == max(roof["vmem"]["frac"], roof["valu"]["frac"])
@@ -136,10 +136,19 @@ def test_bench_helpers_and_committed_counters():
         assert rec is None
     other, why = bench.counter_record(opts, types.SimpleNamespace(spp=64, grid=708), 1024, 1024, 1)
     assert other is None                                           # another configuration never inherits the figure
-    r = bench.roofline_record(opts, args, 2048, 2048, 1, (15.0, 1.8), 1 << 30, 76.0)
-    assert r["bytes_per_ray"] == round(64.0 * 16.8 + 40.0 / 256, 1)             # SURVEY §8(d) as written
-    assert r["frac"] == round((1 << 30) * (64.0 * 16.8 + 40.0 / 256) / 76e-3 / 1e9 / 8000.0, 4)
-    assert r["bytes_per_ray_build"] == round(64.0 * 15.0 + 48.0 * 1.8 + 64.0 + 8.0 / 256, 1)
+    requested = {"node_fetches": 6.0, "triangle_fetches": 1.9, "cut_entries_tested": 30.0, "cut_entries_entered": 2.2, "counted_on": "test"}
+    footprint = {"bytes": 800e6, "of_which": {}}
+    r = bench.roofline_record(opts, args, 2048, 2048, 1, (15.0, 1.8), 1 << 30, 76.0, requested, footprint)
+    assert r["bytes_per_ray_algorithmic"] == round(64.0 * 16.8 + 40.0 / 256, 1)             # SURVEY §8(d) as written ...
+    assert r["algorithmic_frac"] == round((1 << 30) * (64.0 * 16.8 + 40.0 / 256) / 76e-3 / 1e9 / 8000.0, 4)      # ... kept, and allowed above 1
+    # the roofline fraction proper: bytes the lanes request from the vector L1 against its 64 B / clk / CU — physically bounded
+    b_req = 64.0 * 6.0 + 48.0 * 1.9 + 16.0 + 48.0 + 8.0 / 256
+    assert r["requested"]["bytes_per_ray"] == round(b_req, 1)
+    assert r["frac"] == round(round((1 << 30) * b_req / 76e-3 / 1e9, 1) / (64.0 * 256 * 2.4), 4) and 0 < r["frac"] <= 1
+    assert r["achieved"] == r["requested"]["GBps"] and r["peak"] == round(64.0 * 256 * 2.4, 1) and r["unit"] == "GB/s"
+    assert all(v is None or 0 <= v <= 1 for v in r["byte_rate_fractions"].values())
+    if r["fabric"]:
+        assert r["refetch_ratio"] == round(r["fabric"]["bytes_per_launch"] / 800e6, 1) and r["traffic"] == r["fabric"]["bytes_per_launch"]
     surfels = np.zeros(64 * 64, dtype=capi.surfel_dtype())
     surfels["texel_x"], surfels["texel_y"] = np.tile(np.arange(64), 64), np.repeat(np.arange(64), 64)
     sub = bench._subsample(surfels, 16)
@@ -164,7 +173,7 @@ def test_counter_records_and_scaling_bases_of_other_runs_are_refused(tmp_path):
     opts.bvh_builder = 2
     args = types.SimpleNamespace(spp=256, grid=708)
     key = bench.counter_key(opts, args, 2048, 2048, 1)
-    good = {"source_sha256_16": bench.kernel_source_hash(), "config": key, "hbm_side_bytes_per_launch": 4e10, "roof": None}
+    good = {"source_sha256_16": bench.kernel_source_hash(), "config": key, "fabric_side_bytes_per_launch": 4e10, "counters": {"TCP_TCC_READ_REQ_sum": 4e9}, "roof": None}
     path = tmp_path / "rec.json"
     path.write_text(json.dumps(good))
     rec, why = bench.counter_record(opts, args, 2048, 2048, 1, str(path))

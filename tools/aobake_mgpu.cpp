@@ -122,6 +122,12 @@ int main(int argc, char** argv)
 	            "\"triangles\": %llu, \"balance\": %s, \"rank_ms\": [", steps, warmup, ms, best_ms, (unsigned long long)st.surfels, (unsigned long long)st.rays,
 	            (double)st.rays / (ms * 1e-3), (unsigned long long)stats.triangle_count, balance ? "true" : "false");
 	for (size_t r = 0; r < rank_sum.size(); r++) std::printf("%s%.3f", r ? ", " : "", rank_sum[r] / steps);
+	std::printf("], \"rank_bvh_build_ms\": [");
+	for (size_t r = 0; r < st.rank_bvh_build_ms.size(); r++) std::printf("%s%.3f", r ? ", " : "", st.rank_bvh_build_ms[r]);
+	std::printf("], \"rank_trace_kernel_ms\": [");
+	for (size_t r = 0; r < st.trace_ms.size(); r++) std::printf("%s%.3f", r ? ", " : "", st.trace_ms[r]);
+	std::printf("], \"gather_ms\": %.3f, \"rank_gather_ms\": [", st.rank_gather_ms.empty() ? 0.0 : st.rank_gather_ms[0]);
+	for (size_t r = 0; r < st.rank_gather_ms.size(); r++) std::printf("%s%.3f", r ? ", " : "", st.rank_gather_ms[r]);
 	std::printf("], \"rows\": [");
 	for (size_t r = 0; r < st.row_begin.size(); r++) std::printf("%s[%d, %d]", r ? ", " : "", st.row_begin[r], st.row_end[r]);
 	std::printf("], \"image_crc32\": [");

@@ -4,7 +4,7 @@
 FETCH_SIZE`, CALIB_DIR) and the slope builds of the kernel (tools/build_variants.py valuN / loadN, tools/time_trace.py ->
 SLOPES.jsonl) into the record bench.py reads (profiles/k_trace_counters.json):
 
-  hbm_side_bytes_per_launch   FETCH_SIZE x 1 KiB x correction + WRITE_SIZE x 1 KiB, the correction being known bytes /
+  fabric_side_bytes_per_launch  (requests leaving the L2s, Infinity-Cache hits included) FETCH_SIZE x 1 KiB x correction + WRITE_SIZE x 1 KiB, the correction being known bytes /
                               counted bytes of k_gather64 — a lane reading one random 64-byte record as 4 x 16 B, k_trace's
                               own access pattern (the guide's x2 is for wide streaming reads; measured here beside it)
   roof                        BOTH roofs of k_trace as throughput fractions, from measurements on THIS kernel, and the larger named:
@@ -196,8 +196,10 @@ def main():
         "fetch_size_calibration": cal,
         "fetch_correction_used": corr if corr else 1.0,
         "FETCH_bytes_raw": fetch_raw, "WRITE_bytes": write,
-        "hbm_side_bytes_per_launch": fetch_raw * (corr if corr else 1.0) + write,
-        "hbm_side_bytes_per_launch_raw": fetch_raw + write,
+        # requests leaving the L2s: Infinity-Cache (MALL) hits are counted in (MI355X_MICROARCH.md, HBM section) — fabric-side traffic, an
+        # upper bound on what HBM itself moved (rounds 1-4 called it hbm_side_bytes_per_launch)
+        "fabric_side_bytes_per_launch": fetch_raw * (corr if corr else 1.0) + write,
+        "fabric_side_bytes_per_launch_raw": fetch_raw + write,
         "roof": roof,
         "clock_hz_in_pmc_passes": round(clock_hz),
         "valu_lane_occupancy": round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_INSTS_VALU"]), 4),

@@ -28,4 +28,4 @@ cd $R
 bash tools/pmc_passes.sh $O/pmc "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU" "SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_INT32" "SQ_INSTS_VALU_CVT SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT64" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES" "SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "TA_BUSY_avr TA_BUSY_max" "TA_TOTAL_WAVEFRONTS_sum" "TD_TD_BUSY_sum" "TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCP_TCP_LATENCY_sum TCP_TCC_READ_REQ_LATENCY_sum" "TCP_PENDING_STALL_CYCLES_sum" "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH" > $O/pmc_passes.log 2>&1; echo "pmc rc=$?"
 cp tools/_variants/valu_mix.json $O/roofs/valu_mix.json 2>/dev/null
 python3 tools/pmc_record.py $O/pmc $O/calib $O/roofs/slopes.jsonl $O/k_trace_counters.json $O/roofs/valu_mix.json > $O/record.log 2>&1; echo "record rc=$?"
-grep -E "\"bound\"|\"frac\"|hbm_side_bytes_per_launch\"|L2_hit|\"mean\"" $O/record.log
+grep -E "\"bound\"|\"frac\"|fabric_side_bytes_per_launch\"|L2_hit|\"mean\"" $O/record.log
