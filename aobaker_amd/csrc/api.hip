@@ -265,7 +265,7 @@ void aob_default_options(AobOptions* o)
     o->raster_mode = AOB_RASTER_REFERENCE;
     o->raster_layers = AOB_LAYERS_LAST;
     // schedule of k_trace: the measured optima on BASELINE configs[2]
-    o->trace_refill_idle = 0;     // by scoring mode (trace.hip): COSINE sampler with any-hit scoring 16 (42 without tile cuts), table sampler with any-hit scoring 24, closest-hit scoring 16
+    o->trace_refill_idle = 0;     // by scoring mode (trace.hip): COSINE sampler with any-hit scoring 16 (42 without tile cuts), table sampler with any-hit scoring 24, closest-hit scoring 8 (16 without tile cuts)
     o->trace_leaf_wait = 0;       // by scoring mode: 24 with any-hit scoring, 16 with closest-hit scoring (trace.hip)
     o->trace_parts = 4;
     o->trace_part_min = 16;

@@ -500,7 +500,9 @@ void k_trace(TraceParams p)
     const uint32_t kScalarMin = p.scalar_min;
     // overflow stack entry e of this lane lives at gstack[(e * gridDim.x + blockIdx.x) * 64 + lane] (computed on use:
     // the path is cold and the registers are better spent on occupancy)
-    auto gs_slot = [&](int e) -> uint32_t* { return p.gstack + ((uint64_t)e * gridDim.x + blockIdx.x) * kWave + lane; };
+    // (the base stays in scalar registers — it passes an empty asm — instead of a vector-register copy that the allocator, at the 64-register cap,
+    // spilt and re-loaded from scratch INSIDE the main loop: the only scratch accesses there were these, tools/scratch_report.py)
+    auto gs_slot = [&](int e) -> uint32_t* { uint32_t* base = p.gstack; asm volatile("" : "+s"(base)); return base + ((uint64_t)e * gridDim.x + blockIdx.x) * kWave + lane; };
 
     // ---- persistent wavefronts ----
     // The launch is as many wavefronts as the chip holds (32 per CU); each takes work units — one tile (64 surfels) x
@@ -1417,7 +1419,9 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
         // profiles/r04/cuts/)
         // (the table sampler below its tiles' cuts — the reference's own constants on the terrain: refill 8 / 16 / 24 / 32 -> 43.7 / 43.1 / 42.7 / 42.8 ms,
         // leaf wait 16 / 20 / 28 -> 43.5 / 43.1 / 42.6; without cuts 46.6)
-        p.refill_idle = knob(o.trace_refill_idle, o.use_any_hit ? (o.sampler == AOB_SAMPLER_COSINE ? (cut ? 16 : 42) : 24) : 16);
+        // (round 5, closest-hit rays below their tiles' cuts: refill 8 / 12 / 16 / 24 / 32 -> 68.9 / 69.9 / 70.8 / 73.5 / 78.5 ms on the terrain at 256 spp with falloff scoring,
+        // 40.7 / 40.9 / 41.4 / 42.9 / 45.5 on configs[4]'s scene at 2048^2 x 64 spp; profiles/r05/closest_cuts/)
+        p.refill_idle = knob(o.trace_refill_idle, o.use_any_hit ? (o.sampler == AOB_SAMPLER_COSINE ? (cut ? 16 : 42) : 24) : (cut ? 8 : 16));
         // (the leaf section: 16 parked lanes, 24 with any-hit scoring — 12 / 16 / 20 / 24 / 28 -> 59.5 / 58.3 / 57.9 / 57.7 / 57.7 ms on
         // BASELINE configs[2]; the scalar steps: since the vector-memory path is what binds the walk (profiles/r03/roofs/) a step pays
         // for 24 lanes on one node — 16 / 24 / 32 / 36 / 40 -> 56.9 / 56.6 / 56.9 / 57.2 / 57.7 ms — where round 2's kernel wanted 40)

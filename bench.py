@@ -620,8 +620,11 @@ def roofline_record(opts, args, W, H, world, visits, my_rays, kernel_ms, request
     fracs = {"l1_request_path": l1_frac, "l2": (l2 or {}).get("frac"), "fabric": (fabric or {}).get("frac")}
     known = {k: v for k, v in fracs.items() if v is not None}
     binding = max(known, key=known.get) if known else None
-    return {"bound": "vmem", "bound_is": "the CU's vector-memory request path (TA / L1 / TD): of the byte-rate fractions below the largest, and the unit the slope builds point to "
-                                         "(one more 4-byte load per visit costs 20 CU cycles, one more v_xor 1.4 SIMD cycles: roofs)",
+    return {"bound": "vmem", "bound_is": "the memory roof nearest to this kernel: the CU's vector-memory request path (TA / L1 / TD) — of the byte-rate fractions below the largest.  "
+                                         "HBM is far (fabric).  What the slope builds of THIS kernel name as its binding unit — instructions, not bytes — is in `roofs` "
+                                         "(round 5: the vector ALU, 0.72 of its issue slots, the vector-memory path 0.58: `instruction_roof`)",
+            "instruction_roof": ({"bound": roofs.get("bound"), "frac": roofs.get("frac"), "valu_frac": (roofs.get("valu") or {}).get("frac"),
+                                  "vmem_frac": (roofs.get("vmem") or {}).get("frac")} if roofs else None),
             "achieved": (req or {}).get("GBps"), "peak": round(L1_PEAK_GBS, 1), "unit": "GB/s", "frac": l1_frac,
             "frac_is": "bytes the kernel's lanes request from the vector L1 / kernel time / (64 B x 256 CUs x 2.4 GHz); <= 1 by construction",
             "byte_rate_fractions": fracs, "largest_byte_rate_fraction": binding,

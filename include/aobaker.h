@@ -114,8 +114,9 @@ typedef struct AobOptions {
      * cell (tests/test_gpu_parity.py::test_trace_schedule_knobs_do_not_change_results).  aob_default_options writes the
      * values measured fastest on MI355X for BASELINE configs[2]; 0 in any of them also means "that default". */
     int32_t  trace_refill_idle;   /* lanes of a wavefront without a ray that trigger the refill section: 1..64; default 0 = by
-                                     scoring mode: 42 with the COSINE sampler and any-hit scoring, 24 with the table sampler
-                                     and any-hit scoring, 16 with closest-hit scoring                                       */
+                                     scoring mode, for rays that start below tile cuts (trace_cut, the default): 16 with the COSINE sampler
+                                     and any-hit scoring, 24 with the table sampler and any-hit scoring, 8 with closest-hit scoring (from
+                                     the root: 42 / 24 / 16)                                                                 */
     int32_t  trace_leaf_wait;     /* lanes parked at a leaf that trigger the leaf section: 1..64; default 0 = by scoring mode:
                                      24 with any-hit scoring, 16 with closest-hit scoring                                  */
     int32_t  trace_parts;         /* sample parts a tile's rays are cut into (units of one work queue), default 4          */
