@@ -82,7 +82,7 @@ __device__ __forceinline__ uint4 as_uint4(v4u v) { return make_uint4(v.x, v.y, v
 #endif
 #ifndef AOB_LEAF_HELPERS
 #define AOB_LEAF_HELPERS 1          // leaf pairs (QUANT 2): the second triangle of a parked lane's pair is tested by a lane that is NOT parked at a leaf
-                                    // — one Möller–Trumbore pass per leaf section instead of two (round 5); 0: the parked lane tests both itself
+                                    // — one Möller–Trumbore pass per leaf section instead of two (round 5); 0: the parked lane tests both itself; 2: any-hit rays only
 #endif
 #ifndef AOB_CUT_SHRINK_PCT
 #define AOB_CUT_SHRINK_PCT 25        // k_tile_cuts opens the slots that meet the tile's box PULLED IN by this share of its extent on every side
@@ -650,13 +650,21 @@ void k_trace(TraceParams p)
     // ---- one visit of a quantised 4-ary node: four slab tests, the next node and the deferred children ----
     auto visit4 = [&](const uint4& c0, const uint4& c1, const uint4& c2, const uint4& c3, bool shallow) {
             auto slab = [&](const uint4& c, float& tn) -> bool {
-                if (ANYHIT) return slab4q_anyhit(c, invdir, oxinvdir, nsel, fsel, tn);
+                if (ANYHIT && SAMPLER == AOB_SAMPLER_COSINE) return slab4q_anyhit(c, invdir, oxinvdir, nsel, fsel, tn);
+                if (ANYHIT) {
+                    // (the table sampler's instantiations hold a weight and two sums more and spill inside the loop: the far selectors are made here, as below)
+                    constexpr uint32_t kSwapA = 0x0701000cu ^ 0x0703020cu;
+                    return slab4q_anyhit(c, invdir, oxinvdir, nsel, make_uint3(nsel.x ^ kSwapA, nsel.y ^ kSwapA, nsel.z ^ kSwapA), tn);
+                }
                 // closest hit: intersect_bvh2_lds.cl:54-63 on the plane floats — near clamped at 0, far at the closest hit so far.
                 // (Written out here: as a function shared with the any-hit form the register allocator spilt three more values, +40 %.)
                 constexpr uint32_t kHalf = 0x3f000000u;
-                const v2f fx = { __uint_as_float(__builtin_amdgcn_perm(kHalf, c.x, nsel.x)), __uint_as_float(__builtin_amdgcn_perm(kHalf, c.x, fsel.x)) };
-                const v2f fy = { __uint_as_float(__builtin_amdgcn_perm(kHalf, c.y, nsel.y)), __uint_as_float(__builtin_amdgcn_perm(kHalf, c.y, fsel.y)) };
-                const v2f fz = { __uint_as_float(__builtin_amdgcn_perm(kHalf, c.z, nsel.z)), __uint_as_float(__builtin_amdgcn_perm(kHalf, c.z, fsel.z)) };
+                // (the far plane's selector is the near one's with the two half-words swapped: made here, by one v_xor_b32 each, instead of held in
+                // three more registers across the walk — this instantiation is the one that spills inside its loop, tools/scratch_report.py)
+                constexpr uint32_t kSwap = 0x0701000cu ^ 0x0703020cu;
+                const v2f fx = { __uint_as_float(__builtin_amdgcn_perm(kHalf, c.x, nsel.x)), __uint_as_float(__builtin_amdgcn_perm(kHalf, c.x, nsel.x ^ kSwap)) };
+                const v2f fy = { __uint_as_float(__builtin_amdgcn_perm(kHalf, c.y, nsel.y)), __uint_as_float(__builtin_amdgcn_perm(kHalf, c.y, nsel.y ^ kSwap)) };
+                const v2f fz = { __uint_as_float(__builtin_amdgcn_perm(kHalf, c.z, nsel.z)), __uint_as_float(__builtin_amdgcn_perm(kHalf, c.z, nsel.z ^ kSwap)) };
                 const v2f tx = __builtin_elementwise_fma(fx, (v2f){ invdir.x, invdir.x }, (v2f){ oxinvdir.x, oxinvdir.x });
                 const v2f ty = __builtin_elementwise_fma(fy, (v2f){ invdir.y, invdir.y }, (v2f){ oxinvdir.y, oxinvdir.y });
                 const v2f tz = __builtin_elementwise_fma(fz, (v2f){ invdir.z, invdir.z }, (v2f){ oxinvdir.z, oxinvdir.z });
@@ -758,7 +766,7 @@ void k_trace(TraceParams p)
                             // The near plane is min for rays that travel up the axis, max for rays that travel down it.
                             constexpr uint32_t kLow = 0x0701000cu, kHigh = 0x0703020cu;
                             nsel = make_uint3((e1.x >> 31) ? kHigh : kLow, (e1.y >> 31) ? kHigh : kLow, (e1.z >> 31) ? kHigh : kLow);
-                            fsel = make_uint3(nsel.x ^ (kLow ^ kHigh), nsel.y ^ (kLow ^ kHigh), nsel.z ^ (kLow ^ kHigh));
+                            if (ANYHIT && SAMPLER == AOB_SAMPLER_COSINE) fsel = make_uint3(nsel.x ^ (kLow ^ kHigh), nsel.y ^ (kLow ^ kHigh), nsel.z ^ (kLow ^ kHigh));
                         }
                         if (QUANT) {
                             rot = make_uint3((e1.x >> 31) << 4, (e1.y >> 31) << 4, (e1.z >> 31) << 4);
@@ -948,7 +956,7 @@ void k_trace(TraceParams p)
         // (any hit; closest-hit scoring — configs[4] — loses 1.5 % with it and keeps "nobody left walking")
         if (__popcll(__ballot(at_leaf)) >= p.leaf_wait || (uint32_t)__popcll(inner_m) < (ANYHIT ? 16u : 1u)) {
             { const uint64_t leaf_m_ = __ballot(at_leaf); AOB_STAT(3, 1); AOB_STAT(4, __popcll(leaf_m_)); (void)leaf_m_; }
-            if (AOB_LEAF_HELPERS && QUANT == 2) {
+            if ((AOB_LEAF_HELPERS == 1 || (AOB_LEAF_HELPERS == 2 && ANYHIT)) && QUANT == 2) {
                 // ---- helper lanes (round 5) ----
                 // A leaf section runs with ~20 of 64 lanes parked, and a parked lane's PAIR costs two Möller–Trumbore passes (with an IEEE division
                 // each) that the other 44 lanes sit out.  Here the pair with rank j among the parked pairs hands its second triangle to the lane with

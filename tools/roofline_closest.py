@@ -32,10 +32,12 @@ def main():
     lc = last_json(os.path.join(d, "loop_counters.jsonl"))["loop_counters"]
     pmc = json.load(open(os.path.join(d, "pmc", "summary.json")))
     c = pmc["counters"]
-    launches = max(1, min(pmc.get("launches", {"": 1}).values()))
     rays = lc["pops"]
     per = lc["per_ray"]
     seconds = t["trace_ms"] * 1e-3
+    # the launches the counters were summed over: the profiled program traces twice (tools/time_trace.py --reps 1); the summed kernel time says so
+    # (the dispatch count of a pass also holds what other instantiations the process ran)
+    launches = max(1, round(pmc["kernel_ms"] / t["trace_ms"]))
     # what a ray asks the vector L1 for: 64 B per node visit, 48 B per triangle of a leaf visit (a leaf slot is a pair of triangles or one: between 48 and
     # 96 B — the pair share is not counted by the kernel, both bounds are given), 16 B of its surfel's record at the pop, 48 B of the frame at its generation
     lo = 64.0 * per["inner_visits"] + 48.0 * per["leaf_visits"] + 64.0

@@ -11,6 +11,7 @@ Product code only (no oracle).  LIB `-` is the in-tree library.
   refmode  the reference's own constants on the same terrain: 100 spp, table sampler, int32 sums, any hit           k_trace<0,1,0,10,2,0>
   cfg2     configs[1]: 69 938-triangle sphere, 1024^2, 64 spp, any hit
   cfg5     configs[4]'s instanced scene (10 M triangles) at its own 8192^2 atlas, 16 of its 1024 spp, closest-hit falloff scoring
+  cfg5full configs[4] itself: the instanced scene at 8192^2 and all 1024 spp (58 G rays, ~10 s per trace: use --reps 1)
   cfg5s    configs[4]'s instanced scene (10 M triangles) at 2048^2 x 64 spp, closest-hit falloff scoring
 
   python tools/build_variants.py base= valu8=-DAOB_EXP_VALU=8 && python tools/time_trace.py tools/_variants/lib_*.so
@@ -60,6 +61,9 @@ def child(modes, reps, knobs):
         elif mode == "cfg5":
             flat, spp = FlatScene(scenes.instanced_scene(instances=100, rock_n=224, atlas=8192, seed=5, bpc=1)), 16
             o = cosine(16, 5, use_any_hit=0, falloff_distance=1.25, clamp_tmax_to_falloff=1)
+        elif mode == "cfg5full":
+            flat, spp = FlatScene(scenes.instanced_scene(instances=100, rock_n=224, atlas=8192, seed=5, bpc=1)), 1024
+            o = cosine(1024, 5, use_any_hit=0, falloff_distance=1.25, clamp_tmax_to_falloff=1)
         elif mode == "cfg5s":
             flat, spp = FlatScene(scenes.instanced_scene(instances=100, rock_n=224, atlas=2048, seed=5, bpc=1)), 64
             o = cosine(64, 5, use_any_hit=0, falloff_distance=1.25, clamp_tmax_to_falloff=1)
