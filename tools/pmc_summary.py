@@ -15,11 +15,21 @@ def main():
     root = sys.argv[1]
     kernel = sys.argv[2] if len(sys.argv) > 2 else "k_trace"
     out = {"counters": {}, "kernel": None, "launches": {}}
+    # the instantiation measured: of the kernels whose name holds `kernel`, the one the passes spent the most time in — not the one-triangle
+    # warm-up bake of aob_init (another instantiation, microseconds), nor a second mode the profiled program may have run
+    spent = {}
+    for path in sorted(glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True)):
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                if kernel in row["Kernel_Name"]:
+                    spent[row["Kernel_Name"]] = spent.get(row["Kernel_Name"], 0) + int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+    if spent:
+        kernel = max(spent, key=spent.get)
     for path in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
         dispatches = set()
         with open(path, newline="") as f:
             for row in csv.DictReader(f):
-                if kernel not in row["Kernel_Name"]:
+                if kernel not in row["Kernel_Name"] or (spent and row["Kernel_Name"] != kernel):
                     continue
                 out["kernel"] = row["Kernel_Name"]
                 name = row["Counter_Name"]
@@ -30,14 +40,13 @@ def main():
                 out["scratch_size"] = int(row["Scratch_Size"])
         out["launches"][os.path.relpath(path, root)] = len(dispatches)
     # the kernel's duration in the counter passes (kernel-trace of the same runs): the clock the counters ran at = cycles / this
-    # (per pass the SUM over the kernel's launches — the sections of a bake, and the one-triangle warm-up bake of aob_init, a few
-    # microseconds — as the counters are summed; then the mean over the passes)
+    # (per pass the SUM over that instantiation's launches — the sections of a bake — as the counters are summed; then the mean over the passes)
     ms = []
     for path in sorted(glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True)):
         total = 0.0
         with open(path, newline="") as f:
             for row in csv.DictReader(f):
-                if kernel in row["Kernel_Name"]:
+                if kernel in row["Kernel_Name"] and (not spent or row["Kernel_Name"] == kernel):
                     total += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6
         if total > 0.0:
             ms.append(total)
