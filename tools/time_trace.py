@@ -95,6 +95,7 @@ def child(modes, reps, knobs):
                 names = ("loop_iterations", "inner_sections", "inner_lanes", "leaf_sections", "leaf_lanes", "refill_sections", "pops", "generation_batches",
                          "cut_entries_tested", "cut_entries_entered", "drain_packed", "deep_stack_visits")
                 stats = {k: int(buf[i]) for i, k in enumerate(names)}
+                stats["hbm_stack_pushes"], stats["hbm_stack_pops"] = int(buf[12]), int(buf[13])      # (counted only by experiment builds; 0 otherwise)
                 # (inner sections run after the unit's last ray was generated: sections << 40 | lanes)
                 stats["drain_inner_sections"], stats["drain_inner_lanes"] = stats["drain_packed"] >> 40, stats["drain_packed"] & ((1 << 40) - 1)
                 del stats["drain_packed"]
