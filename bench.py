@@ -375,14 +375,14 @@ def main():
         rank_ms = [float(v.item()) for v in every]
         # every rank's own stages of the last step (each builds the whole tree — redundantly — and rasterises and traces its strip) and what
         # it spent in the gather: the redundant build's share of a rank's step is visible here, not inferred
-        mine4 = torch.tensor([stats.ms_bvh_build, sum(build_raster_ms) / len(build_raster_ms) - stats.ms_bvh_build, sum(trace_ms) / len(trace_ms), sum(gather_ms) / max(1, len(gather_ms))],
+        mine4 = torch.tensor([stats.ms_bvh_build, max(0.0, sum(build_raster_ms) / len(build_raster_ms) - stats.ms_bvh_build), sum(trace_ms) / len(trace_ms), sum(gather_ms) / max(1, len(gather_ms))],
                              dtype=torch.float64, device=comm_device)
         every4 = [torch.zeros(4, dtype=torch.float64, device=comm_device) for _ in range(world)]
         dist.all_gather(every4, mine4)
         rank_stages = [[float(x) for x in v.tolist()] for v in every4]
     else:
         counts["surfels"] = counts["mine"]
-        rank_stages = [[stats.ms_bvh_build, sum(build_raster_ms) / len(build_raster_ms) - stats.ms_bvh_build, sum(trace_ms) / len(trace_ms), 0.0]]
+        rank_stages = [[stats.ms_bvh_build, max(0.0, sum(build_raster_ms) / len(build_raster_ms) - stats.ms_bvh_build), sum(trace_ms) / len(trace_ms), 0.0]]
     total_rays = counts["surfels"] * args.spp                  # all ranks together
     ms_per_step = elapsed / args.steps * 1e3
     value = total_rays / (elapsed / args.steps)
