@@ -121,6 +121,17 @@ class Baker:
         capi.check(self.lib.aob_bake_copy_tile_cuts(self.handle, material, out.ctypes.data, out.size, C.byref(tiles), C.byref(records)))
         return out
 
+    def horizon(self, material=0) -> np.ndarray:
+        """The horizon tables of the material's most recent trace launches: uint8 [surfels, stride] in the order of surfels() — byte cy =
+        leading cells of row cy of the COSINE sampler's grid that were not cast — or an empty array if the launches had none."""
+        stride, n = C.c_uint32(), C.c_uint64()
+        n_all = self.surfel_count(material)
+        out = np.zeros((max(n_all, 1), 32), dtype=np.uint8)
+        capi.check(self.lib.aob_bake_copy_horizon(self.handle, material, out.ctypes.data, out.nbytes, C.byref(stride), C.byref(n)))
+        if n.value == 0:
+            return np.zeros((0, 0), dtype=np.uint8)
+        return out.reshape(-1)[:n.value * stride.value].reshape(n.value, stride.value).copy()
+
     def surfel_count(self, material=0) -> int:
         n = C.c_uint64()
         capi.check(self.lib.aob_bake_surfel_count(self.handle, material, C.byref(n)))

@@ -61,6 +61,9 @@ struct DeviceMaterial {
     uint32_t* tile_cuts = nullptr;        // 128 words per 64-surfel tile and sample part of a trace launch: the tile's cut of the tree (trace.hip k_tile_cuts)
     uint64_t  tile_cut_capacity = 0;      // ... in words
     uint32_t  tile_cut_tiles = 0, tile_cut_records = 0;   // ... of the most recent launch (0 tiles: it walked from the root)
+    uint8_t*  horizon = nullptr;          // horizon tables of the surfels (horizon.hip): per surfel, in trace order, the free columns of every azimuth row of the COSINE sampler's grid
+    uint64_t  horizon_capacity = 0;       // ... in bytes
+    uint64_t  horizon_asked = 0;          // samples of the launches that had tables, since the last rasterisation (AobStats::rays_cast)
     uint32_t* tile_sums = nullptr;        // scan partials of the tile-order pass
     uint32_t* tile_row_prefix = nullptr;  // covered texels before each 8-texel tile row (first section)
     uint32_t* tile_row_prefix_host = nullptr;   // pinned copy
@@ -125,6 +128,7 @@ struct AobBake {
     bool      any_mesh_flags = false;
     int cu_count = 256;
     uint64_t gstack_words = 0;
+    unsigned long long* horizon_counters = nullptr;   // [8]: k_horizon's diagnostics [0..5], [6] the samples k_trace generated under horizon tables, [7] those it was asked for
     unsigned long long* acc_cells = nullptr;   // 2 x 64-bit exact sums per result cell of the largest material: where the sample parts of a tile
     uint64_t acc_cells_count = 0;              // add up when the cells are floats that hold fractions (trace.hip; sized at creation, kept zero)
 
@@ -156,6 +160,9 @@ int rasterize_material(AobBake* b, int32_t material, int32_t row_begin, int32_t 
 int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end);   // trace.hip
 void reserve_tile_cuts(AobBake* b, int32_t material);        // trace.hip: the tile cuts of the material's launches, sized by what was rasterised
 int reserve_trace_stack(AobBake* b);                         // trace.hip: the walk's HBM overflow stack, sized by the tree's depth
+bool horizon_applies(const AobBake* b);                      // horizon.hip: the options allow horizon tables (COSINE sampler on a full grid, quantised 4-ary nodes, trace_horizon != 1)
+uint32_t horizon_stride(const AobBake* b);                   // ... bytes per surfel
+bool horizon_build(AobBake* b, DeviceMaterial& m, uint64_t begin, uint64_t end, float tmax);   // ... the tables of a launch's surfels (false: no memory)
 int resolve_material(AobBake* b, int32_t material);          // resolve.hip
 uint64_t chunk_texel_max(const AobOptions& opt);             // trace.hip (BakeEngine.cpp:359-364)
 }

@@ -116,6 +116,7 @@ static int validate_options(const AobOptions* o)
     if (o->trace_parts < 0 || o->trace_parts > 64 || o->trace_part_min < 0 || o->trace_fine_div < 0) { set_error("trace_parts %d (0..64), trace_part_min %d, trace_fine_div %d: must not be negative", o->trace_parts, o->trace_part_min, o->trace_fine_div); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->trace_scalar_min < 0 || o->trace_scalar_min > 64) { set_error("trace_scalar_min %d: must be 0 (default) or 1..64", o->trace_scalar_min); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->trace_cut < 0 || o->trace_cut > 32 || o->trace_cut == 2 || o->trace_cut == 3) { set_error("trace_cut %d: must be 0 (default: 32 entries), 1 (off) or 4..32", o->trace_cut); return AOB_ERR_INVALID_ARGUMENT; }
+    if (o->trace_horizon < 0 || o->trace_horizon > 1) { set_error("trace_horizon %d: must be 0 (default: horizon tables where they apply) or 1 (off)", o->trace_horizon); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->trace_bands < 0 || o->trace_bands > 2) { set_error("trace_bands %d: must be 0 (default), 1 or 2", o->trace_bands); return AOB_ERR_INVALID_ARGUMENT; }
     if (!(o->falloff_distance > 0.0f)) { set_error("falloff_distance must be positive"); return AOB_ERR_INVALID_ARGUMENT; }
     return AOB_OK;
@@ -157,6 +158,7 @@ static void free_bake(AobBake* b)
     for (auto& m : b->materials) {
         release_device(b, m.prev_layer); release_device(b, m.surfels); release_device(b, m.section_index); release_device(b, m.frames); release_device(b, m.perm);
         release_device(b, m.tile_cuts);
+        if (m.horizon) hipFree(m.horizon);
         if (m.tile_row_prefix_host) hipHostFree(m.tile_row_prefix_host);
     }
     release_device(b, b->gstack);
@@ -273,6 +275,7 @@ void aob_default_options(AobOptions* o)
     o->trace_bands = 1;
     o->trace_scalar_min = 0;       // by sampler (trace.hip)
     o->trace_cut = 0;              // tile cuts of 32 entries where they apply (trace.hip)
+    o->trace_horizon = 0;          // horizon tables where they apply (horizon.hip)
 }
 
 int aob_init(const AobDeviceConfig* config)
@@ -389,6 +392,7 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
     // ---- plan: what every stage needs, sized once ----
     ArenaPlan plan;
     plan.want(&b->trace_unit_next, 8);
+    plan.want(&b->horizon_counters, 8 + scene->material_count);
     b->meshes.resize(scene->mesh_count);
     uint64_t tri_total = 0;
     for (uint32_t i = 0; i < scene->mesh_count; i++) {
@@ -537,6 +541,7 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
     for (auto& d : b->materials)
         AOB_CH(hipMemsetAsync(d.results, 0, sizeof(AobResult) * (uint64_t)d.width * d.height, b->stream));
     if (b->acc_cells) AOB_CH(hipMemsetAsync(b->acc_cells, 0, 16ull * b->acc_cells_count, b->stream));      // (kept zero between launches)
+    AOB_CH(hipMemsetAsync(b->horizon_counters, 0, sizeof(unsigned long long) * (8 + b->materials.size()), b->stream));
     std::shared_ptr<const std::vector<float>> table;                // (held until the stream has drained, below)
     if (b->hemisphere_entries) {
         table = hemisphere_table(b->hemisphere_entries);
@@ -706,6 +711,20 @@ int aob_bake_get_stats(AobBake* b, AobStats* stats)
     b->stats.surfel_count = surfels;
     b->stats.ray_count = surfels * (uint64_t)b->opt.sample_count;
     b->stats.ms_total_device = b->stats.ms_bvh_build + b->stats.ms_rasterize + b->stats.ms_trace + b->stats.ms_resolve;
+    // the samples the trace launches cast: all of them, less what the horizon tables resolved (launches since each material's last rasterisation)
+    b->stats.rays_cast = b->stats.ray_count;
+    {
+        uint64_t asked = 0;
+        for (auto& m : b->materials) asked += m.horizon_asked;
+        if (asked) {
+            std::vector<unsigned long long> c(8 + b->materials.size());
+            AOB_HIP(hipMemcpyAsync(c.data(), b->horizon_counters, sizeof(unsigned long long) * c.size(), hipMemcpyDeviceToHost, b->stream));
+            AOB_HIP(hipStreamSynchronize(b->stream));
+            uint64_t cast = 0;
+            for (size_t i = 0; i < b->materials.size(); i++) cast += c[8 + i];
+            b->stats.rays_cast = b->stats.ray_count > asked ? b->stats.ray_count - asked + cast : cast;
+        }
+    }
     *stats = b->stats;
     return AOB_OK;
 }
@@ -794,6 +813,29 @@ int aob_bake_copy_nodes4q(AobBake* b, AobBvh4QNode* dst, uint64_t capacity)
     if (capacity < n || (!dst && n)) { set_error("node4q buffer too small"); return AOB_ERR_INVALID_ARGUMENT; }
     if (n) AOB_HIP(hipMemcpyAsync(dst, b->nodes4q, sizeof(AobBvh4QNode) * n, hipMemcpyDeviceToHost, b->stream));
     AOB_HIP(hipStreamSynchronize(b->stream));
+    return AOB_OK;
+}
+
+int aob_bake_copy_horizon(AobBake* b, int32_t material, uint8_t* dst, uint64_t capacity_bytes, uint32_t* stride, uint64_t* surfels)
+{
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, material, true));
+    DeviceMaterial& m = b->materials[material];
+    if (!stride || !surfels) { set_error("stride / surfels is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
+    *stride = 0; *surfels = 0;
+    if (!m.horizon || b->stats.trace_horizon != 1u || m.surfel_count == 0) return AOB_OK;
+    const uint32_t st = horizon_stride(b);
+    *stride = st; *surfels = m.surfel_count;
+    const uint64_t bytes = (uint64_t)st * m.surfel_count;
+    if (!dst || capacity_bytes < bytes) { set_error("horizon buffer too small (%llu bytes needed)", (unsigned long long)bytes); return AOB_ERR_INVALID_ARGUMENT; }
+    // the tables are kept in trace order; hand them out in the order of aob_bake_copy_surfels
+    std::vector<uint8_t> hz(bytes);
+    std::vector<uint32_t> perm(m.surfel_count);
+    AOB_HIP(hipMemcpyAsync(hz.data(), m.horizon, bytes, hipMemcpyDeviceToHost, b->stream));
+    AOB_HIP(hipMemcpyAsync(perm.data(), m.perm, sizeof(uint32_t) * m.surfel_count, hipMemcpyDeviceToHost, b->stream));
+    AOB_HIP(hipStreamSynchronize(b->stream));
+    for (size_t si = 0; si + 1 < m.section_offsets.size(); si++)
+        for (uint64_t j = m.section_offsets[si]; j < m.section_offsets[si + 1]; j++)
+            memcpy(dst + (m.section_offsets[si] + perm[j]) * st, hz.data() + j * st, st);
     return AOB_OK;
 }
 

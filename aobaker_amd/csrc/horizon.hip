@@ -1,0 +1,82 @@
+// horizon.hip — per-surfel HORIZON TABLES: which strata of the COSINE sampler's grid cannot hold an occluded ray (gfx950).
+//
+// The COSINE sampler (aob_math.h cosine_sample_cell) is stratified: sample i = (cx, cy) of an sx x sy grid draws u1 in
+// [cx/sx, (cx+1)/sx) — u1 = sin^2(angle to the normal) — and u2 in [cy/sy, (cy+1)/sy) — the azimuth in the surfel's tangent frame
+// (GenerateRaysComputeShader.hlsl:34-46).  A hit point p of such a ray lies at P + s d with s >= ray_bias, so in the frame's (dual)
+// coordinates (alpha, beta, gamma) of p - P the azimuth is atan2(gamma, alpha) = 2 pi u2 and beta / rho = sqrt((1 - u1) / u1): a piece of
+// geometry that stays below beta_max and beyond rho_min as seen from P can only be hit by rays with u1 >= rho_min^2 / (rho_min^2 +
+// beta_max^2), inside the arc of azimuths it spans.  k_horizon turns that into a table per surfel — for every azimuth row cy the number of
+// leading columns cx that NO geometry of the scene reaches — and k_trace (trace.hip) does not generate the samples of those cells: they
+// are unoccluded whatever their jitter, and score as the oracle's rays would have.  The table is an accelerator like the tile cuts: it
+// moves work and never changes a result cell; every bound below is conservative with margins far above the rounding involved
+// (kMarginU, kMarginPhi, kMarginF), and the parity suite bakes with it by default.
+//
+// One wavefront per tile of 64 surfels (the trace order's 8x8-texel tiles), three phases:
+//   A  lane = child box: a walk of the quantised 4-ary tree from the tile (depth first, the children of 16 nodes per round).  A box nearer
+//      than r_near is opened down to its triangles (the NEAR list).  Every other box is measured against the tile in the tile's own frame
+//      (pole = the surfels' mean normal): its top — the largest sin(elevation) any point of it can have over any origin of the tile, the box
+//      grown by the tile's extent — and its arc of azimuths.  H[32] is the tile's horizon: the sin(elevation) below which a direction may be
+//      blocked for SOME origin of the tile.  A box wholly under H is dropped (what it could block is blocked already); a leaf in the middle
+//      distance is measured exactly (its vertices against the boxes of 16 groups of four origins) and raises H; a small box or a far leaf
+//      raises H by its own top; anything else is opened.
+//   B  lane = surfel: the near triangles against each surfel's own tangent frame, into its local table (LDS).
+//   C  lane = surfel: the boundary of {sin E <= H[az]} as a closed polyline of great-circle arcs (a latitude's chord lies poleward of it:
+//      southern latitudes are raised so that the chord stays above), each arc into the local table: from a blocked direction the way to
+//      the surfel's pole along its meridian leaves the blocked set through that boundary, inside the same azimuth row.
+// The prototypes that chose this shape: tools/horizon_proto2.py (numpy, the oracle's rays as the check), profiles/r06/horizon/.
+#include "aob_internal.h"
+#include "horizon_kernel.h"
+
+namespace aob {
+
+// ---- host ----
+
+bool horizon_applies(const AobBake* b)
+{
+    const AobOptions& o = b->opt;
+    if (o.trace_horizon == 1 || o.sampler != AOB_SAMPLER_COSINE || !o.bvh_quantised || o.bvh_width != 4) return false;
+    CosineGrid g;
+    cosine_grid(o.sample_count, g);
+    return g.sx >= 4 && g.sy >= 4 && g.sx <= 32 && g.sy <= 32 && g.sx * g.sy == o.sample_count;      // (a grid with unstratified samples beyond it keeps them all)
+}
+
+uint32_t horizon_stride(const AobBake* b)
+{
+    CosineGrid g;
+    cosine_grid(b->opt.sample_count, g);
+    return g.sy <= 16 ? 16u : 32u;
+}
+
+// The tables of the surfels [begin, end) of a material (a trace launch's range), into m.horizon.  false: no memory — the launch traces every sample.
+bool horizon_build(AobBake* b, DeviceMaterial& m, uint64_t begin, uint64_t end, float tmax)
+{
+    const AobOptions& o = b->opt;
+    const uint32_t stride = horizon_stride(b);
+    const uint64_t bytes = (uint64_t)stride * m.surfel_count;
+    if (bytes > m.horizon_capacity) {
+        (void)hipStreamSynchronize(b->stream);
+        if (m.horizon) hipFree(m.horizon);
+        m.horizon = nullptr; m.horizon_capacity = 0;
+        const uint64_t want = (uint64_t)stride * (m.surfel_capacity > m.surfel_count ? m.surfel_capacity : m.surfel_count);
+        if (hipMalloc((void**)&m.horizon, want) != hipSuccess) { (void)hipGetLastError(); m.horizon = nullptr; return false; }
+        m.horizon_capacity = want;
+    }
+    HorizonParams p;
+    std::memset(&p, 0, sizeof p);
+    CosineGrid g;
+    cosine_grid(o.sample_count, g);
+    p.frames = m.frames; p.begin = begin; p.end = end;
+    p.nodes4q = b->nodes4q; p.leaf_tris = b->leaf_tris; p.quant_frame = b->quant_frame; p.node_count = (uint32_t)b->node_count;
+    p.K = g.sy; p.C = g.sx;
+    p.bias = o.ray_bias > 0.0f ? o.ray_bias : 0.0f;
+    p.reach = tmax < 1e30f ? (tmax + fabsf(o.ray_bias)) * 1.01f : INFINITY;
+    p.near_factor = 0.5f; p.mid_factor = 4.0f; p.small2 = 0.08f * 0.08f;
+    p.out = m.horizon; p.stride = stride;
+    p.counters = b->horizon_counters;
+    const uint32_t tiles = (uint32_t)((end - begin + kHzWave - 1) / kHzWave);
+    if (g.sx <= 16) hipLaunchKernelGGL(k_horizon<16>, dim3(tiles), dim3(kHzWave), 0, b->stream, p);
+    else hipLaunchKernelGGL(k_horizon<32>, dim3(tiles), dim3(kHzWave), 0, b->stream, p);
+    return hipGetLastError() == hipSuccess;
+}
+
+} // namespace aob

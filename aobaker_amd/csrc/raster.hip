@@ -551,6 +551,9 @@ int rasterize_material(AobBake* b, int32_t material, int32_t row_begin, int32_t 
     // the tile cuts of this material's trace launches, sized by what was covered (a strip of rows: a strip's worth) — here, so that no trace
     // launch carries an allocation; without the memory the launches walk from the root and the bake says so (trace.hip ensure_tile_cuts)
     b->stats.trace_cuts = 0u;
+    b->stats.trace_horizon = 0u;
+    m.horizon_asked = 0;
+    (void)hipMemsetAsync(b->horizon_counters + 8 + material, 0, sizeof(unsigned long long), b->stream);
     reserve_tile_cuts(b, material);
     return AOB_OK;
 }

@@ -145,6 +145,9 @@ struct TraceParams {
     uint32_t scalar_min;           // lanes on one node that make a scalar step (refill section) worth its pass
     const uint32_t* tile_cuts;     // CUT: kCutWords words per tile of [begin, end) (k_tile_cuts), or null
     uint32_t cut_records;          // CUT: records per tile — one per sample part (coarse parts first, then the fine ones), or 1
+    const uint32_t* horizon;       // COSINE sampler, QUANT 2: the surfels' horizon tables (horizon.hip: free columns of every azimuth row, a byte each), or null
+    uint32_t horizon_words;        // ... words per surfel (4 or 8)
+    unsigned long long* cast_total;   // ... the samples the launch generated (a sum per wavefront, added when it ends)
 };
 
 // ---- tile cuts (CUT mode of k_trace) ----
@@ -514,6 +517,7 @@ void k_trace(TraceParams p)
     // run at the same time and share their nodes in L2 (four parts: 54 % fewer bytes from HBM than one).
     const uint32_t home = blockIdx.x & 7u;             // workgroups are dealt round-robin over the XCDs: this one's
     uint32_t tried = 0;                                // queues found dry, starting with the home queue
+    uint32_t cast_acc = 0;                             // wave-uniform: samples this wavefront generated (horizon tables: fewer than it was given)
   for (;;) {
     uint32_t xcd, rank;
     for (;;) {
@@ -522,8 +526,9 @@ void k_trace(TraceParams p)
         if (lane == 0) r = atomicAdd(&p.unit_next[xcd], 1u);
         rank = __builtin_amdgcn_readfirstlane(r);
         if (rank < p.units_per_xcd) break;
-        if (++tried == 8u) return;
+        if (++tried == 8u) break;
     }
+    if (tried == 8u) break;                            // every queue is dry
     const bool fine = rank >= p.coarse_units;
     const uint32_t nparts = fine ? p.parts_fine : p.parts;
     const uint32_t part = fine ? (rank - p.coarse_units) % p.parts_fine : rank % p.parts;
@@ -586,6 +591,46 @@ void k_trace(TraceParams p)
     const int32_t gen_first = GEN_DOWN && gen_end > gen_begin ? gen_end - 1 : gen_begin;
     int32_t gen_cy = gen_first / p.grid.sx, gen_cx = gen_first - gen_cy * p.grid.sx;     // the next sample's cell of the COSINE sampler's grid
     uint32_t q_head = 0, q_count = 0;                   // wave-uniform: the queue is a ring of 64 rays
+    // ---- horizon tables (horizon.hip) ----
+    // The unit's samples are whole rows cy0 .. cy0 + rows - 1 of the sampler's grid (trace_range makes sure: at most four, inside one word of the
+    // table); byte r of a surfel's word is the number of leading cells of row cy0 + r that no triangle of the scene reaches: those samples are
+    // unoccluded whatever their jitter and are NOT cast — they go into the sums in the epilogue.  What is left of the rows is a list per surfel,
+    // and pass j of the generator makes entry j of every list that has one: row after row, each from its last cell (the most grazing) down to
+    // the first blocked one.  The word is fetched again in every pass (L1) rather than held across the walk: this kernel lives at the register cap.
+    constexpr bool HZ = SAMPLER == AOB_SAMPLER_COSINE && QUANT == 2;
+    const bool hz_on = HZ && p.horizon != nullptr;
+    const uint32_t hz_cy0 = (uint32_t)gen_begin / (uint32_t)p.grid.sx;
+    const uint32_t hz_rows = (uint32_t)(gen_end - gen_begin) / (uint32_t)p.grid.sx;
+    // a surfel's row word -> the rows' remaining cells, cumulated: byte r = cells cast in rows 0 .. r (byte 3: the list's length)
+    // (a raw buffer: the table's base in scalar registers, the unit's first word as the scalar offset, the lane's as the vector offset — made where it
+    // is used, behind an empty asm, so that no per-lane address is kept, and spilt, across the walk)
+    const __amdgpu_buffer_rsrc_t hz_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.horizon, 0, 0xffffffff, 0x00020000);
+    const uint32_t hz_unit = (uint32_t)(wave_first * (uint64_t)p.horizon_words + (hz_cy0 >> 2)) * 4u;
+    auto hz_cum = [&](uint32_t& skipped) -> uint32_t {
+        uint32_t lo = lane;
+        asm volatile("" : "+v"(lo));
+        uint32_t w = __builtin_amdgcn_raw_buffer_load_b32(hz_rsrc, lo * (p.horizon_words * 4u), hz_unit, 0) >> ((hz_cy0 & 3u) << 3);
+        const uint32_t sx = (uint32_t)p.grid.sx;
+        uint32_t cum = 0u, run = 0u;
+        skipped = 0u;
+#pragma unroll
+        for (uint32_t r = 0; r < 4u; r++) {
+            const uint32_t f = r < hz_rows ? min((w >> (8u * r)) & 0xffu, sx) : sx;
+            if (r < hz_rows) skipped += f;
+            run += sx - f;
+            cum |= run << (8u * r);
+        }
+        return cum;
+    };
+    int32_t hz_passes = 0;
+    if (hz_on) {
+        uint32_t sk;
+        int32_t len = valid ? (int32_t)(hz_cum(sk) >> 24) : 0;
+        for (int off = 32; off > 0; off >>= 1) len = max(len, __shfl_xor(len, off));
+        hz_passes = __builtin_amdgcn_readfirstlane(len);
+    }
+    // (the generator's pass counter runs over [gen_begin, gen_pass_end): the unit's samples, or the passes its longest list takes)
+    const int32_t gen_pass_end = hz_on ? gen_begin + hz_passes : gen_end;
 
     // ---- the ray a lane is tracing ----
     f3 org, dir, invdir, oxinvdir;
@@ -735,7 +780,7 @@ void k_trace(TraceParams p)
 
     for (;;) {
         const uint64_t active_m = __ballot(addr != kIdle);
-        const bool more = q_count != 0u || gen_next < gen_end;
+        const bool more = q_count != 0u || gen_next < gen_pass_end;
         if (active_m == 0ull && !more) break;
         AOB_STAT(0, 1);
 
@@ -812,15 +857,34 @@ void k_trace(TraceParams p)
                     q_count -= taken;
                 }
                 // rays left in the queue: every idle lane was served
-                if (pass == 1 || q_count != 0u || gen_next >= gen_end) break;
+                if (pass == 1 || q_count != 0u || gen_next >= gen_pass_end) break;
                 // the queue is empty: sample gen_next of all 64 surfels, one per lane
-                const int32_t i = GEN_DOWN ? gen_end - 1 - (gen_next - gen_begin) : gen_next;
+                int32_t i = GEN_DOWN ? gen_end - 1 - (gen_next - gen_begin) : gen_next;
+                int32_t cell_x = gen_cx, cell_y = gen_cy;
+                bool make = valid;
+                if (hz_on) {
+                    // entry j of this surfel's list: the row the cumulated counts put it in, that row's cells from the last one down
+                    const uint32_t j = (uint32_t)(gen_next - gen_begin);
+                    uint32_t sk;
+                    const uint32_t cum = valid ? hz_cum(sk) : 0u;
+                    make = j < (cum >> 24);
+                    const uint32_t c0 = cum & 0xffu, c1 = (cum >> 8) & 0xffu, c2 = (cum >> 16) & 0xffu;
+                    const uint32_t r = (j >= c0 ? 1u : 0u) + (j >= c1 ? 1u : 0u) + (j >= c2 ? 1u : 0u);
+                    const uint32_t before = r == 0u ? 0u : (r == 1u ? c0 : (r == 2u ? c1 : c2));
+                    cell_y = (int32_t)(hz_cy0 + r);
+                    cell_x = p.grid.sx - 1 - (int32_t)(j - before);
+                    i = cell_y * p.grid.sx + cell_x;
+                }
                 gen_next++;
                 AOB_STAT(7, 1);
-                const int32_t cell_x = gen_cx, cell_y = gen_cy;
                 if (GEN_DOWN) { if (gen_cx-- == 0) { gen_cx = p.grid.sx - 1; gen_cy--; } }
                 else if (++gen_cx == p.grid.sx) { gen_cx = 0; gen_cy++; }
-                if (valid) {
+                const uint64_t make_m = hz_on ? __ballot(make) : valid_m;
+                if (HZ) cast_acc += (uint32_t)__popcll(make_m);
+                // (the cut's planes are fetched by scalar loads: their address is made here, where control flow is wave-uniform)
+                const uint32_t* cut_planes = cut_on ? tile_cut + kCutMax : nullptr;
+                asm volatile("" : "+s"(cut_planes));
+                if (make) {
                     const float4* fr = p.frames + 4ull * (wave_first + lane);
                     const float4 a = fr[0], b = fr[1], c = fr[2];
                     const f3 N = make_f3(a.w, b.x, b.y), X = make_f3(b.z, b.w, c.x), Z = make_f3(c.y, c.z, c.w);
@@ -835,7 +899,7 @@ void k_trace(TraceParams p)
                                          fmaf(h.z, Z.y, fmaf(h.y, N.y, h.x * X.y)),
                                          fmaf(h.z, Z.z, fmaf(h.y, N.z, h.x * X.z)));                       // GenerateRays:46
                     const float gw = SAMPLER == AOB_SAMPLER_REFERENCE_COMPAT ? dot(N, d) : 1.0f;
-                    const uint32_t pos = (q_head + __builtin_amdgcn_mbcnt_hi((uint32_t)(valid_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)valid_m, 0u))) & (kWave - 1u);
+                    const uint32_t pos = (q_head + __builtin_amdgcn_mbcnt_hi((uint32_t)(make_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)make_m, 0u))) & (kWave - 1u);
                     const f3 gi = make_f3(safe_inv1(d.x), safe_inv1(d.y), safe_inv1(d.z));
                     queue[pos * 2] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), lane);
                     uint32_t entry_mask = 0u;
@@ -864,7 +928,7 @@ void k_trace(TraceParams p)
                             // four entries per pass (the list is padded to a multiple of four with empty slots, which no ray enters), the
                             // next four fetched (scalar loads) while these are tested; the fetch past the list's end reads the next record
                             typedef const __attribute__((address_space(4))) uint32_t* const_words;
-                            const uint32_t* eg = tile_cut + kCutMax;
+                            const uint32_t* eg = cut_planes;
                             asm volatile("" : "+s"(eg));
                             const_words ew = (const_words)eg;
                             uint32_t w0 = ew[0], w1 = ew[1], w2 = ew[2], w3 = ew[3], w4 = ew[4], w5 = ew[5], w6 = ew[6], w7 = ew[7], w8 = ew[8], w9 = ew[9], w10 = ew[10], w11 = ew[11];
@@ -884,7 +948,7 @@ void k_trace(TraceParams p)
                     queue[pos * 2 + 1] = make_uint4(__float_as_uint(gi.x), __float_as_uint(gi.y), __float_as_uint(gi.z),
                                                     cut_on ? entry_mask : __float_as_uint(gw));
                 }
-                q_count = n_valid;
+                q_count = hz_on ? (uint32_t)__popcll(make_m) : n_valid;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the queue writes land before other lanes read them
                 __builtin_amdgcn_wave_barrier();
             }
@@ -1156,7 +1220,9 @@ void k_trace(TraceParams p)
     // hit: misses and samples counted), or — fractions — to 64-bit accumulators that are rounded once after the launch.
     if (valid) {
         const float4 d = p.frames[4ull * (wave_first + lane) + 3];
-        const long long sT = COUNT32 ? (long long)(CUT ? (miss_count[lane >> 1] >> ((lane & 1u) << 4)) & 0xffffu : miss_count[lane]) * kUnit : (long long)acc[lane][0];
+        long long sT = COUNT32 ? (long long)(CUT ? (miss_count[lane >> 1] >> ((lane & 1u) << 4)) & 0xffffu : miss_count[lane]) * kUnit : (long long)acc[lane][0];
+        // (the samples the horizon table resolved: unoccluded, weight 1 — what finish() adds for a ray that ends without a hit)
+        if (hz_on) { uint32_t sk; (void)hz_cum(sk); sT += (long long)sk * kUnit; }
         const long long sW = UNITW ? (long long)(gen_end - gen_begin) * kUnit : (long long)acc[lane][TOTAL_ONLY ? 0 : 1];
         AobResult* cell = p.results + __float_as_uint(d.x);
         if (p.parts > 1u) {
@@ -1188,6 +1254,7 @@ void k_trace(TraceParams p)
         }
     }
   }   // next unit
+    if (SAMPLER == AOB_SAMPLER_COSINE && QUANT == 2 && p.cast_total && lane == 0) atomicAdd(p.cast_total, (unsigned long long)cast_acc);
 }
 
 // After a launch whose parts met in acc_cells: every surfel of the launch owns one cell (sections in one launch share no texel);
@@ -1518,6 +1585,24 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
                     m.tile_cut_tiles = p.ntiles; m.tile_cut_records = p.cut_records;
                     if (b->stats.trace_cuts != 2u) b->stats.trace_cuts = 1u;
                 } else p.cut_records = 1u;
+            }
+            // ---- horizon tables (horizon.hip): where the unit's samples are whole rows of the sampler's grid, at most four of them in one word of the table ----
+            p.horizon = nullptr; p.horizon_words = 0u; p.cast_total = nullptr;
+            if (horizon_applies(b) && quant == 2 && b->node_count > 0) {
+                const uint32_t per = (uint32_t)o.sample_count / p.parts, sx = (uint32_t)p.grid.sx;
+                const uint32_t rows = per / sx;
+                const bool whole = per * p.parts == (uint32_t)o.sample_count && rows * sx == per && (rows == 1u || rows == 2u || rows == 4u) && !(fine_tiles && rows == 1u);
+                if (whole) {
+                    if (horizon_build(b, m, sb, se, p.tmax)) {
+                        p.horizon = (const uint32_t*)m.horizon; p.horizon_words = horizon_stride(b) / 4u;
+                        p.cast_total = b->horizon_counters + 8 + material;
+                        m.horizon_asked += (se - sb) * (uint64_t)o.sample_count;
+                        if (b->stats.trace_horizon != 2u) b->stats.trace_horizon = 1u;
+                    } else {
+                        b->stats.trace_horizon = 2u;
+                        set_error("warning: the horizon tables of a %dx%d material could not be allocated: every sample is cast (same results, slower; AobStats::trace_horizon = 2)", m.width, m.height);
+                    }
+                }
             }
             // the HBM overflow stack (reserved when the tree was built; a launch whose schedule or mode was set later re-sizes it here)
             const uint32_t overflow = stack_overflow_entries(b, p.tile_cuts != nullptr);

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AOB_ABI_VERSION 6
+#define AOB_ABI_VERSION 7
 #define AOB_BVH_BUILDER_AUTO (-1)
 
 typedef enum AobStatus {
@@ -137,6 +137,13 @@ typedef struct AobOptions {
                                      it moves work and never changes a result cell.  The cuts take 512 B per tile and record of device
                                      memory (up to 96 B per covered texel), allocated when a material is rasterised; a bake that cannot
                                      have them walks from the root and says so (AobStats::trace_cuts).  (ABI 5)                        */
+    int32_t  trace_horizon;       /* COSINE sampler on a full sx x sy grid (sample_count = sx * sy, both 4..32), quantised 4-ary nodes: every surfel
+                                     gets a HORIZON TABLE — for each azimuth row of the sampler's grid the number of leading columns (the
+                                     directions nearest the normal) that no triangle of the scene can reach, proven from the tree with
+                                     conservative bounds (horizon.hip) — and the trace kernel does not cast the samples of those cells: they are
+                                     unoccluded whatever their jitter and score as cast rays would.  0 (default): on where it applies, 1: off.
+                                     Moves work, never changes a result cell.  16 or 32 bytes per covered texel of device memory; a bake that
+                                     cannot have them casts every sample and says so (AobStats::trace_horizon = 2).  (ABI 7)              */
 } AobOptions;
 
 /* ---- scene description ----------------------------------------------------
@@ -220,6 +227,11 @@ typedef struct AobStats {
     float ms_download;
     float ms_total_device;        /* bvh_build + rasterize + trace + resolve */
     float reserved1;
+    uint64_t rays_cast;           /* of ray_count, the samples the trace kernels generated and walked; the rest were resolved by the surfels' horizon
+                                     tables (AobOptions::trace_horizon) as unoccluded without being cast.  ray_count where no launch had tables (ABI 7) */
+    uint32_t trace_horizon;       /* the trace launches since the last rasterisation — 0: no horizon tables (off, or a mode they do not apply to);
+                                     1: had them; 2: at least one wanted them and could not allocate them (same cells, every sample cast)   */
+    uint32_t reserved2;
 } AobStats;
 
 /* ---- device records (layouts shared with the parity tests) ---------------- */
@@ -376,6 +388,11 @@ int aob_bake_copy_nodes4q(AobBake* bake, AobBvh4QNode* dst, uint64_t capacity);
  * 0x8000ffff) after.  One record per tile, or one per sample part (the coarse parts, then the fine ones) holding the entries that
  * part's rays can reach.  *tiles = 0 if the launch used no cuts.  For the parity tests (the oracle's orc_tile_cut). */
 int aob_bake_copy_tile_cuts(AobBake* bake, int32_t material, uint32_t* dst, uint64_t capacity_words, uint32_t* tiles, uint32_t* records_per_tile);
+/* The horizon tables the material's most recent trace launches used (AobOptions::trace_horizon; horizon.hip): `*stride` bytes per surfel, in the
+ * order of aob_bake_copy_surfels; byte cy = the number of leading cells of row cy of the COSINE sampler's grid whose samples were not cast
+ * (no triangle of the scene can be reached through them).  *surfels = 0 if the launches had no tables.  For the tests: every ray of such a
+ * cell must be unoccluded for the oracle. */
+int aob_bake_copy_horizon(AobBake* bake, int32_t material, uint8_t* dst, uint64_t capacity_bytes, uint32_t* stride, uint64_t* surfels);
 int aob_bake_surfel_count(AobBake* bake, int32_t material, uint64_t* count);
 int aob_bake_copy_surfels(AobBake* bake, int32_t material, AobSurfel* dst, uint64_t capacity);
 int aob_bake_copy_results(AobBake* bake, int32_t material, AobResult* dst, uint64_t capacity);

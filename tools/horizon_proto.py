@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""tools/horizon_proto.py (a measurement script, not a test, not product code) — prototype of the HIERARCHICAL horizon-table build that k_horizon
+runs per tile (lane = surfel, wave-uniform best-first walk of the 4-ary tree), in numpy: the share of rays it culls, the boxes and triangles it
+touches per tile, the generation occupancy the culled lists leave, and the check that no culled ray is occluded for the oracle.
+
+  python tools/horizon_proto.py [--tiles 8] [--thr 0.08] [--tri exact|cheap]
+"""
+import argparse
+import heapq
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+MU, MPHI = 2e-3, 1e-3
+
+
+def frames_of(sub):
+    P = sub["position"].astype(np.float64)
+    N = sub["normal"].astype(np.float64)
+    X = np.zeros_like(N); Z = np.zeros_like(N)
+    for i in range(len(N)):
+        n = N[i]
+        if -0.9999 < n[1] < 0.9999:
+            x = np.array([-n[2], 0.0, n[0]]); x /= np.linalg.norm(x)
+            z = np.cross(x, n); z /= np.linalg.norm(z)
+        else:
+            x, z = np.array([1.0, 0, 0]), np.array([0, 0, 1.0])
+        X[i], Z[i] = x, z
+    det = np.einsum("ij,ij->i", X, np.cross(N, Z))
+    Xd = np.cross(N, Z) / det[:, None]
+    Nd = np.cross(Z, X) / det[:, None]
+    Zd = np.cross(X, N) / det[:, None]
+    return P, Xd, Nd, Zd
+
+
+def sector_mask(theta, alpha, full, K):
+    lo = np.floor((theta - alpha - MPHI) * K).astype(np.int64)
+    hi = np.floor((theta + alpha + MPHI) * K).astype(np.int64)
+    cnt = np.minimum(hi - lo + 1, K)
+    cnt = np.where(full, K, cnt)
+    base = ((1 << cnt) - 1).astype(np.uint64)
+    sh = (lo % K).astype(np.uint64)
+    m = ((base << sh) | (base >> (np.uint64(K) - sh))) & np.uint64((1 << K) - 1)
+    return np.where(cnt >= K, np.uint64((1 << K) - 1), m)
+
+
+class Tile:
+    def __init__(self, sub, K, C, bias, reach):
+        self.P, self.Xd, self.Nd, self.Zd = frames_of(sub)
+        self.aX, self.aN, self.aZ = np.abs(self.Xd), np.abs(self.Nd), np.abs(self.Zd)
+        self.K, self.C, self.bias, self.reach = K, C, bias, reach
+        self.blocked = np.zeros((64, C + 1), dtype=np.uint64)          # cumulative: blocked[:, c] = sectors blocked at column c
+        self.lo, self.hi = self.P.min(0), self.P.max(0)
+        self.st = dict(box_tests=0, terminal_boxes=0, tris=0, pops=0, tri_updates=0)
+
+    def box(self, lo, hi):
+        """per-lane footprint of a box: (relevant, c0, M, ang2)"""
+        c, e = 0.5 * (lo + hi), 0.5 * (hi - lo)
+        v = c - self.P
+        a, b, g = (v * self.Xd).sum(1), (v * self.Nd).sum(1), (v * self.Zd).sum(1)
+        rX, rN, rZ = self.aX @ e, self.aN @ e, self.aZ @ e
+        ymax = b + rN
+        rx, rz = np.maximum(np.abs(a) - rX, 0), np.maximum(np.abs(g) - rZ, 0)
+        rho2 = rx * rx + rz * rz
+        u = np.where(ymax > 0, rho2 / np.maximum(rho2 + ymax * ymax, 1e-300), 1.0) - MU
+        c0 = np.clip(np.floor(u * self.C), 0, self.C).astype(np.int64)
+        R = np.sqrt(rX * rX + rZ * rZ)
+        rc = np.sqrt(a * a + g * g)
+        full = rc <= R
+        theta = np.arctan2(g, a) / (2 * np.pi)
+        alpha = np.arcsin(np.minimum(1.0, R / np.maximum(rc, 1e-300))) / (2 * np.pi)
+        M = sector_mask(theta, alpha, full, self.K)
+        # reach: nearest point of the box (world distance, conservative through the world box)
+        dmin = np.sqrt((np.maximum(np.maximum(lo - self.P, self.P - hi), 0) ** 2).sum(1))
+        rel = (ymax > 0) & (c0 < self.C) & (dmin <= self.reach)
+        new = M & ~self.blocked[np.arange(64), np.minimum(c0, self.C)]
+        rel &= new != 0
+        ang2 = (e * e).sum() / np.maximum((v * v).sum(1), 1e-300)
+        return rel, c0, M, ang2, (ymax > 0) & (c0 < self.C) & (dmin <= self.reach), u
+
+    def apply(self, who, c0, M):
+        for s in np.nonzero(who)[0]:
+            self.blocked[s, c0[s]:] |= M[s]
+
+    def tri(self, V, mode):
+        self.st["tris"] += 1
+        v = V[None, :, :] - self.P[:, None, :]                     # [64, 3, 3]
+        al = np.einsum("svk,sk->sv", v, self.Xd); be = np.einsum("svk,sk->sv", v, self.Nd); ga = np.einsum("svk,sk->sv", v, self.Zd)
+        bmax = be.max(1)
+        if mode == "exact":
+            def cr(i, j):
+                return al[:, i] * ga[:, j] - ga[:, i] * al[:, j]
+            c0_, c1_, c2_ = cr(0, 1), cr(1, 2), cr(2, 0)
+            inside = ((c0_ >= 0) & (c1_ >= 0) & (c2_ >= 0)) | ((c0_ <= 0) & (c1_ <= 0) & (c2_ <= 0))
+            def sd(i, j):
+                ax, az, bx, bz = al[:, i], ga[:, i], al[:, j], ga[:, j]
+                dx, dz = bx - ax, bz - az
+                l2 = dx * dx + dz * dz
+                t = np.clip(np.where(l2 > 0, -(ax * dx + az * dz) / np.where(l2 > 0, l2, 1.0), 0.0), 0, 1)
+                return (ax + t * dx) ** 2 + (az + t * dz) ** 2
+            d2 = np.where(inside, 0.0, np.minimum(np.minimum(sd(0, 1), sd(1, 2)), sd(2, 0)))
+            th = np.arctan2(ga, al) / (2 * np.pi)
+            rel_ = (th - th[:, :1] + 0.5) % 1.0 - 0.5
+            lo = th[:, 0] + rel_.min(1); hi = th[:, 0] + rel_.max(1)
+            full = inside | ((hi - lo) >= 0.5)
+            theta, alpha = 0.5 * (lo + hi), 0.5 * (hi - lo)
+        else:
+            # cheap: the projected triangle's bounding circle about its centroid (azimuths) and its 2D box (distance)
+            ca, cg = al.mean(1), ga.mean(1)
+            R = np.sqrt(((al - ca[:, None]) ** 2 + (ga - cg[:, None]) ** 2).max(1))
+            rc = np.sqrt(ca * ca + cg * cg)
+            full = rc <= R
+            theta = np.arctan2(cg, ca) / (2 * np.pi)
+            alpha = np.arcsin(np.minimum(1.0, R / np.maximum(rc, 1e-300))) / (2 * np.pi)
+            gx = np.maximum(np.maximum(al.min(1), -al.max(1)), 0); gz = np.maximum(np.maximum(ga.min(1), -ga.max(1)), 0)
+            d2 = np.maximum(gx * gx + gz * gz, np.maximum(rc - R, 0) ** 2)
+        bm = np.maximum(bmax, 0)
+        ua = d2 / np.maximum(d2 + bm * bm, 1e-300)
+        ub = 1.0 - np.minimum(1.0, bm / self.bias) ** 2
+        u = np.maximum(ua, ub) - MU
+        c0 = np.clip(np.floor(u * self.C), 0, self.C).astype(np.int64)
+        M = sector_mask(theta, alpha, full, self.K)
+        dmin = np.sqrt((v * v).sum(2).min(1))          # (a vertex: not a bound on the nearest point, good enough for the prototype's reach = inf)
+        who = (bmax > 0) & (c0 < self.C)
+        if np.isfinite(self.reach):
+            who &= dmin <= self.reach + 1.0
+        self.st["tri_updates"] += int(who.any())
+        self.apply(who, c0, M)
+
+
+def build_tile(tile, n4, lt, thr2, tri_mode, budget, prio="dist"):
+    heap = [(0.0, 0)]
+    while heap:
+        _, node = heapq.heappop(heap)
+        tile.st["pops"] += 1
+        nd = n4[node]
+        for j in range(4):
+            ref = int(nd["lo"][j][3].view(np.uint32))
+            if ref == 0xffffffff:
+                continue
+            lo, hi = nd["lo"][j][:3].astype(np.float64), nd["hi"][j][:3].astype(np.float64)
+            if (lo > hi).any():
+                continue
+            tile.st["box_tests"] += 1
+            rel, c0, M, ang2, could, u_ = tile.box(lo, hi)
+            if not rel.any():
+                continue
+            if ref & 0x80000000:
+                p = ref & 0x3fffffff
+                for q in range(2 if ref & 0x40000000 else 1):
+                    t = lt[p + q]
+                    tile.tri(np.stack([t["v0"][:3], t["v1"][:3], t["v2"][:3]]).astype(np.float64), tri_mode)
+                continue
+            over = tile.st["pops"] + len(heap) > budget
+            if (ang2[rel] <= thr2).all() or over:
+                tile.st["terminal_boxes"] += 1
+                tile.apply(could, c0, M)
+                continue
+            d = np.sqrt((np.maximum(np.maximum(lo - tile.hi, tile.lo - hi), 0) ** 2).sum())
+            if prio == "elev":
+                d = float(u_[rel].min())
+            heapq.heappush(heap, (d, ref))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tiles", type=int, default=8)
+    ap.add_argument("--atlas", type=int, default=2048)
+    ap.add_argument("--grid", type=int, default=708)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--thr", type=float, default=0.08)
+    ap.add_argument("--tri", default="exact")
+    ap.add_argument("--budget", type=int, default=100000)
+    ap.add_argument("--scene", default="terrain")
+    ap.add_argument("--prio", default="dist")
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+    from aobaker_amd import capi, scenes
+    from aobaker_amd.scene import FlatScene
+    from oracle import oracle as orc
+    atlas = args.atlas
+    flat = FlatScene(scenes.terrain_scene(grid=args.grid, atlas=atlas, seed=3))
+    opt = orc.default_options()
+    opt.sample_count, opt.sampler, opt.accumulate, opt.seed = args.spp, capi.SAMPLER_COSINE, capi.ACCUMULATE_FLOAT, 3
+    tris = orc.scene_triangles(flat.desc)
+    surfels, _ = orc.rasterize(flat.desc, 0, opt)
+    nodes2 = orc.bvh_build(tris, 2, 1)[0]
+    n4, lt = orc.bvh4_build(nodes2, pairs=True)
+    grid = surfels.reshape(atlas, atlas)
+    tw = atlas // 8
+    rng = np.random.default_rng(11)
+    picks = rng.choice(tw * tw, size=args.tiles, replace=False)
+    sx = int(np.floor(np.sqrt(args.spp))); sy = args.spp // sx
+    K, C = sy, sx
+    bias = float(opt.ray_bias)
+    tot = dict(rays=0, occluded=0, culled=0, wrong=0, box_tests=0, terminal_boxes=0, tris=0, pops=0, tri_updates=0, passes_lane=0, passes_uniform=0, survivors=0)
+    for t_ in picks:
+        sub = np.ascontiguousarray(grid[8 * (t_ // tw):8 * (t_ // tw) + 8, 8 * (t_ % tw):8 * (t_ % tw) + 8].reshape(-1))
+        rays = np.ascontiguousarray(orc.generate_rays(sub, None, opt, atlas))
+        occ = (orc.occluded_rays(nodes2, rays).reshape(64, args.spp) == 1)[:, :sx * sy].reshape(64, sy, sx)
+        tile = Tile(sub, K, C, bias, np.inf)
+        build_tile(tile, n4, lt, args.thr ** 2, args.tri, args.budget, args.prio)
+        # free[s, cy] = the first blocked column of sector cy
+        bl = tile.blocked[:, :C]                                       # [64, C]
+        bits = ((bl[:, :, None] >> np.arange(K, dtype=np.uint64)[None, None, :]) & np.uint64(1)).astype(bool)     # [64, C, K]
+        free = np.where(bits.any(1), bits.argmax(1), C)                # [64, K]
+        cx = np.arange(sx)
+        culled = cx[None, None, :] < free[:, :, None]                  # [64, sy, sx]
+        tot["rays"] += culled.size; tot["culled"] += int(culled.sum()); tot["occluded"] += int(occ.sum())
+        tot["wrong"] += int((culled & occ).sum())
+        for k, v in tile.st.items():
+            tot[k] += v
+        # generation occupancy for the 4 parts (rows 4p .. 4p+3)
+        rows = sy // 4
+        for p_ in range(4):
+            f = free[:, p_ * rows:(p_ + 1) * rows]                     # [64, rows]
+            n_s = (sx - f).sum(1)
+            tot["survivors"] += int(n_s.sum())
+            tot["passes_lane"] += int(n_s.max())
+            tot["passes_uniform"] += int((sx - f.min(0)).sum())
+    r = float(tot["rays"]); T = float(args.tiles)
+    rec = {"workload": f"terrain, {atlas}^2, {args.spp} spp, {args.tiles} tiles; K={K} sectors, C={C} columns; stop at angular radius {args.thr}; triangles: {args.tri}",
+           "occluded_share": round(tot["occluded"] / r, 4), "culled_share": round(tot["culled"] / r, 4), "culled_and_occluded": tot["wrong"],
+           "per_tile": {k: round(tot[k] / T, 1) for k in ("pops", "box_tests", "terminal_boxes", "tris", "tri_updates")},
+           "generation_occupancy": {"per-lane lists": round(tot["survivors"] / (64.0 * max(1, tot["passes_lane"])), 3),
+                                    "wave-uniform order": round(tot["survivors"] / (64.0 * max(1, tot["passes_uniform"])), 3)}}
+    text = json.dumps(rec, indent=1)
+    print(text)
+    if args.out:
+        os.makedirs(os.path.dirname(os.path.join(ROOT, args.out)), exist_ok=True)
+        with open(os.path.join(ROOT, args.out), "w") as f:
+            f.write(text + "\n")
+
+
+if __name__ == "__main__":
+    main()
