@@ -128,7 +128,7 @@ struct AobBake {
     bool      any_mesh_flags = false;
     int cu_count = 256;
     uint64_t gstack_words = 0;
-    unsigned long long* horizon_counters = nullptr;   // [8]: k_horizon's diagnostics [0..5], [6] the samples k_trace generated under horizon tables, [7] those it was asked for
+    unsigned long long* horizon_counters = nullptr;   // k_horizon's diagnostics [0..8] (rounds, box tests, near triangles, middle leaves, tiles given up, tiles, clock ticks of its three phases), then from [16] one word per material: the samples k_trace cast under horizon tables
     unsigned long long* acc_cells = nullptr;   // 2 x 64-bit exact sums per result cell of the largest material: where the sample parts of a tile
     uint64_t acc_cells_count = 0;              // add up when the cells are floats that hold fractions (trace.hip; sized at creation, kept zero)
 
@@ -160,7 +160,8 @@ int rasterize_material(AobBake* b, int32_t material, int32_t row_begin, int32_t 
 int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end);   // trace.hip
 void reserve_tile_cuts(AobBake* b, int32_t material);        // trace.hip: the tile cuts of the material's launches, sized by what was rasterised
 int reserve_trace_stack(AobBake* b);                         // trace.hip: the walk's HBM overflow stack, sized by the tree's depth
-bool horizon_applies(const AobBake* b);                      // horizon.hip: the options allow horizon tables (COSINE sampler on a full grid, quantised 4-ary nodes, trace_horizon != 1)
+bool horizon_applies(const AobOptions& o);                   // horizon.hip: the options ask for horizon tables (COSINE sampler on a full grid, quantised 4-ary nodes, trace_horizon)
+bool horizon_applies(const AobBake* b);
 uint32_t horizon_stride(const AobBake* b);                   // ... bytes per surfel
 bool horizon_build(AobBake* b, DeviceMaterial& m, uint64_t begin, uint64_t end, float tmax);   // ... the tables of a launch's surfels (false: no memory)
 int resolve_material(AobBake* b, int32_t material);          // resolve.hip

@@ -116,7 +116,7 @@ static int validate_options(const AobOptions* o)
     if (o->trace_parts < 0 || o->trace_parts > 64 || o->trace_part_min < 0 || o->trace_fine_div < 0) { set_error("trace_parts %d (0..64), trace_part_min %d, trace_fine_div %d: must not be negative", o->trace_parts, o->trace_part_min, o->trace_fine_div); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->trace_scalar_min < 0 || o->trace_scalar_min > 64) { set_error("trace_scalar_min %d: must be 0 (default) or 1..64", o->trace_scalar_min); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->trace_cut < 0 || o->trace_cut > 32 || o->trace_cut == 2 || o->trace_cut == 3) { set_error("trace_cut %d: must be 0 (default: 32 entries), 1 (off) or 4..32", o->trace_cut); return AOB_ERR_INVALID_ARGUMENT; }
-    if (o->trace_horizon < 0 || o->trace_horizon > 1) { set_error("trace_horizon %d: must be 0 (default: horizon tables where they apply) or 1 (off)", o->trace_horizon); return AOB_ERR_INVALID_ARGUMENT; }
+    if (o->trace_horizon < 0 || o->trace_horizon > 2) { set_error("trace_horizon %d: must be 0 (default: horizon tables from 128 samples per surfel on), 1 (off) or 2 (wherever they apply)", o->trace_horizon); return AOB_ERR_INVALID_ARGUMENT; }
     if (o->trace_bands < 0 || o->trace_bands > 2) { set_error("trace_bands %d: must be 0 (default), 1 or 2", o->trace_bands); return AOB_ERR_INVALID_ARGUMENT; }
     if (!(o->falloff_distance > 0.0f)) { set_error("falloff_distance must be positive"); return AOB_ERR_INVALID_ARGUMENT; }
     return AOB_OK;
@@ -392,7 +392,7 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
     // ---- plan: what every stage needs, sized once ----
     ArenaPlan plan;
     plan.want(&b->trace_unit_next, 8);
-    plan.want(&b->horizon_counters, 8 + scene->material_count);
+    plan.want(&b->horizon_counters, 16 + scene->material_count);
     b->meshes.resize(scene->mesh_count);
     uint64_t tri_total = 0;
     for (uint32_t i = 0; i < scene->mesh_count; i++) {
@@ -541,7 +541,7 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
     for (auto& d : b->materials)
         AOB_CH(hipMemsetAsync(d.results, 0, sizeof(AobResult) * (uint64_t)d.width * d.height, b->stream));
     if (b->acc_cells) AOB_CH(hipMemsetAsync(b->acc_cells, 0, 16ull * b->acc_cells_count, b->stream));      // (kept zero between launches)
-    AOB_CH(hipMemsetAsync(b->horizon_counters, 0, sizeof(unsigned long long) * (8 + b->materials.size()), b->stream));
+    AOB_CH(hipMemsetAsync(b->horizon_counters, 0, sizeof(unsigned long long) * (16 + b->materials.size()), b->stream));
     std::shared_ptr<const std::vector<float>> table;                // (held until the stream has drained, below)
     if (b->hemisphere_entries) {
         table = hemisphere_table(b->hemisphere_entries);
@@ -717,11 +717,11 @@ int aob_bake_get_stats(AobBake* b, AobStats* stats)
         uint64_t asked = 0;
         for (auto& m : b->materials) asked += m.horizon_asked;
         if (asked) {
-            std::vector<unsigned long long> c(8 + b->materials.size());
+            std::vector<unsigned long long> c(16 + b->materials.size());
             AOB_HIP(hipMemcpyAsync(c.data(), b->horizon_counters, sizeof(unsigned long long) * c.size(), hipMemcpyDeviceToHost, b->stream));
             AOB_HIP(hipStreamSynchronize(b->stream));
             uint64_t cast = 0;
-            for (size_t i = 0; i < b->materials.size(); i++) cast += c[8 + i];
+            for (size_t i = 0; i < b->materials.size(); i++) cast += c[16 + i];
             b->stats.rays_cast = b->stats.ray_count > asked ? b->stats.ray_count - asked + cast : cast;
         }
     }
@@ -812,6 +812,16 @@ int aob_bake_copy_nodes4q(AobBake* b, AobBvh4QNode* dst, uint64_t capacity)
     AOB_TRY(node4q_count(b, &n));
     if (capacity < n || (!dst && n)) { set_error("node4q buffer too small"); return AOB_ERR_INVALID_ARGUMENT; }
     if (n) AOB_HIP(hipMemcpyAsync(dst, b->nodes4q, sizeof(AobBvh4QNode) * n, hipMemcpyDeviceToHost, b->stream));
+    AOB_HIP(hipStreamSynchronize(b->stream));
+    return AOB_OK;
+}
+
+int aob_bake_horizon_counters(AobBake* b, unsigned long long* out16, int clear)
+{
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, 0, false));
+    if (!out16) { set_error("out is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
+    AOB_HIP(hipMemcpyAsync(out16, b->horizon_counters, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, b->stream));
+    if (clear) AOB_HIP(hipMemsetAsync(b->horizon_counters, 0, sizeof(unsigned long long) * 16, b->stream));
     AOB_HIP(hipStreamSynchronize(b->stream));
     return AOB_OK;
 }

@@ -23,7 +23,7 @@
 //   C  lane = surfel: the boundary of {sin E <= H[az]} as a closed polyline of great-circle arcs (a latitude's chord lies poleward of it:
 //      southern latitudes are raised so that the chord stays above), each arc into the local table: from a blocked direction the way to
 //      the surfel's pole along its meridian leaves the blocked set through that boundary, inside the same azimuth row.
-// The prototypes that chose this shape: tools/horizon_proto2.py (numpy, the oracle's rays as the check), profiles/r06/horizon/.
+// The prototypes that chose this shape: tools/measure_horizon_proto2.py (numpy, the oracle's rays as the check), profiles/r06/horizon/.
 #include "aob_internal.h"
 #include "horizon_kernel.h"
 
@@ -31,14 +31,18 @@ namespace aob {
 
 // ---- host ----
 
-bool horizon_applies(const AobBake* b)
+// The tables cost a fixed time per surfel (k_horizon: ~1.7 us per tile of 64 on the 1 M-triangle terrain) and save time per SAMPLE: measured on
+// MI355X, BASELINE configs[2] (256 spp) traces 6 % faster with them, the terrain with closest-hit scoring 11 %, configs[1] (64 spp) 39 % SLOWER
+// (profiles/r06/horizon/).  trace_horizon 0 — the default — therefore means: from 128 samples per surfel on.
+bool horizon_applies(const AobOptions& o)
 {
-    const AobOptions& o = b->opt;
     if (o.trace_horizon == 1 || o.sampler != AOB_SAMPLER_COSINE || !o.bvh_quantised || o.bvh_width != 4) return false;
+    if (o.trace_horizon == 0 && o.sample_count < 128) return false;
     CosineGrid g;
     cosine_grid(o.sample_count, g);
     return g.sx >= 4 && g.sy >= 4 && g.sx <= 32 && g.sy <= 32 && g.sx * g.sy == o.sample_count;      // (a grid with unstratified samples beyond it keeps them all)
 }
+bool horizon_applies(const AobBake* b) { return horizon_applies(b->opt); }
 
 uint32_t horizon_stride(const AobBake* b)
 {
@@ -70,12 +74,12 @@ bool horizon_build(AobBake* b, DeviceMaterial& m, uint64_t begin, uint64_t end, 
     p.K = g.sy; p.C = g.sx;
     p.bias = o.ray_bias > 0.0f ? o.ray_bias : 0.0f;
     p.reach = tmax < 1e30f ? (tmax + fabsf(o.ray_bias)) * 1.01f : INFINITY;
-    p.near_factor = 0.5f; p.mid_factor = 4.0f; p.small2 = 0.08f * 0.08f;
+    p.near_factor = 0.5f; p.mid_factor = 3.0f; p.small2 = 0.14f * 0.14f; p.big2 = 0.6f;
     p.out = m.horizon; p.stride = stride;
     p.counters = b->horizon_counters;
     const uint32_t tiles = (uint32_t)((end - begin + kHzWave - 1) / kHzWave);
-    if (g.sx <= 16) hipLaunchKernelGGL(k_horizon<16>, dim3(tiles), dim3(kHzWave), 0, b->stream, p);
-    else hipLaunchKernelGGL(k_horizon<32>, dim3(tiles), dim3(kHzWave), 0, b->stream, p);
+    if (g.sx <= 16 && g.sy <= 16) hipLaunchKernelGGL((k_horizon<16, true>), dim3(tiles), dim3(kHzWave), 0, b->stream, p);
+    else hipLaunchKernelGGL((k_horizon<32, false>), dim3(tiles), dim3(kHzWave), 0, b->stream, p);
     return hipGetLastError() == hipSuccess;
 }
 

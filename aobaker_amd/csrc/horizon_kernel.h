@@ -1,4 +1,4 @@
-// horizon_kernel.h — the device side of horizon.hip (see there), apart so that tools/horizon_emu.cpp can run it on the CPU, a thread per lane.
+// horizon_kernel.h — the device side of horizon.hip (see there), apart so that tests/horizon_emu/horizon_emu.cpp can run it on the CPU, a thread per lane.
 #pragma once
 #include "aob_math.h"
 
@@ -10,17 +10,19 @@ namespace aob {
 static constexpr int kHzWave = 64;
 static constexpr int kHzSectors = 32;            // sectors of the tile's horizon H
 static constexpr int kHzOpenCap = 512;           // open nodes of the walk (LDS); a node that does not fit raises H by its own box instead
-static constexpr int kHzNearCap = 512;           // near triangles per tile; more: the tile gets no culling (every cell blocked)
+static constexpr int kHzNearCap = 384;           // near triangles per tile; more: the tile gets no culling (every cell blocked)
 static constexpr int kHzMaxRounds = 1024;
 static constexpr uint32_t kHzEmptyPlanes = 0x8000ffffu;
 static constexpr float kMarginU = 2e-3f;         // on u1 (a column of a 32-column grid is 0.031 wide)
 static constexpr float kMarginPhi = 1e-3f;       // on azimuths, in turns (0.36 degrees)
 static constexpr float kMarginF = 1e-3f;         // on sines / cosines of elevations
 
-#ifdef AOB_HORIZON_EMU                       // tools/horizon_emu.cpp: the kernel on the CPU, a thread per lane
+#ifdef AOB_HORIZON_EMU                       // tests/horizon_emu/horizon_emu.cpp: the kernel on the CPU, a thread per lane
+#define HZ_CLOCK() 0ull
 #define HZ_SCALAR_POINTER(p) ((void)0)
 typedef const float* hz_const_floats;
 #else
+#define HZ_CLOCK() ((unsigned long long)__builtin_readcyclecounter())
 #define HZ_SCALAR_POINTER(p) asm volatile("" : "+s"(p))
 typedef const __attribute__((address_space(4))) float* hz_const_floats;
 #endif
@@ -37,9 +39,10 @@ struct HorizonParams {
     float bias, reach;             // ray_bias; the farthest a hit can be from its surfel (tmax + bias, a little more), INFINITY: unbounded
     float near_factor, mid_factor; // r_near, r_mid in diagonals of the tile's box
     float small2;                  // a box whose angular radius squared is below this is not opened
+    float big2;                    // a leaf whose box diagonal squared exceeds this times its squared gap to the tile is a near leaf
     uint8_t* out;                  // stride bytes per surfel: free columns of row cy in byte cy
     uint32_t stride;
-    unsigned long long* counters;  // diagnostics (or null): rounds, box tests, near triangles, mid leaves, tiles given up
+    unsigned long long* counters;  // diagnostics (or null): rounds, box tests, near triangles, mid leaves, tiles given up, tiles, clock ticks of phases A / B / C
 #ifdef AOB_HORIZON_EMU
     float* dbg;                    // per tile 32 floats: the tile's horizon after phase A; then per tile 64 x 32 words: the local tables after phase B
     uint32_t* dbg_tables;
@@ -105,22 +108,23 @@ __device__ __forceinline__ float hz_wave_min(float v) { for (int off = 32; off >
 __device__ __forceinline__ float hz_wave_max(float v) { for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off)); return v; }
 __device__ __forceinline__ float hz_wave_sum(float v) { for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off); return v; }
 
-struct HzWalk { uint32_t open_ref[kHzOpenCap]; uint32_t open_key[kHzOpenCap]; uint4 leafq[kHzWave]; };
+struct HzLeaf { uint32_t ref, key; };                 // key: first sector | sectors << 5 | margin (sin, 1 / 16384ths, rounded up) << 11
+struct HzWalk { uint32_t open_ref[kHzOpenCap]; uint32_t open_key[kHzOpenCap]; HzLeaf leafq[4 * kHzWave]; };
 union HzScratch { HzWalk walk; float arcs[kHzWave][12]; };
 
-template <int CMAX>
+template <int CMAX, bool T16>
 __global__ __launch_bounds__(kHzWave)
 void k_horizon(HorizonParams p)
 {
     __shared__ HzScratch scratch;                    // phase A's lists, then phase C's arcs
     uint32_t* const open_ref = scratch.walk.open_ref;   // phase A: the nodes to open (bit 31: a near node), last in first out
     uint32_t* const open_key = scratch.walk.open_key;   // ... and what the box they came from measured: top (16 bits, rounded up) | first sector << 16 | sectors << 21
-    uint4* const leafq = scratch.walk.leafq;         // a round's middle-distance leaves: ref, sector range, margin bits
+    HzLeaf* const leafq = scratch.walk.leafq;        // a round's middle-distance leaves
     float (* const arcs)[12] = scratch.arcs;         // phase C: b, n, n x a, b x n of every arc (a = the arc before's b)
     __shared__ uint32_t near_tri[kHzNearCap];
     __shared__ uint32_t H[kHzSectors];               // bits of (sin E + 2): positive floats order like integers
     __shared__ float grp[16][8];                     // the boxes of 16 groups of four origins, in the tile's frame: lo xyz, hi xyz, valid
-    __shared__ uint32_t table[CMAX * kHzWave];       // local tables: [column][lane] = rows blocked FROM that column (cumulated at the end)
+    __shared__ uint32_t table[CMAX * kHzWave / (T16 ? 2 : 1)];    // local tables: [column][lane] = rows blocked FROM that column (cumulated at the end); T16: 16 rows, two lanes a word
 
     const uint32_t lane = threadIdx.x;
     const uint64_t k = p.begin + (uint64_t)blockIdx.x * kHzWave + lane;
@@ -215,37 +219,55 @@ void k_horizon(HorizonParams p)
     const f3 qo = make_f3(p.quant_frame[0], p.quant_frame[1], p.quant_frame[2]), qs = make_f3(p.quant_frame[3], p.quant_frame[4], p.quant_frame[5]);
 
     if (lane < (uint32_t)kHzSectors) H[lane] = __float_as_uint(1.0f);          // sin E = -1: nothing blocked
-    for (int c = 0; c < C; c++) table[c * kHzWave + lane] = 0u;
+    for (int c = 0; c < C; c++) { if (!T16 || lane < 32u) table[c * (kHzWave / (T16 ? 2 : 1)) + (int)lane] = 0u; }
     if (lane == 0) { open_ref[0] = 0x80000000u; open_key[0] = 0xffffffffu; }       // the root, as a near node: opened whatever the horizon
     HZ_SYNC();
 
     // ---- phase A ----
+    const unsigned long long clk0 = p.counters ? HZ_CLOCK() : 0ull;
     int open_n = 1, near_n = 0, rounds = 0;
     bool give_up = false;
     unsigned long long n_tests = 0, n_leaves = 0;
     auto key_top = [](uint32_t key) { return (float)(key & 0xffffu) * (1.0f / 32767.0f) - 1.0f; };   // the sin E a key stands for (rounded up when it was made)
-    // does [first, first + cnt) hold a sector whose horizon is below `top`?
+    // does [first, first + cnt) hold a sector whose horizon is below `top`?  Up to four sectors are looked at one by one; a wider range is held
+    // against the lowest horizon of all sectors as the round found it (an older, lower horizon only keeps more: conservative either way).
+    uint32_t h_low = __float_as_uint(1.0f);
     auto over_horizon = [&](float top, uint32_t rng, bool want) -> bool {
         const uint32_t first = rng & 31u, cnt = rng >> 8;
         const uint32_t tb = __float_as_uint(top + 2.0f);
-        bool over = false;
-        for (uint32_t i = 0; __ballot(want && i < cnt) != 0ull; i++)
-            if (want && i < cnt && H[(first + i) & 31u] < tb) over = true;
-        return over;
+        const uint32_t h0 = H[first], h1 = H[(first + 1u) & 31u], h2 = H[(first + 2u) & 31u], h3 = H[(first + 3u) & 31u];
+        const uint32_t few = min(min(h0, cnt > 1u ? h1 : 0xffffffffu), min(cnt > 2u ? h2 : 0xffffffffu, cnt > 3u ? h3 : 0xffffffffu));
+        return want && (cnt <= 4u ? few : h_low) < tb;
     };
+    // raise the horizon of [first, first + cnt) to `top`: a narrow range sector by sector (most ranges are one to three sectors wide), a wide one —
+    // a box close to the tile — by the first 32 lanes together, one such box after the other
     auto raise = [&](float top, uint32_t rng, bool want) {
         const uint32_t first = rng & 31u, cnt = rng >> 8;
         const uint32_t tb = __float_as_uint(fminf(top, 1.0f) + 2.0f);
-        for (uint32_t i = 0; __ballot(want && i < cnt) != 0ull; i++)
-            if (want && i < cnt) atomicMax(&H[(first + i) & 31u], tb);
+        const bool narrow = want && cnt <= 4u;
+        if (__ballot(narrow) != 0ull) {
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; i++) if (narrow && i < cnt) atomicMax(&H[(first + i) & 31u], tb);
+        }
+        for (uint64_t wide = __ballot(want && cnt > 4u); wide; wide &= wide - 1ull) {
+            const int l = (int)__builtin_ctzll(wide);
+            const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)first, l), n = (uint32_t)__builtin_amdgcn_readlane((int)cnt, l), t = (uint32_t)__builtin_amdgcn_readlane((int)tb, l);
+            if (lane < 32u && ((lane - f) & 31u) < n) atomicMax(&H[lane], t);
+        }
     };
     while (open_n > 0) {
         if (++rounds > kHzMaxRounds) break;
-        const int take = min(16, open_n);
-        const int ni = (int)(lane >> 2), ci = (int)(lane & 3u);
-        bool have = ni < take;
+        {
+            uint32_t hv = H[lane & 31u];
+            for (int off = 16; off > 0; off >>= 1) hv = min(hv, (uint32_t)__shfl_xor((int)hv, off));
+            h_low = (uint32_t)__builtin_amdgcn_readfirstlane((int)hv);
+        }
+        // ---- a round: every lane opens one node of the list's top (up to 64), its four children one after the other ----
+        // (as many as the list can take the children of: a node leaves the list and up to four enter it)
+        const int take = min(min(kHzWave, open_n), max(1, (kHzOpenCap - open_n) / 3));
+        bool have = (int)lane < take;
         uint32_t node = 0u, key = 0u;
-        if (have) { node = open_ref[open_n - 1 - ni]; key = open_key[open_n - 1 - ni]; }
+        if (have) { node = open_ref[open_n - 1 - (int)lane]; key = open_key[open_n - 1 - (int)lane]; }
         open_n -= take;
         const bool near_node = (node >> 31) != 0u;
         node &= 0x7fffffffu;
@@ -254,125 +276,137 @@ void k_horizon(HorizonParams p)
             const bool still = over_horizon(key_top(key), ((key >> 16) & 31u) | (((key >> 21) & 63u) << 8), have && !near_node);
             if (have && !near_node && !still) have = false;
         }
-        uint4 c = make_uint4(kHzEmptyPlanes, kHzEmptyPlanes, kHzEmptyPlanes, 0u);
-        if (have) c = p.nodes4q[4ull * node + ci];
-        bool live = have && !(c.x == kHzEmptyPlanes && c.y == kHzEmptyPlanes && c.z == kHzEmptyPlanes);
-        n_tests += (unsigned long long)__popcll(__ballot(live));
-        // the child's box (stored planes: origin + q * scale, min rounded down, max up)
-        const f3 lo = make_f3(fmaf((float)(c.x & 0x7fffu), qs.x, qo.x), fmaf((float)(c.y & 0x7fffu), qs.y, qo.y), fmaf((float)(c.z & 0x7fffu), qs.z, qo.z));
-        const f3 hi = make_f3(fmaf((float)((c.x >> 16) & 0x7fffu), qs.x, qo.x), fmaf((float)((c.y >> 16) & 0x7fffu), qs.y, qo.y), fmaf((float)((c.z >> 16) & 0x7fffu), qs.z, qo.z));
-        const float gx = fmaxf(fmaxf(lo.x - thi.x, tlo.x - hi.x), 0.0f), gy = fmaxf(fmaxf(lo.y - thi.y, tlo.y - hi.y), 0.0f), gz = fmaxf(fmaxf(lo.z - thi.z, tlo.z - hi.z), 0.0f);
-        const float gap2 = gx * gx + gy * gy + gz * gz;
-        if (live && gap2 > reach2 * 1.0001f) live = false;          // no ray of the tile reaches it
-        const bool leaf = (c.w >> 31) != 0u;
-        // near: within r_near of the tile — or a leaf that looks big from the tile (its box's diagonal against the gap): an edge seen under a wide
-        // angle bulges far over its ends, and the tile-level bounds below would have to give up on it
-        const float ldiag2 = (hi.x - lo.x) * (hi.x - lo.x) + (hi.y - lo.y) * (hi.y - lo.y) + (hi.z - lo.z) * (hi.z - lo.z);
-        const bool near = live && (gap2 <= r_near2 || (leaf && ldiag2 > 0.36f * gap2));
-        const bool far = live && !near;
-        // ---- far boxes: top and arc in the tile's frame, the box grown by the tile's extent ----
-        const f3 cw = make_f3(0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)), ew = make_f3(0.5f * (hi.x - lo.x), 0.5f * (hi.y - lo.y), 0.5f * (hi.z - lo.z));
-        const f3 v = make_f3(dot(Xt, cw) - fc.x, dot(Nt, cw) - fc.y, dot(Zt, cw) - fc.z);
-        const float slack = 2e-6f * (fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(fc.x) + fabsf(fc.y) + fabsf(fc.z));
-        const f3 e = make_f3(dot(aXt, ew) + te.x + slack, dot(aNt, ew) + te.y + slack, dot(aZt, ew) + te.z + slack);
-        const float a0 = v.x - e.x, a1 = v.x + e.x, b1 = v.y + e.y, g0 = v.z - e.z, g1 = v.z + e.z;
-        const float rx = fmaxf(fmaxf(a0, -a1), 0.0f), rz = fmaxf(fmaxf(g0, -g1), 0.0f);
-        const float rmin2 = rx * rx + rz * rz;
-        const float fx = fmaxf(fabsf(a0), fabsf(a1)), fz = fmaxf(fabsf(g0), fabsf(g1));
-        const float r2 = b1 > 0.0f ? rmin2 : fx * fx + fz * fz;
-        const float den = b1 * b1 + r2;
-        float top = den > 0.0f ? b1 * hz_rsq(den) : 1.0f;
-        top = fminf(top + kMarginF, 1.0f);
-        const bool around = rmin2 == 0.0f;                          // the grown box stands over (or under) the tile: every azimuth
-        const float t0 = hz_atan2_turns(g0, a0), t1 = hz_atan2_turns(g1, a0), t2 = hz_atan2_turns(g0, a1), t3 = hz_atan2_turns(g1, a1);
-        auto wrap = [](float d) { d = d - floorf(d + 0.5f); return d; };
-        const float d1 = wrap(t1 - t0), d2 = wrap(t2 - t0), d3 = wrap(t3 - t0);
-        const float rlo = fminf(fminf(d1, d2), fminf(d3, 0.0f)), rhi = fmaxf(fmaxf(d1, d2), fmaxf(d3, 0.0f));
-        uint32_t rng = hz_sector_range32(t0 + rlo, t0 + rhi, around || !(rhi - rlo < 0.5f));
-        if ((rng >> 8) >= 32u) rng = 32u << 8;
-        const bool over = over_horizon(top, rng, far);
-        const float ang2 = dot(e, e) * hz_rcp(fmaxf(dot(v, v), 1e-30f));
-        const bool relevant = far && over;
-        // (a leaf whose grown box stands over the tile may hold the pole of some origin in its INTERIOR, where no vertex or edge sees it: its box's top, 1, it is)
-        const bool mid_leaf = relevant && leaf && gap2 <= r_mid2 && gap2 > 0.0f && !around;
-        const bool box_apply = relevant && !mid_leaf && (leaf || ang2 <= p.small2);
-        const bool push_far = relevant && !leaf && !box_apply;
-        const bool push_near = near && !leaf;
-        const bool near_leaf = near && leaf;
-        // ---- near leaves: their triangles to the near list ----
-        {
-            const uint64_t m1 = __ballot(near_leaf), m2 = __ballot(near_leaf && (c.w & 0x40000000u));
-            const int n1 = __popcll(m1), n2 = __popcll(m2);
-            if (near_n + n1 + n2 > kHzNearCap) give_up = true;
-            else {
-                const uint64_t below = (1ull << lane) - 1ull;
-                if (near_leaf) near_tri[near_n + __popcll(m1 & below)] = c.w & 0x3fffffffu;
-                if (near_leaf && (c.w & 0x40000000u)) near_tri[near_n + n1 + __popcll(m2 & below)] = (c.w & 0x3fffffffu) + 1u;
-                near_n += n1 + n2;
-            }
-        }
-        if (give_up) break;
-        // ---- nodes to open: the far ones first, the near ones on top of them (last in, first out) ----
-        {
-            const uint32_t tq = (uint32_t)fminf(ceilf((top + 1.0f) * 32767.0f), 65535.0f);
-            const uint32_t mykey = tq | ((rng & 31u) << 16) | ((rng >> 8) << 21);
-            const uint64_t mf = __ballot(push_far), mn = __ballot(push_near);
+        uint4 kid[4];
+#pragma unroll
+        for (int ci = 0; ci < 4; ci++) kid[ci] = have ? p.nodes4q[4ull * node + ci] : make_uint4(kHzEmptyPlanes, kHzEmptyPlanes, kHzEmptyPlanes, 0u);
+        int n_leafq = 0;
+        for (int ci = 0; ci < 4; ci++) {
+            const uint4 c = kid[ci];
+            bool live = have && !(c.x == kHzEmptyPlanes && c.y == kHzEmptyPlanes && c.z == kHzEmptyPlanes);
+            if (__ballot(live) == 0ull) continue;
+            n_tests += (unsigned long long)__popcll(__ballot(live));
+            // the child's box (stored planes: origin + q * scale, min rounded down, max up)
+            const f3 lo = make_f3(fmaf((float)(c.x & 0x7fffu), qs.x, qo.x), fmaf((float)(c.y & 0x7fffu), qs.y, qo.y), fmaf((float)(c.z & 0x7fffu), qs.z, qo.z));
+            const f3 hi = make_f3(fmaf((float)((c.x >> 16) & 0x7fffu), qs.x, qo.x), fmaf((float)((c.y >> 16) & 0x7fffu), qs.y, qo.y), fmaf((float)((c.z >> 16) & 0x7fffu), qs.z, qo.z));
+            const float gx = fmaxf(fmaxf(lo.x - thi.x, tlo.x - hi.x), 0.0f), gy = fmaxf(fmaxf(lo.y - thi.y, tlo.y - hi.y), 0.0f), gz = fmaxf(fmaxf(lo.z - thi.z, tlo.z - hi.z), 0.0f);
+            const float gap2 = gx * gx + gy * gy + gz * gz;
+            if (live && gap2 > reach2 * 1.0001f) live = false;          // no ray of the tile reaches it
+            const bool leaf = (c.w >> 31) != 0u;
+            // near: within r_near of the tile — or a leaf that looks big from the tile (its box's diagonal against the gap): an edge seen under a wide
+            // angle bulges far over its ends, and the tile-level bounds below would have to give up on it
+            const float ldiag2 = (hi.x - lo.x) * (hi.x - lo.x) + (hi.y - lo.y) * (hi.y - lo.y) + (hi.z - lo.z) * (hi.z - lo.z);
+            const bool near = live && (gap2 <= r_near2 || (leaf && ldiag2 > p.big2 * gap2));
+            const bool far = live && !near;
+            // ---- far boxes: top and arc in the tile's frame, the box grown by the tile's extent ----
+            const f3 cw = make_f3(0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)), ew = make_f3(0.5f * (hi.x - lo.x), 0.5f * (hi.y - lo.y), 0.5f * (hi.z - lo.z));
+            const f3 v = make_f3(dot(Xt, cw) - fc.x, dot(Nt, cw) - fc.y, dot(Zt, cw) - fc.z);
+            const float slack = 2e-6f * (fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(fc.x) + fabsf(fc.y) + fabsf(fc.z));
+            const f3 e = make_f3(dot(aXt, ew) + te.x + slack, dot(aNt, ew) + te.y + slack, dot(aZt, ew) + te.z + slack);
+            const float a0 = v.x - e.x, a1 = v.x + e.x, b1 = v.y + e.y, g0 = v.z - e.z, g1 = v.z + e.z;
+            const float rx = fmaxf(fmaxf(a0, -a1), 0.0f), rz = fmaxf(fmaxf(g0, -g1), 0.0f);
+            const float rmin2 = rx * rx + rz * rz;
+            const float fx = fmaxf(fabsf(a0), fabsf(a1)), fz = fmaxf(fabsf(g0), fabsf(g1));
+            const float r2 = b1 > 0.0f ? rmin2 : fx * fx + fz * fz;
+            const float den = b1 * b1 + r2;
+            float top = den > 0.0f ? b1 * hz_rsq(den) : 1.0f;
+            top = fminf(top + kMarginF, 1.0f);
+            const bool around = rmin2 == 0.0f;                          // the grown box stands over (or under) the tile: every azimuth
+            // the arc of azimuths: the grown rectangle's bounding circle about its centre (cheaper than its four corners, and the rectangle is nearly a square)
+            const float rc2 = v.x * v.x + v.z * v.z, R2c = e.x * e.x + e.z * e.z;
+            const float thc = hz_atan2_turns(v.z, v.x);
+            const float alpha = (around || rc2 <= R2c) ? 0.5f : hz_asin_turns_up(sqrtf(R2c * hz_rcp(rc2)) * 1.0001f);
+            uint32_t rng = hz_sector_range32(thc - alpha, thc + alpha, around || alpha >= 0.25f);
+            const bool over = over_horizon(top, rng, far);
+            const float ang2 = dot(e, e) * hz_rcp(fmaxf(dot(v, v), 1e-30f));
+            const bool relevant = far && over;
+            // (a leaf whose grown box stands over the tile may hold the pole of some origin in its INTERIOR, where no vertex or edge sees it: its box's top, 1, it is)
+            const bool mid_leaf = relevant && leaf && gap2 <= r_mid2 && gap2 > 0.0f && !around;
+            const bool box_apply = relevant && !mid_leaf && (leaf || ang2 <= p.small2);
+            const bool push_far = relevant && !leaf && !box_apply;
+            const bool push_near = near && !leaf;
+            const bool near_leaf = near && leaf;
             const uint64_t below = (1ull << lane) - 1ull;
-            const int nf = __popcll(mf), nn = __popcll(mn);
-            const int room = kHzOpenCap - open_n;
-            bool spill_far = false;
-            if (push_far) {
-                const int r = __popcll(mf & below);
-                if (r < room - nn) { open_ref[open_n + r] = c.w; open_key[open_n + r] = mykey; }
-                else spill_far = true;                                     // no room: the box itself raises the horizon
+            // ---- near leaves: their triangles to the near list ----
+            {
+                const uint64_t m1 = __ballot(near_leaf), m2 = __ballot(near_leaf && (c.w & 0x40000000u));
+                const int n1 = __popcll(m1), n2 = __popcll(m2);
+                if (near_n + n1 + n2 > kHzNearCap) give_up = true;
+                else {
+                    if (near_leaf) near_tri[near_n + __popcll(m1 & below)] = c.w & 0x3fffffffu;
+                    if (near_leaf && (c.w & 0x40000000u)) near_tri[near_n + n1 + __popcll(m2 & below)] = (c.w & 0x3fffffffu) + 1u;
+                    near_n += n1 + n2;
+                }
             }
-            const int kept_f = max(0, min(nf, room - nn));
-            if (nn > room) give_up = true;
-            else if (push_near) { const int r = __popcll(mn & below); open_ref[open_n + kept_f + r] = c.w | 0x80000000u; open_key[open_n + kept_f + r] = 0xffffffffu; }
-            open_n += kept_f + (give_up ? 0 : nn);
-            if (__ballot(box_apply || spill_far) != 0ull) raise(top, rng, box_apply || spill_far);
-        }
-        if (give_up) break;
-        // ---- middle-distance leaves: their vertices against the 16 groups' boxes ----
-        {
-            const uint64_t ml = __ballot(mid_leaf);
-            const int nl = __popcll(ml);
-            n_leaves += (unsigned long long)nl;
-            if (nl) {
+            if (give_up) break;
+            // ---- nodes to open: the far ones first, the near ones on top of them (last in, first out) ----
+            {
+                const uint32_t tq = (uint32_t)fminf(ceilf((top + 1.0f) * 32767.0f), 65535.0f);
+                const uint32_t mykey = tq | ((rng & 31u) << 16) | ((rng >> 8) << 21);
+                const uint64_t mf = __ballot(push_far), mn = __ballot(push_near);
+                const int nf = __popcll(mf), nn = __popcll(mn);
+                const int room = kHzOpenCap - open_n;
+                bool spill_far = false;
+                if (push_far) {
+                    const int r = __popcll(mf & below);
+                    if (r < room - nn) { open_ref[open_n + r] = c.w; open_key[open_n + r] = mykey; }
+                    else spill_far = true;                                     // no room: the box itself raises the horizon
+                }
+                const int kept_f = max(0, min(nf, room - nn));
+                if (nn > room) give_up = true;
+                else if (push_near) { const int r = __popcll(mn & below); open_ref[open_n + kept_f + r] = c.w | 0x80000000u; open_key[open_n + kept_f + r] = 0xffffffffu; }
+                open_n += kept_f + (give_up ? 0 : nn);
+                if (__ballot(box_apply || spill_far) != 0ull) raise(top, rng, box_apply || spill_far);
+            }
+            if (give_up) break;
+            // ---- middle-distance leaves: put aside, measured together below ----
+            {
+                const uint64_t ml = __ballot(mid_leaf);
                 if (mid_leaf) {
                     // the arc's bulge over its ends: an edge of angular length w rises at most w^2 / 7 (in sine) over the higher end; w <= box diagonal / gap
                     // (1 / cos(w / 2) - 1 <= w^2 / 7 up to w = 1.2)
                     const float w2 = 4.0f * dot(ew, ew) * hz_rcp(gap2) * 1.001f;
-                    leafq[__popcll(ml & ((1ull << lane) - 1ull))] = make_uint4(c.w, rng, __float_as_uint((w2 <= 1.0f ? w2 * (1.0f / 7.0f) : 2.0f) + kMarginF), 0u);
+                    const float mg = (w2 <= 1.0f ? w2 * (1.0f / 7.0f) : 2.0f) + kMarginF;
+                    HzLeaf lf; lf.ref = c.w; lf.key = (rng & 31u) | ((rng >> 8) << 5) | ((uint32_t)fminf(ceilf(mg * 16384.0f), 32768.0f) << 11);
+                    leafq[n_leafq + __popcll(ml & below)] = lf;
                 }
-                HZ_SYNC();
-                for (int base = 0; base < nl; base += 4) {
-                    const int j = base + (int)(lane >> 4), g = (int)(lane & 15u);
-                    const bool on = j < nl;
-                    float el = -2.0f;
-                    uint4 q = make_uint4(0u, 0u, 0u, 0u);
-                    if (on) q = leafq[j];
-                    const float* gb = grp[g];
-                    if (on && gb[6] != 0.0f) {
-                        const uint32_t tri = q.x & 0x3fffffffu;
-                        const int nv = (q.x & 0x40000000u) ? 6 : 3;
-                        for (int vi = 0; vi < nv; vi++) {
-                            const float4 w = p.leaf_tris[3ull * tri + vi];
-                            const f3 f = make_f3(dot(Xt, make_f3(w.x, w.y, w.z)), dot(Nt, make_f3(w.x, w.y, w.z)), dot(Zt, make_f3(w.x, w.y, w.z)));
-                            const float sl = 2e-6f * (fabsf(f.x) + fabsf(f.y) + fabsf(f.z));
+                n_leafq += __popcll(ml);
+            }
+        }
+        if (give_up) break;
+        // ---- the round's middle-distance leaves, 16 at a time: four lanes a leaf, each lane its vertices against four of the 16 groups' boxes ----
+        n_leaves += (unsigned long long)n_leafq;
+        if (n_leafq) {
+            HZ_SYNC();
+            for (int base = 0; base < n_leafq; base += 16) {
+                const int j = base + (int)(lane >> 2), g0i = (int)(lane & 3u) * 4;
+                const bool on = j < n_leafq;
+                float el = -2.0f;
+                HzLeaf q; q.ref = 0u; q.key = 0u;
+                if (on) q = leafq[j];
+                if (on) {
+                    const uint32_t tri = q.ref & 0x3fffffffu;
+                    const int nv = (q.ref & 0x40000000u) ? 6 : 3;
+                    for (int vi = 0; vi < nv; vi++) {
+                        const float4 w = p.leaf_tris[3ull * tri + vi];
+                        const f3 f = make_f3(dot(Xt, make_f3(w.x, w.y, w.z)), dot(Nt, make_f3(w.x, w.y, w.z)), dot(Zt, make_f3(w.x, w.y, w.z)));
+                        const float sl = 2e-6f * (fabsf(f.x) + fabsf(f.y) + fabsf(f.z));
+#pragma unroll
+                        for (int gi = 0; gi < 4; gi++) {
+                            const float* gb = grp[g0i + gi];
                             const float lx = f.x - gb[3] - sl, hx = f.x - gb[0] + sl, lz = f.z - gb[5] - sl, hz = f.z - gb[2] + sl;
                             const float bh = f.y - gb[1] + sl;               // the highest the vertex stands over an origin of the group
                             const float da = fmaxf(fmaxf(lx, -hx), 0.0f), dg = fmaxf(fmaxf(lz, -hz), 0.0f);
                             const float fa = fmaxf(fabsf(lx), fabsf(hx)), fg = fmaxf(fabsf(lz), fabsf(hz));
                             const float rr = bh > 0.0f ? da * da + dg * dg : fa * fa + fg * fg;
                             const float dd = bh * bh + rr;
-                            el = fmaxf(el, dd > 0.0f ? bh * hz_rsq(dd) : 1.0f);
+                            const float e1 = dd > 0.0f ? bh * hz_rsq(dd) : 1.0f;
+                            if (gb[6] != 0.0f) el = fmaxf(el, e1);
                         }
                     }
-                    el = fmaxf(el, __shfl_xor(el, 1)); el = fmaxf(el, __shfl_xor(el, 2)); el = fmaxf(el, __shfl_xor(el, 4)); el = fmaxf(el, __shfl_xor(el, 8));
-                    const bool lead = on && g == 0 && el > -1.5f;
-                    if (__ballot(lead) != 0ull) raise(fminf(el + __uint_as_float(q.z), 1.0f), q.y, lead);
                 }
+                el = fmaxf(el, __shfl_xor(el, 1)); el = fmaxf(el, __shfl_xor(el, 2));
+                const bool lead = on && (lane & 3u) == 0u && el > -1.5f;
+                if (__ballot(lead) != 0ull) raise(fminf(el + (float)(q.key >> 11) * (1.0f / 16384.0f), 1.0f), (q.key & 31u) | (((q.key >> 5) & 63u) << 8), lead);
             }
         }
         HZ_SYNC();
@@ -389,6 +423,7 @@ void k_horizon(HorizonParams p)
         }
         give_up = __ballot(give_up) != 0ull;
     }
+    const unsigned long long clk1 = p.counters ? HZ_CLOCK() : 0ull;
     if (p.counters && lane == 0) {
         atomicAdd(&p.counters[0], (unsigned long long)rounds); atomicAdd(&p.counters[1], n_tests); atomicAdd(&p.counters[2], (unsigned long long)near_n);
         atomicAdd(&p.counters[3], n_leaves); atomicAdd(&p.counters[4], give_up ? 1ull : 0ull); atomicAdd(&p.counters[5], 1ull);
@@ -402,10 +437,17 @@ void k_horizon(HorizonParams p)
     const uint32_t allK = K >= 32 ? 0xffffffffu : (1u << K) - 1u;
     const float fC = (float)C;
     const float inv_bias = p.bias > 0.0f ? 1.0f / p.bias : 0.0f;
+    auto tab_or = [&](int c, uint32_t mask) {
+        if (T16) atomicOr(&table[c * (kHzWave / 2) + (int)(lane >> 1)], mask << ((lane & 1u) << 4));
+        else atomicOr(&table[c * kHzWave + (int)lane], mask);
+    };
+    auto tab_get = [&](int c) -> uint32_t {
+        return T16 ? (table[c * (kHzWave / 2) + (int)(lane >> 1)] >> ((lane & 1u) << 4)) & 0xffffu : table[c * kHzWave + (int)lane];
+    };
     // block the rows of `mask` from the column u falls in
     auto block = [&](float u, uint32_t mask, bool want) {
         const int c0 = (int)fminf(fmaxf(floorf((u - kMarginU) * fC), 0.0f), fC);
-        if (want && c0 < C) atomicOr(&table[c0 * kHzWave + (int)lane], mask);
+        if (want && c0 < C) tab_or(c0, mask);
     };
 
     // ---- phase B: the near triangles, every surfel in its own frame ----
@@ -448,9 +490,10 @@ void k_horizon(HorizonParams p)
         block(u, hz_sector_mask(th - alpha, th + alpha, full || alpha >= 0.25f, K, kMarginPhi), want);
     }
 
+    const unsigned long long clk2 = p.counters ? HZ_CLOCK() : 0ull;
 #ifdef AOB_HORIZON_EMU
     HZ_SYNC();
-    if (p.dbg_tables) for (int c = 0; c < C; c++) p.dbg_tables[((uint64_t)blockIdx.x * 64u + lane) * 32u + c] = table[c * kHzWave + (int)lane];
+    if (p.dbg_tables) for (int c = 0; c < C; c++) p.dbg_tables[((uint64_t)blockIdx.x * 64u + lane) * 32u + c] = tab_get(c);
 #endif
     // ---- phase C: the horizon's boundary as arcs, every arc into the local tables ----
     {
@@ -508,7 +551,7 @@ void k_horizon(HorizonParams p)
             uint32_t hb = max(max(H[sk], H[(sk + 1) & 31]), H[(sk + 31) & 31]);
             if (sN > 0.99f) for (int q = 0; q < kHzSectors; q++) hb = max(hb, H[q]);
             const float hN = __uint_as_float(hb) - 2.0f;
-            if (framed && sN <= hN + 4.0f * kMarginF + 2e-3f) atomicOr(&table[(int)lane], allK);
+            if (framed && sN <= hN + 4.0f * kMarginF + 2e-3f) tab_or(0, allK);
         }
         float cs_a, th_a;
         {
@@ -549,7 +592,7 @@ void k_horizon(HorizonParams p)
 #pragma unroll
         for (int r = 0; r < 32; r++) cnt[r] = 0u;
         for (int c = 0; c < C; c++) {
-            cum |= table[c * kHzWave + (int)lane];
+            cum |= tab_get(c);
             const uint32_t freebits = ~cum & allK;
 #pragma unroll
             for (int r = 0; r < 32; r++) cnt[r] += (freebits >> r) & 1u;
@@ -558,6 +601,11 @@ void k_horizon(HorizonParams p)
         for (int r = 0; r < 32; r++) fr[r >> 2] |= cnt[r] << ((r & 3) * 8);
     }
     write_out(fr);
+    if (p.counters && lane == 0) {
+        // (clock ticks per phase, summed over the tiles: A, B, C + the epilogue)
+        const unsigned long long clk3 = HZ_CLOCK();
+        atomicAdd(&p.counters[6], clk1 - clk0); atomicAdd(&p.counters[7], clk2 - clk1); atomicAdd(&p.counters[8], clk3 - clk2);
+    }
 }
 
 

@@ -553,7 +553,7 @@ int rasterize_material(AobBake* b, int32_t material, int32_t row_begin, int32_t 
     b->stats.trace_cuts = 0u;
     b->stats.trace_horizon = 0u;
     m.horizon_asked = 0;
-    (void)hipMemsetAsync(b->horizon_counters + 8 + material, 0, sizeof(unsigned long long), b->stream);
+    (void)hipMemsetAsync(b->horizon_counters + 16 + material, 0, sizeof(unsigned long long), b->stream);
     reserve_tile_cuts(b, material);
     return AOB_OK;
 }

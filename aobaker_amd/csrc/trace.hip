@@ -1400,7 +1400,15 @@ static bool cuts_apply(const AobBake* b)
 // the sample parts per tile of a launch (and whether the last tiles of a queue are cut finer): trace_range's schedule
 static uint32_t schedule_parts(const AobOptions& o)
 {
-    return (uint32_t)max(1, min(o.trace_parts > 0 ? o.trace_parts : 4, o.sample_count / (o.trace_part_min > 0 ? o.trace_part_min : 16)));
+    uint32_t parts = (uint32_t)max(1, min(o.trace_parts > 0 ? o.trace_parts : 4, o.sample_count / (o.trace_part_min > 0 ? o.trace_part_min : 16)));
+    // horizon tables (horizon.hip): a unit's samples are at most four whole rows of the sampler's grid — one word of a surfel's table.  A 32 x 32 grid
+    // (1024 spp) in four parts would be eight rows each: eight parts then.
+    if (horizon_applies(o)) {
+        CosineGrid g;
+        cosine_grid(o.sample_count, g);
+        if ((uint32_t)g.sy % parts == 0u && (uint32_t)g.sy / parts > 4u && g.sy % 4 == 0 && g.sy / 4 <= kCutWedges) parts = (uint32_t)g.sy / 4u;
+    }
+    return parts;
 }
 
 void reserve_tile_cuts(AobBake* b, int32_t material)
@@ -1409,7 +1417,8 @@ void reserve_tile_cuts(AobBake* b, int32_t material)
     DeviceMaterial& m = b->materials[material];
     if (m.surfel_count == 0) return;
     const uint32_t parts = schedule_parts(b->opt);
-    const uint64_t records = b->opt.sampler == AOB_SAMPLER_COSINE ? 3ull * parts : 1ull;       // coarse parts + twice as many fine ones
+    const bool fine = parts > 1u && (uint32_t)b->opt.sample_count / (2u * parts) >= 16u && 3u * parts <= (uint32_t)kCutWedges;
+    const uint64_t records = b->opt.sampler == AOB_SAMPLER_COSINE ? (fine ? 3ull : 1ull) * parts : 1ull;       // coarse parts + twice as many fine ones
     const uint64_t tiles = m.surfel_count / 64 + m.section_offsets.size() + 1;
     (void)ensure_tile_cuts(b, m, (tiles * records + 1) * (uint64_t)kCutWords);
 }
@@ -1554,7 +1563,8 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
             // when the slowest wavefront finishes its last unit
             const uint32_t queue_tiles = p.xcd_chunk_tiles + p.rest_per_xcd;
             p.parts_fine = p.parts * 2u;
-            const uint32_t fine_tiles = (p.parts > 1u && (uint32_t)o.sample_count / p.parts_fine >= 16u) ? queue_tiles / (uint32_t)knob(o.trace_fine_div, 8) : 0u;
+            // (... and where the parts' records still fit the tile cuts' wedge table)
+            const uint32_t fine_tiles = (p.parts > 1u && (uint32_t)o.sample_count / p.parts_fine >= 16u && p.parts + p.parts_fine <= (uint32_t)kCutWedges) ? queue_tiles / (uint32_t)knob(o.trace_fine_div, 8) : 0u;
             p.coarse_tiles = queue_tiles - fine_tiles;
             p.coarse_units = p.coarse_tiles * p.parts;
             p.units_per_xcd = p.coarse_units + fine_tiles * p.parts_fine;
@@ -1595,7 +1605,7 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
                 if (whole) {
                     if (horizon_build(b, m, sb, se, p.tmax)) {
                         p.horizon = (const uint32_t*)m.horizon; p.horizon_words = horizon_stride(b) / 4u;
-                        p.cast_total = b->horizon_counters + 8 + material;
+                        p.cast_total = b->horizon_counters + 16 + material;
                         m.horizon_asked += (se - sb) * (uint64_t)o.sample_count;
                         if (b->stats.trace_horizon != 2u) b->stats.trace_horizon = 1u;
                     } else {

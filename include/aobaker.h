@@ -141,7 +141,8 @@ typedef struct AobOptions {
                                      gets a HORIZON TABLE — for each azimuth row of the sampler's grid the number of leading columns (the
                                      directions nearest the normal) that no triangle of the scene can reach, proven from the tree with
                                      conservative bounds (horizon.hip) — and the trace kernel does not cast the samples of those cells: they are
-                                     unoccluded whatever their jitter and score as cast rays would.  0 (default): on where it applies, 1: off.
+                                     unoccluded whatever their jitter and score as cast rays would.  The tables cost time per surfel and save
+                                     time per sample: 0 (default) = from 128 samples per surfel on, 1 = off, 2 = wherever they apply.
                                      Moves work, never changes a result cell.  16 or 32 bytes per covered texel of device memory; a bake that
                                      cannot have them casts every sample and says so (AobStats::trace_horizon = 2).  (ABI 7)              */
 } AobOptions;
@@ -393,6 +394,9 @@ int aob_bake_copy_tile_cuts(AobBake* bake, int32_t material, uint32_t* dst, uint
  * (no triangle of the scene can be reached through them).  *surfels = 0 if the launches had no tables.  For the tests: every ray of such a
  * cell must be unoccluded for the oracle. */
 int aob_bake_copy_horizon(AobBake* bake, int32_t material, uint8_t* dst, uint64_t capacity_bytes, uint32_t* stride, uint64_t* surfels);
+/* Diagnostics of the horizon-table kernel since the bake was created (or last cleared), summed over its tiles: out16[0..8] = walk rounds, child
+ * boxes measured, near triangles, middle-distance leaves, tiles that got no tables (lists full), tiles, clock ticks of the kernel's three phases. */
+int aob_bake_horizon_counters(AobBake* bake, unsigned long long* out16, int clear);
 int aob_bake_surfel_count(AobBake* bake, int32_t material, uint64_t* count);
 int aob_bake_copy_surfels(AobBake* bake, int32_t material, AobSurfel* dst, uint64_t capacity);
 int aob_bake_copy_results(AobBake* bake, int32_t material, AobResult* dst, uint64_t capacity);

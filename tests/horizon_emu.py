@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""tools/horizon_emu.py — the horizon kernel (aobaker_amd/csrc/horizon_kernel.h) on the CPU (tools/horizon_emu.cpp: a host thread per lane) against the
+"""tests/horizon_emu.py — the horizon kernel (aobaker_amd/csrc/horizon_kernel.h) on the CPU (tests/horizon_emu/horizon_emu.cpp: a host thread per lane) against the
 oracle's rays: tables of whole tiles of a scene, the share of samples they skip, and the count of skipped cells that hold an occluded ray (must be 0).
 Test infrastructure (tests/test_horizon_emu.py imports it); also the tool behind profiles/r06/horizon/*.json.
-  python tools/horizon_emu.py [--scene terrain|terrain_small|cube|inward|sphere|soup|rocks] [--tiles 8] [--spp 256]
+  python tests/horizon_emu.py [--scene terrain|terrain_small|cube|inward|sphere|soup|rocks] [--tiles 8] [--spp 256]
 """
 import argparse
 import ctypes as C
@@ -21,16 +21,16 @@ _LIB = None
 def load():
     global _LIB
     if _LIB is None:
-        so = os.path.join(ROOT, "tools", "libhorizon_emu.so")
-        src = [os.path.join(ROOT, "tools", "horizon_emu.cpp"), os.path.join(ROOT, "aobaker_amd", "csrc", "horizon_kernel.h"),
-               os.path.join(ROOT, "tools", "horizon_emu", "hip", "hip_runtime.h")]
+        so = os.path.join(ROOT, "tests", "horizon_emu", "libhorizon_emu.so")
+        src = [os.path.join(ROOT, "tests", "horizon_emu", "horizon_emu.cpp"), os.path.join(ROOT, "aobaker_amd", "csrc", "horizon_kernel.h"),
+               os.path.join(ROOT, "tests", "horizon_emu", "hip", "hip_runtime.h")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
-            subprocess.run(["g++", "-O2", "-std=c++20", "-fPIC", "-shared", "-pthread", "-DAOB_HORIZON_EMU", "-I" + os.path.join(ROOT, "tools", "horizon_emu"),
+            subprocess.run(["g++", "-O2", "-std=c++20", "-fPIC", "-shared", "-pthread", "-DAOB_HORIZON_EMU", "-I" + os.path.join(ROOT, "tests", "horizon_emu"),
                             "-I" + os.path.join(ROOT, "aobaker_amd", "csrc"), src[0], "-o", so], check=True)
         _LIB = C.CDLL(so)
         _LIB.emu_horizon.restype = C.c_int
         _LIB.emu_horizon.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.c_float, C.c_float,
-                                     C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+                                     C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
     return _LIB
 
 
@@ -53,7 +53,7 @@ def frames_of(surfels):
     return f
 
 
-def tables(surfels, n4q, leaf_tris, qframe, spp, bias=1e-3, reach=np.inf, near=0.5, mid=4.0, small=0.08, counters=None, debug=None):
+def tables(surfels, n4q, leaf_tris, qframe, spp, bias=1e-3, reach=np.inf, near=0.5, mid=3.0, small=0.14, big=0.36, counters=None, debug=None):
     """uint8 [n, stride]: the free columns of every azimuth row, surfels taken 64 at a time in the order given"""
     sx = int(np.floor(np.sqrt(spp))); sy = spp // sx
     assert sx * sy == spp and 4 <= sx <= 32 and 4 <= sy <= 32
@@ -63,7 +63,7 @@ def tables(surfels, n4q, leaf_tris, qframe, spp, bias=1e-3, reach=np.inf, near=0
     n4q = np.ascontiguousarray(n4q, dtype=np.uint32); lt = np.ascontiguousarray(leaf_tris); qf = np.ascontiguousarray(qframe, dtype=np.float32)
     cnt = np.zeros(8, np.uint64) if counters is None else counters
     tiles = (len(surfels) + 63) // 64
-    load().emu_horizon(f.ctypes.data, 0, len(surfels), n4q.ctypes.data, lt.ctypes.data, qf.ctypes.data, len(n4q), sy, sx, bias, reach, near, mid, small * small,
+    load().emu_horizon(f.ctypes.data, 0, len(surfels), n4q.ctypes.data, lt.ctypes.data, qf.ctypes.data, len(n4q), sy, sx, bias, reach, near, mid, small * small, big,
                        out.ctypes.data, stride, cnt.ctypes.data, 0, tiles,
                        None if debug is None else debug["H"].ctypes.data, None if debug is None else debug["tables"].ctypes.data)
     return out
@@ -143,7 +143,7 @@ def main():
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--near", type=float, default=0.5)
-    ap.add_argument("--mid", type=float, default=4.0)
+    ap.add_argument("--mid", type=float, default=3.0)
     ap.add_argument("--builder", type=int, default=1)
     ap.add_argument("--out", default="")
     args = ap.parse_args()

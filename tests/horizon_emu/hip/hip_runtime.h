@@ -1,6 +1,6 @@
 // A stand-in for <hip/hip_runtime.h> that lets ONE kernel file (aobaker_amd/csrc/horizon_kernel.h) run on the CPU: a wavefront is 64 host
 // threads in lockstep at every cross-lane operation (a barrier and an exchange buffer), LDS is static storage.  Test infrastructure only
-// (tools/horizon_emu.cpp, tests/test_horizon_emu.py): it checks the kernel's LOGIC against the oracle where there is no GPU; nothing of the
+// (tests/horizon_emu/horizon_emu.cpp, tests/test_horizon_emu.py): it checks the kernel's LOGIC against the oracle where there is no GPU; nothing of the
 // product includes it.
 #pragma once
 #include <atomic>
@@ -59,6 +59,7 @@ static inline uint64_t __ballot(bool p)
     return m;
 }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return emu::from_lane(v, 0u); }
+static inline int __builtin_amdgcn_readlane(int v, int l) { return emu::from_lane(v, (unsigned)l); }
 static inline float __builtin_amdgcn_rcpf(float v) { return 1.0f / v; }
 static inline float __builtin_amdgcn_rsqf(float v) { return 1.0f / std::sqrt(v); }
 #define __builtin_amdgcn_fence(...) ((void)0)

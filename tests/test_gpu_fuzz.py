@@ -67,6 +67,8 @@ def random_options(rng):
         o.trace_bands = int(rng.integers(0, 3))
         o.trace_scalar_min = int(rng.choice([0, 1, 8, 24, 64]))
         o.trace_cut = int(rng.choice([0, 0, 1, 4, 7, 16, 32]))
+    # horizon tables (round 6; drawn after everything else): forced on — they apply to the COSINE sampler's full grids (16, 64 samples here) on the quantised 4-ary nodes
+    o.trace_horizon = int(rng.choice([0, 1, 2, 2]))
     return o
 
 

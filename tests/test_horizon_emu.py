@@ -1,4 +1,4 @@
-"""The horizon kernel's LOGIC without a GPU: aobaker_amd/csrc/horizon_kernel.h compiled for the CPU (tools/horizon_emu.cpp: one host thread per lane,
+"""The horizon kernel's LOGIC without a GPU: aobaker_amd/csrc/horizon_kernel.h compiled for the CPU (tests/horizon_emu/horizon_emu.cpp: one host thread per lane,
 LDS as static storage) builds the tables of whole tiles, and every cell they skip must hold only rays the oracle finds unoccluded — on scenes of
 every kind the suite has, several sample counts, both tree builders.  (The same kernel source on the GPU: tests/test_gpu_horizon.py.)"""
 import os
@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import horizon_emu as he          # noqa: E402
 from aobaker_amd import scenes    # noqa: E402

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""tools/check_horizon.py — GPU check of the horizon tables (horizon.hip) against the oracle, outside pytest: for a list of scenes, the cells baked
+"""tools/measure_horizon_gpu.py — GPU check of the horizon tables (horizon.hip) against the oracle, outside pytest: for a list of scenes, the cells baked
 with tables == the cells baked without == the oracle's; every cell the tables skip holds only unoccluded rays of the oracle; the share skipped.
-  python tools/check_horizon.py [--big]
+  python tools/measure_horizon_gpu.py [--big]
 """
 import argparse
 import json

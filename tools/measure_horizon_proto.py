@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""tools/horizon_proto.py (a measurement script, not a test, not product code) — prototype of the HIERARCHICAL horizon-table build that k_horizon
+"""tools/measure_horizon_proto.py (a measurement script, not a test, not product code) — prototype of the HIERARCHICAL horizon-table build that k_horizon
 runs per tile (lane = surfel, wave-uniform best-first walk of the 4-ary tree), in numpy: the share of rays it culls, the boxes and triangles it
 touches per tile, the generation occupancy the culled lists leave, and the check that no culled ray is occluded for the oracle.
 
-  python tools/horizon_proto.py [--tiles 8] [--thr 0.08] [--tri exact|cheap]
+  python tools/measure_horizon_proto.py [--tiles 8] [--thr 0.08] [--tri exact|cheap]
 """
 import argparse
 import heapq

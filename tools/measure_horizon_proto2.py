@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/horizon_proto2.py (a measurement script, not a test, not product code) — numpy prototype of the THREE-PHASE horizon-table build of k_horizon:
+"""tools/measure_horizon_proto2.py (a measurement script, not a test, not product code) — numpy prototype of the THREE-PHASE horizon-table build of k_horizon:
 
   A  lane = item, world frame: a best-first walk of the tree from the tile's box; boxes nearer than r_near are opened down to their triangles (the NEAR
      list); every other box raises a per-tile world horizon H[az] (sin of the elevation below which a direction may be blocked for SOME origin of the
@@ -19,7 +19,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-import horizon_proto as hp
+import measure_horizon_proto as hp
 
 MID = 3.0
 VM = 0

@@ -108,10 +108,22 @@ def child(modes, reps, knobs):
                                     "inner_sections_with_a_deep_stack": round(stats["deep_stack_visits"] / max(1, stats["inner_sections"]), 4),
                                     "inner_sections_in_the_drain": round(stats["drain_inner_sections"] / max(1, stats["inner_sections"]), 4),
                                     "lanes_per_inner_section_in_the_drain": round(stats["drain_inner_lanes"] / max(1, stats["drain_inner_sections"]), 2)}
+            hz = None
+            if hasattr(b.lib, "aob_bake_horizon_counters") and st.trace_horizon == 1:
+                import ctypes
+                hb = (ctypes.c_ulonglong * 16)()
+                b.lib.aob_bake_horizon_counters(b.handle, hb, 1)
+                b.clear_results(0); b.trace(0); b.sync()
+                b.lib.aob_bake_horizon_counters(b.handle, hb, 1)
+                tl = max(1, int(hb[5]))
+                hz = {"tiles": int(hb[5]), "per_tile": {"rounds": round(hb[0] / tl, 1), "box_tests": round(hb[1] / tl, 1), "near_triangles": round(hb[2] / tl, 1),
+                                                        "middle_leaves": round(hb[3] / tl, 1), "given_up": round(hb[4] / tl, 4)},
+                      "clock_ticks_per_tile": {"walk": round(hb[6] / tl), "near": round(hb[7] / tl), "arcs_and_out": round(hb[8] / tl)},
+                      "rays_cast_share": round(st.rays_cast / max(1, st.ray_count), 4)}
         best = min(ms[1:])
         print(json.dumps({"lib": os.path.relpath(lib, ROOT) if lib != "-" else "in-tree", "mode": mode, "knobs": knobs, "trace_ms": round(best, 3),
                           "all_ms": [round(x, 3) for x in ms], "grays_per_s": round(n * spp / best / 1e6, 3), "results_crc32": crc,
-                          "bvh_build_wall_ms": round(min(build_ms), 3), "bvh_depth": st.bvh_depth, **({"loop_counters": stats} if stats else {})}), flush=True)
+                          "bvh_build_wall_ms": round(min(build_ms), 3), "bvh_depth": st.bvh_depth, **({"horizon": hz} if hz else {}), **({"loop_counters": stats} if stats else {})}), flush=True)
     BakeEngine.Dispose()
 
 
