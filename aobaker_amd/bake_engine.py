@@ -69,6 +69,12 @@ class Baker:
         capi.check(self.lib.aob_bake_get_stats(self.handle, C.byref(s)))
         return s
 
+    def last_stage_ms(self) -> dict:
+        """HIP-event times of the most recent stages (ms; None: not run): bvh_build, rasterize, trace, and of the trace's last launch tile_cuts, horizon, walk."""
+        out = (C.c_float * 6)()
+        capi.check(self.lib.aob_bake_last_stage_ms(self.handle, out))
+        return {k: (None if out[i] < 0 else float(out[i])) for i, k in enumerate(("bvh_build", "rasterize", "trace", "tile_cuts", "horizon", "walk"))}
+
     def node_count(self) -> int:
         n = C.c_uint64()
         capi.check(self.lib.aob_bake_node_count(self.handle, C.byref(n)))

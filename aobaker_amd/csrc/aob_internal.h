@@ -137,6 +137,8 @@ struct AobBake {
 
     hipEvent_t ev[8] = {};
     hipEvent_t ev_trace[2] = {};
+    hipEvent_t ev_part[4] = {};         // the most recent trace launch: before its tile cuts, after them, after its horizon tables, after its walk (aob_bake_last_stage_ms)
+    bool parts_timed = false, raster_timed = false;
     hipEvent_t ev_peer = nullptr;       // aob_bake_add_results_from: "everything enqueued on this handle's stream so far", for another handle to wait on
     hipEvent_t ev_ploc[2] = {};         // PLOC rounds: the list length of round r is read back while round r + 1 runs
     bool trace_timed = false;

@@ -167,6 +167,7 @@ static void free_bake(AobBake* b)
     if (b->pinned) hipHostFree(b->pinned);
     for (auto& e : b->ev) if (e) hipEventDestroy(e);
     for (auto& e : b->ev_trace) if (e) hipEventDestroy(e);
+    for (auto& e : b->ev_part) if (e) hipEventDestroy(e);
     for (auto& e : b->ev_ploc) if (e) hipEventDestroy(e);
     if (b->ev_peer) hipEventDestroy(b->ev_peer);
     if (b->stream) hipStreamDestroy(b->stream);
@@ -383,6 +384,7 @@ int aob_bake_create(const AobSceneDesc* scene, const AobOptions* options, AobBak
     AOB_CH(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     for (auto& e : b->ev) AOB_CH(hipEventCreate(&e));
     for (auto& e : b->ev_trace) AOB_CH(hipEventCreate(&e));
+    for (auto& e : b->ev_part) AOB_CH(hipEventCreate(&e));
     for (auto& e : b->ev_ploc) AOB_CH(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     AOB_CH(hipEventCreateWithFlags(&b->ev_peer, hipEventDisableTiming));
     AOB_CH(hipHostMalloc((void**)&b->pinned, 64));
@@ -584,7 +586,11 @@ int aob_bake_build_bvh(AobBake* b)
 int aob_bake_rasterize(AobBake* b, int32_t material)
 {
     DeviceScope scope; AOB_TRY(check_bake(scope, b, material, true));
-    return rasterize_material(b, material, 0, b->materials[material].height);
+    AOB_HIP(hipEventRecord(b->ev[4], b->stream));
+    const int rc = rasterize_material(b, material, 0, b->materials[material].height);
+    AOB_HIP(hipEventRecord(b->ev[5], b->stream));
+    b->raster_timed = rc == AOB_OK;
+    return rc;
 }
 
 int aob_bake_rasterize_rows(AobBake* b, int32_t material, int32_t row_begin, int32_t row_end)
@@ -594,7 +600,11 @@ int aob_bake_rasterize_rows(AobBake* b, int32_t material, int32_t row_begin, int
         set_error("rows [%d, %d) outside the %d-row atlas", row_begin, row_end, b->materials[material].height);
         return AOB_ERR_INVALID_ARGUMENT;
     }
-    return rasterize_material(b, material, row_begin, row_end);
+    AOB_HIP(hipEventRecord(b->ev[4], b->stream));
+    const int rc = rasterize_material(b, material, row_begin, row_end);
+    AOB_HIP(hipEventRecord(b->ev[5], b->stream));
+    b->raster_timed = rc == AOB_OK;
+    return rc;
 }
 
 int aob_bake_trace(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
@@ -844,8 +854,10 @@ int aob_bake_copy_horizon(AobBake* b, int32_t material, uint8_t* dst, uint64_t c
     AOB_HIP(hipMemcpyAsync(perm.data(), m.perm, sizeof(uint32_t) * m.surfel_count, hipMemcpyDeviceToHost, b->stream));
     AOB_HIP(hipStreamSynchronize(b->stream));
     for (size_t si = 0; si + 1 < m.section_offsets.size(); si++)
-        for (uint64_t j = m.section_offsets[si]; j < m.section_offsets[si + 1]; j++)
+        for (uint64_t j = m.section_offsets[si]; j < m.section_offsets[si + 1]; j++) {
+            if (perm[j] >= m.section_offsets[si + 1] - m.section_offsets[si]) { set_error("the trace order of material %d is not a permutation", material); return AOB_ERR_DEVICE; }
             memcpy(dst + (m.section_offsets[si] + perm[j]) * st, hz.data() + j * st, st);
+        }
     return AOB_OK;
 }
 
@@ -980,6 +992,24 @@ int aob_bake_last_trace_ms(AobBake* b, float* ms)
     if (!b->trace_timed) { set_error("no trace has been launched"); return AOB_ERR_INVALID_ARGUMENT; }
     AOB_HIP(hipEventSynchronize(b->ev_trace[1]));
     AOB_HIP(hipEventElapsedTime(ms, b->ev_trace[0], b->ev_trace[1]));
+    return AOB_OK;
+}
+
+int aob_bake_last_stage_ms(AobBake* b, float* out6)
+{
+    DeviceScope scope; AOB_TRY(check_bake(scope, b, 0, false));
+    if (!out6) { set_error("out is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
+    AOB_HIP(hipStreamSynchronize(b->stream));
+    for (int i = 0; i < 6; i++) out6[i] = -1.0f;
+    if (b->bvh_timed) hipEventElapsedTime(&out6[0], b->ev[2], b->ev[3]);
+    if (b->raster_timed) hipEventElapsedTime(&out6[1], b->ev[4], b->ev[5]);
+    if (b->trace_timed) hipEventElapsedTime(&out6[2], b->ev_trace[0], b->ev_trace[1]);
+    if (b->parts_timed) {
+        hipEventElapsedTime(&out6[3], b->ev_part[0], b->ev_part[1]);
+        hipEventElapsedTime(&out6[4], b->ev_part[1], b->ev_part[2]);
+        hipEventElapsedTime(&out6[5], b->ev_part[2], b->ev_part[3]);
+    }
+    (void)hipGetLastError();
     return AOB_OK;
 }
 

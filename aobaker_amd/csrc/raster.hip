@@ -440,6 +440,7 @@ static int ensure_surfel_capacity(AobBake* b, DeviceMaterial& m, uint64_t need)
             e = hipMemcpyAsync(ns, m.surfels, sizeof(AobSurfel) * m.surfel_count, hipMemcpyDeviceToDevice, b->stream);
             if (e == hipSuccess) e = hipMemcpyAsync(ni, m.section_index, sizeof(uint32_t) * m.surfel_count, hipMemcpyDeviceToDevice, b->stream);
             if (e == hipSuccess) e = hipMemcpyAsync(nf, m.frames, sizeof(float4) * 4 * m.surfel_count, hipMemcpyDeviceToDevice, b->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(np, m.perm, sizeof(uint32_t) * m.surfel_count, hipMemcpyDeviceToDevice, b->stream);      // (aob_bake_copy_horizon hands the tables out in surfel order)
         }
         if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
         if (e != hipSuccess) {

@@ -1575,6 +1575,7 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
             p.unit_next = b->trace_unit_next;
             p.tile_cuts = nullptr; p.cut_records = 1u;
             m.tile_cut_tiles = 0; m.tile_cut_records = 0;
+            AOB_HIP(hipEventRecord(b->ev_part[0], s));
             // (16-bit miss counters: a part of at most 65 535 samples)
             if (cut && (uint32_t)o.sample_count / p.parts <= 65535u - 1u) {
                 // the cuts of this launch's tiles (a wavefront per tile; kCutMax entries of four words each)
@@ -1596,6 +1597,7 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
                     if (b->stats.trace_cuts != 2u) b->stats.trace_cuts = 1u;
                 } else p.cut_records = 1u;
             }
+            AOB_HIP(hipEventRecord(b->ev_part[1], s));
             // ---- horizon tables (horizon.hip): where the unit's samples are whole rows of the sampler's grid, at most four of them in one word of the table ----
             p.horizon = nullptr; p.horizon_words = 0u; p.cast_total = nullptr;
             if (horizon_applies(b) && quant == 2 && b->node_count > 0) {
@@ -1614,6 +1616,7 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
                     }
                 }
             }
+            AOB_HIP(hipEventRecord(b->ev_part[2], s));
             // the HBM overflow stack (reserved when the tree was built; a launch whose schedule or mode was set later re-sizes it here)
             const uint32_t overflow = stack_overflow_entries(b, p.tile_cuts != nullptr);
             if (overflow) AOB_TRY(reserve_gstack(b, (uint64_t)grid.x * kWave * overflow));
@@ -1624,6 +1627,8 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
             else launch_masked<AOB_SAMPLER_COSINE>(b->any_mesh_flags, o.use_any_hit, o.accumulate, quant, grid, s, p);
             if (through_acc)
                 hipLaunchKernelGGL(k_acc_to_cells, dim3((uint32_t)((se - sb + 255) / 256)), dim3(256), 0, s, m.frames, sb, se, b->acc_cells, m.results);
+            AOB_HIP(hipEventRecord(b->ev_part[3], s));
+            b->parts_timed = true;
         }
         AOB_HIP(hipGetLastError());
     }

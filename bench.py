@@ -45,16 +45,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# CRC-32 of the resolved float atlas of BASELINE configs[2] (999 698-triangle terrain, seed 3, 2048^2, 256 spp, cosine / any hit /
-# float): what every builder, schedule and host must produce (the cells are oracle-exact, and an any-hit answer does not depend on
-# the tree).  tests/test_gpu_fullsize.py asserts it for bvh_builder 1 and 2; the line carries it as config.image_crc32_expected.
-CONFIG2_IMAGE_CRC32 = 259823415
-# ... and of BASELINE configs[3]'s atlas — the same terrain at 4096^2, 256 spp, what `--gpus N` (N > 1, strong scaling) bakes in N strips: the
-# first real multi-GPU line proves its own image (measured on one GPU in round 5, profiles/r05/bench_4096_single_gpu.json; the strips of a
-# COSINE-sampler bake add up to the single-device cells exactly, tests/test_gpu_configs.py, so every N must print this number).
-CONFIG3_IMAGE_CRC32 = 3632858360
+# CRC-32 of the resolved float atlases of BASELINE configs[2] (999 698-triangle terrain, seed 3, 2048^2, 256 spp, cosine / any hit / float) and
+# configs[3] (the same terrain at 4096^2: what `--gpus N`, N > 1, bakes in N strips).  ORACLE-DERIVED since round 6: tests/golden/make_fullsize_golden.py
+# bakes both atlases completely with the CPU oracle (every texel: 1.07 G / 4.29 G rays) and writes tests/golden/fullsize_crc.json; rounds 4 and 5
+# carried constants the GPU path had produced (they turned out to be these very numbers).  What every builder, schedule, accelerator and host
+# must print: the line carries them as config.image_crc32_expected, tests/test_gpu_fullsize.py and tests/test_gpu_configs.py assert them.
+def _golden_crc(config, fallback):
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "fullsize_crc.json")) as f:
+            return int(json.load(f)[config]["image_crc32"])
+    except Exception:
+        return fallback
+
+
+CONFIG2_IMAGE_CRC32 = _golden_crc("2", 259823415)
+CONFIG3_IMAGE_CRC32 = _golden_crc("3", 3632858360)
 # what k_trace's time depends on: the kernel, and the builder whose tree it walks
-KERNEL_SOURCES = ("aobaker_amd/csrc/trace.hip", "aobaker_amd/csrc/aob_math.h", "aobaker_amd/csrc/aob_internal.h", "aobaker_amd/csrc/bvh_build.hip")
+KERNEL_SOURCES = ("aobaker_amd/csrc/trace.hip", "aobaker_amd/csrc/aob_math.h", "aobaker_amd/csrc/aob_internal.h", "aobaker_amd/csrc/bvh_build.hip",
+                  "aobaker_amd/csrc/horizon_kernel.h", "aobaker_amd/csrc/horizon.hip")
 
 
 def parse_args():
@@ -273,7 +281,7 @@ def main():
 
     baker = Baker(flat, opts)           # uploads the scene: inputs resident in HBM from here on
     cells = aod.alias_results(baker, 0, as_float=True) if world > 1 else None
-    trace_ms, step_ms, gather_ms, build_raster_ms = [], [], [], []
+    trace_ms, step_ms, gather_ms, build_raster_ms, stage_hist = [], [], [], [], []
     counts = {}
     bounds = aod.equal_rows(H, world)   # every rank rasterises and traces its own strip of texel rows; the BVH is built by all
 
@@ -308,6 +316,7 @@ def main():
         if world == 1:
             mine = (time.perf_counter() - t) * 1e3
         trace_ms.append(baker.last_trace_ms())
+        stage_hist.append(baker.last_stage_ms())           # (HIP events on the library's stream: build, rasterisation, and the trace's tile cuts / horizon tables / walk)
         step_ms.append(mine)
         counts["mine"] = n
 
@@ -329,6 +338,7 @@ def main():
             history.append({"rows": list(bounds), "rank_ms": [round(v, 3) for v in ms]})
             bounds = aod.rebalance_rows(bounds, ms, H)
     trace_ms.clear()
+    stage_hist.clear()
     step_ms.clear()
     gather_ms.clear()
     build_raster_ms.clear()
@@ -344,6 +354,11 @@ def main():
         elapsed = float(t.item())
 
     stats = baker.stats()
+
+    def stage_mean(name):
+        """mean over the timed steps of one stage's HIP-event time (the same clock for every stage: the library's stream)"""
+        v = [h[name] for h in stage_hist if h.get(name) is not None]
+        return sum(v) / len(v) if v else 0.0
     # every buffer one trace launch reads, once (the compulsory footprint the fabric-side traffic is read against)
     footprint = None
     try:
@@ -375,18 +390,28 @@ def main():
         rank_ms = [float(v.item()) for v in every]
         # every rank's own stages of the last step (each builds the whole tree — redundantly — and rasterises and traces its strip) and what
         # it spent in the gather: the redundant build's share of a rank's step is visible here, not inferred
-        mine4 = torch.tensor([stats.ms_bvh_build, max(0.0, sum(build_raster_ms) / len(build_raster_ms) - stats.ms_bvh_build), sum(trace_ms) / len(trace_ms), sum(gather_ms) / max(1, len(gather_ms))],
+        mine4 = torch.tensor([stage_mean("bvh_build"), stage_mean("rasterize"), sum(trace_ms) / len(trace_ms), sum(gather_ms) / max(1, len(gather_ms))],
                              dtype=torch.float64, device=comm_device)
         every4 = [torch.zeros(4, dtype=torch.float64, device=comm_device) for _ in range(world)]
         dist.all_gather(every4, mine4)
         rank_stages = [[float(x) for x in v.tolist()] for v in every4]
     else:
         counts["surfels"] = counts["mine"]
-        rank_stages = [[stats.ms_bvh_build, max(0.0, sum(build_raster_ms) / len(build_raster_ms) - stats.ms_bvh_build), sum(trace_ms) / len(trace_ms), 0.0]]
+        rank_stages = [[stage_mean("bvh_build"), stage_mean("rasterize"), sum(trace_ms) / len(trace_ms), 0.0]]
     total_rays = counts["surfels"] * args.spp                  # all ranks together
     ms_per_step = elapsed / args.steps * 1e3
     value = total_rays / (elapsed / args.steps)
-    kernel_ms = sum(trace_ms) / len(trace_ms)
+    trace_total_ms = sum(trace_ms) / len(trace_ms)
+    # the dominant kernel alone: k_trace (the walk); the tile cuts and the horizon tables — kernels of their own inside the trace stage — beside it
+    kernel_ms = stage_mean("walk") or trace_total_ms
+    horizon_ms, cuts_ms = stage_mean("horizon"), stage_mean("tile_cuts")
+    rays_cast = int(stats.rays_cast) if stats.trace_horizon == 1 else None
+    hz_tables = None
+    if rank == 0 and world == 1 and rays_cast is not None:
+        try:
+            hz_tables = baker.horizon(0)
+        except Exception as e:
+            print(f"bench: horizon tables not read back: {e!r}", file=sys.stderr)
     baker.close()
     BakeEngine.Dispose()
 
@@ -409,11 +434,11 @@ def main():
             visits = visits_per_ray(flat, opts, W, H)
         requested = None
         try:
-            requested = requested_per_ray(flat, opts, W, H)
+            requested = requested_per_ray(flat, opts, W, H, tables=hz_tables)
         except Exception as e:                       # (a report, never a reason to lose the bench line)
             requested = None
             print(f"bench: requested_per_ray failed: {e!r}", file=sys.stderr)
-        roofline = roofline_record(opts, args, W, H, world, visits, my_rays, kernel_ms, requested, footprint)
+        roofline = roofline_record(opts, args, W, H, world, visits, my_rays, kernel_ms, requested, footprint, rays_cast)
         line = {
             "metric": "AO rays/sec", "value": value, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -430,6 +455,11 @@ def main():
                        "surfels": counts["surfels"], "rays": total_rays, "sharding": f"strips of texel rows x{world}",
                        "rows": [[bounds[r], bounds[r + 1]] for r in range(world)],
                        "bvh_nodes": stats.node_count, "bvh_depth": stats.bvh_depth,
+                       # horizon tables (AobOptions::trace_horizon, horizon.hip): of this rank's rays, how many the trace kernel cast — the rest sit in cells of the
+                       # sampler's grid that no triangle can reach (proven per surfel from the tree, inside the timed step) and score as unoccluded without a walk;
+                       # `value` counts every ray the bake resolved, as the metric defines it (covered surfels x spp), the image is the oracle's
+                       "horizon_tables": ({"rays_cast": rays_cast, "rays_cast_share": round(rays_cast / max(1, my_rays), 4), "rays_resolved_by_tables": my_rays - rays_cast,
+                                           "table_kernel_ms": round(horizon_ms, 3), "cast_rays_per_s": round(rays_cast / (kernel_ms * 1e-3), 1)} if rays_cast is not None else None),
                        "image_crc32": image_crc,
                        "image_crc32_expected": (CONFIG2_IMAGE_CRC32 if (W, H, args.spp, args.grid) == (2048, 2048, 256, 708) else
                                                 CONFIG3_IMAGE_CRC32 if (W, H, args.spp, args.grid) == (4096, 4096, 256, 708) else None),
@@ -437,10 +467,12 @@ def main():
                                          bool(image_crc == (CONFIG2_IMAGE_CRC32 if W == 2048 else CONFIG3_IMAGE_CRC32)),
                        "host": ("REHEARSAL: ranks share devices, strips gathered with gloo through host memory" if rehearsal else
                                 "python ranks, one process per GPU, torch.distributed nccl (= RCCL) point-to-point gather to rank 0")},
-            "stage_ms": {"bvh_build": round(stats.ms_bvh_build, 3), "trace_kernel": round(kernel_ms, 3),
+            "stage_ms": {"bvh_build": round(stage_mean("bvh_build"), 3), "rasterize": round(stage_mean("rasterize"), 3), "trace": round(trace_total_ms, 3),
+                         "of_which_trace": {"tile_cuts": round(cuts_ms, 3), "horizon_tables": round(horizon_ms, 3), "k_trace": round(kernel_ms, 3)},
+                         "trace_kernel": round(kernel_ms, 3),
                          "rank_build_raster_trace": [round(v, 3) for v in rank_ms],
-                         # per rank: the tree's build (HIP events, last step), the rasterisation of its strip (host clock up to the rasteriser's read-back,
-                         # less the build), its trace kernel (HIP events, mean), and the host time it spent in the gather (N > 1)
+                         # per rank, means over the timed steps of the library's own HIP events: the tree's build, the rasterisation of its strip, its trace stage
+                         # (tile cuts + horizon tables + k_trace), and the host time it spent in the gather (N > 1)
                          "rank_bvh_build": [round(v[0], 3) for v in rank_stages], "rank_rasterize": [round(v[1], 3) for v in rank_stages],
                          "rank_trace_kernel": [round(v[2], 3) for v in rank_stages],
                          "gather_ms": round(rank_stages[0][3], 3) if world > 1 else None,
@@ -513,7 +545,7 @@ def counter_key(opts, args, W, H, world):
     """What a counter record must have been measured on to describe this run: the line carries it (roofline.counter_key) and
     tools/pmc_record.py copies it from the line of the PROFILED run into the record — never from literals."""
     return {"atlas": [W, H], "spp": args.spp, "grid": args.grid, "n_gpus": world, "bvh_width": opts.bvh_width, "bvh_quantised": opts.bvh_quantised,
-            "bvh_builder": opts.bvh_builder, "trace_cut": opts.trace_cut}
+            "bvh_builder": opts.bvh_builder, "trace_cut": opts.trace_cut, "trace_horizon": opts.trace_horizon}
 
 
 def counter_record(opts, args, W, H, world, path=None):
@@ -532,16 +564,16 @@ def counter_record(opts, args, W, H, world, path=None):
     return rec, None
 
 
-L1_PEAK_GBS = 64.0 * 256 * 2.4           # the vector L1 returns 64 B per clock and CU: 256 CUs at 2.4 GHz = 39.3 TB/s (the floor tools/l1_probe.hip measures:
-                                         # a wave64 16-byte-per-lane load takes 16 CU cycles whatever its lanes touch)
 L2_PEAK_GBS = 34500.0                    # MI355X_MICROARCH.md "L2 (per XCD)": 34.5 TB/s aggregate
 
 
-def requested_per_ray(flat, opts, W, H, tiles=96):
+def requested_per_ray(flat, opts, W, H, tiles=96, tables=None):
     """What ONE ray asks the vector-memory path for, counted by the oracle walking the product's schedule on `tiles` random tiles of the trace
     order: every ray of a tile tests its tile's cut (orc_tile_cut_reach: k_tile_cuts' rule) and walks below the entries it entered
     (orc_cut_walk).  Returns node fetches, triangle fetches, entries tested / entered per ray — the counts the kernel's own loop counters
-    give (tools/time_trace.py on the -DAOB_TRACE_STATS build; profiles/): the oracle's are live, on this very run's scene and options."""
+    give (tools/time_trace.py on the -DAOB_TRACE_STATS build; profiles/): the oracle's are live, on this very run's scene and options.
+    `tables`: the horizon tables the run's trace used (Baker.horizon: free columns per surfel and row, surfel order) — then only the rays the
+    kernel CAST are walked, and the figures are per cast ray."""
     import numpy as np
     native_oracle()
     from oracle import oracle as orc
@@ -553,7 +585,12 @@ def requested_per_ray(flat, opts, W, H, tiles=96):
     surfels, _ = orc.rasterize(flat.desc, 0, opts)
     x, y = surfels["texel_x"].astype(np.int64), surfels["texel_y"].astype(np.int64)
     key = ((y // 8) * ((W + 7) // 8) + x // 8) * 64 + (y % 8) * 8 + x % 8
-    ordered = surfels[np.argsort(key, kind="stable")]
+    order = np.argsort(key, kind="stable")
+    ordered = surfels[order]
+    sx = int(np.floor(np.sqrt(opts.sample_count))); sy = opts.sample_count // max(1, sx)
+    free_all = None
+    if tables is not None and len(tables) == len(surfels) and sx * sy == opts.sample_count:
+        free_all = np.minimum(tables[order][:, :sy].astype(np.int64), sx)
     nt = len(ordered) // 64
     picks = np.random.default_rng(7).choice(nt, size=min(tiles, nt), replace=False)
     reach = float((np.float32(opts.ray_tmax) + np.float32(abs(opts.ray_bias))) * np.float32(1.01))
@@ -561,6 +598,13 @@ def requested_per_ray(flat, opts, W, H, tiles=96):
     for t in picks:
         sub = np.ascontiguousarray(ordered[64 * t:64 * t + 64])
         rays = np.ascontiguousarray(orc.generate_rays(sub, None, opts, W))
+        if free_all is not None:
+            # sample i = (cx, cy) = (i % sx, i // sx) of a surfel is cast iff cx >= free[cy]
+            f = free_all[64 * t:64 * t + 64]
+            cast = (np.arange(sx)[None, None, :] >= f[:, :, None]).reshape(len(sub), sx * sy)
+            rays = np.ascontiguousarray(rays.reshape(len(sub), -1)[:, :sx * sy][cast])
+            if len(rays) == 0:
+                continue
         pos = sub["position"].astype(np.float32)
         pmin, pmax = pos.min(axis=0), pos.max(axis=0)
         pull = np.float32(0.25) * (pmax - pmin)
@@ -569,11 +613,12 @@ def requested_per_ray(flat, opts, W, H, tiles=96):
         rays_n += st.rays; inner += st.inner_visits; leaf += st.leaf_visits; tested += st.entries_tested; entered += st.mask_bits
     r = float(max(1, rays_n))
     return {"node_fetches": inner / r, "triangle_fetches": leaf / r, "cut_entries_tested": tested / r, "cut_entries_entered": entered / r,
+            "per": "cast ray (the rays the horizon tables left to the walk)" if free_all is not None else "ray",
             "counted_on": f"{len(picks)} random tiles of 64 surfels ({rays_n} rays), the oracle walking the tiles' cuts (32 entries; the kernel tests fewer: its "
                           "records are culled by sample part, which changes no walk)"}
 
 
-def roofline_record(opts, args, W, H, world, visits, my_rays, kernel_ms, requested=None, footprint=None):
+def roofline_record(opts, args, W, H, world, visits, my_rays, kernel_ms, requested=None, footprint=None, rays_cast=None):
     """The trace kernel against its roofs, every fraction physically bounded (<= 1):
       frac / achieved / peak   the BINDING roof: the CU's vector-memory (L1) request path — bytes the kernel's lanes ask it for (node, triangle,
                                surfel-record and frame fetches, counted live by the oracle walking the product's schedule) / kernel time /
@@ -592,14 +637,19 @@ def roofline_record(opts, args, W, H, world, visits, my_rays, kernel_ms, request
     algorithmic = my_rays * b_ray / seconds / 1e9
     rec, why = counter_record(opts, args, W, H, world)
     # ---- the L1 request path: what the lanes ask for ----
+    walked = rays_cast if rays_cast is not None else my_rays          # the rays k_trace walked (horizon tables: the cast ones)
     req = None
     if requested:
-        # per ray: 64 B per node fetched below the cut, 48 B per triangle fetched, 16 B of the surfel's record when a lane takes the ray off the
-        # queue, 48 B of its frame when the sample is generated, the 8-B cell per surfel
-        b_req = 64.0 * requested["node_fetches"] + 48.0 * requested["triangle_fetches"] + 16.0 + 48.0 + 8.0 / args.spp
+        # per walked ray: 64 B per node fetched below the cut, 48 B per triangle fetched, 16 B of the surfel's record when a lane takes the ray off the
+        # queue, 48 B of its frame (+ 4 B of its horizon-table word) when the sample is generated, the 8-B cell per surfel and sample part
+        b_req = 64.0 * requested["node_fetches"] + 48.0 * requested["triangle_fetches"] + 16.0 + 48.0 + (4.0 if rays_cast is not None else 0.0) + 8.0 / args.spp
         req = {"bytes_per_ray": round(b_req, 1), "per_ray": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in requested.items()},
-               "GBps": round(my_rays * b_req / seconds / 1e9, 1)}
-    l1_frac = round(req["GBps"] / L1_PEAK_GBS, 4) if req else None
+               "rays_walked": walked, "GBps": round(walked * b_req / seconds / 1e9, 1),
+               "counted_by": "the oracle walking the product's schedule on sampled tiles (the rays the run's own horizon tables left); the kernel's own loop counters "
+                             "(-DAOB_TRACE_STATS build) are in profiles/: roofs/loop_counters.jsonl of the round's final profile"}
+    cus = 256
+    l1_peak = 64.0 * cus * 2.4
+    l1_frac = round(req["GBps"] / l1_peak, 4) if req else None
     l2 = fabric = None
     roofs = None
     if rec:
@@ -620,23 +670,35 @@ def roofline_record(opts, args, W, H, world, visits, my_rays, kernel_ms, request
         refetch = round(fabric["bytes_per_launch"] / footprint["bytes"], 1)
     fracs = {"l1_request_path": l1_frac, "l2": (l2 or {}).get("frac"), "fabric": (fabric or {}).get("frac")}
     known = {k: v for k, v in fracs.items() if v is not None}
-    binding = max(known, key=known.get) if known else None
-    return {"bound": "vmem", "bound_is": "the memory roof nearest to this kernel: the CU's vector-memory request path (TA / L1 / TD) — of the byte-rate fractions below the largest.  "
-                                         "HBM is far (fabric).  What the slope builds of THIS kernel name as its binding unit — instructions, not bytes — is in `roofs` "
-                                         "(round 5: the vector ALU, 0.72 of its issue slots, the vector-memory path 0.58: `instruction_roof`)",
-            "instruction_roof": ({"bound": roofs.get("bound"), "frac": roofs.get("frac"), "valu_frac": (roofs.get("valu") or {}).get("frac"),
-                                  "vmem_frac": (roofs.get("vmem") or {}).get("frac")} if roofs else None),
-            "achieved": (req or {}).get("GBps"), "peak": round(L1_PEAK_GBS, 1), "unit": "GB/s", "frac": l1_frac,
-            "frac_is": "bytes the kernel's lanes request from the vector L1 / kernel time / (64 B x 256 CUs x 2.4 GHz); <= 1 by construction",
-            "byte_rate_fractions": fracs, "largest_byte_rate_fraction": binding,
+    largest = max(known, key=known.get) if known else None
+    # WHICH unit binds is a measurement of this kernel source (the slope builds and class counters of profiles/k_trace_counters.json): named only when
+    # the committed record is of this source and configuration
+    bound = (roofs or {}).get("bound")
+    inst = ({"bound": roofs.get("bound"), "frac": roofs.get("frac"), "valu_frac": (roofs.get("valu") or {}).get("frac"),
+             "vmem_frac": (roofs.get("vmem") or {}).get("frac")} if roofs else None)
+    return {"bound": bound,
+            "bound_is": ("the unit the slope builds and class counters of THIS kernel source name (profiles/k_trace_counters.json): "
+                         + (f"{bound}, {roofs.get('frac')} of its issue slots" if roofs else "no record of this kernel source and configuration is committed: not named")
+                         + " — this walk is bound by instruction issue, not by bytes; the byte-rate fractions (L1 request path, L2, fabric / HBM) are beside it"),
+            "instruction_roof": inst,
+            # the contract's byte figures: `achieved` / `peak` / `frac` are the LARGEST byte-rate fraction's — the CU's vector-memory (L1) request path —
+            # and `hbm_frac` is the one the north star asks for: what leaves the L2s against HBM's 8 TB/s
+            "achieved": (req or {}).get("GBps"), "peak": round(l1_peak, 1), "unit": "GB/s", "frac": l1_frac,
+            "frac_is": f"bytes the kernel's lanes request from the vector L1 / k_trace's time / (64 B per clock and CU x {cus} CUs x 2.4 GHz, the rate tools/l1_probe.hip measures)",
+            "hbm_frac": (fabric or {}).get("frac"),
+            "hbm_frac_is": "fabric-side bytes per launch (FETCH_SIZE + WRITE_SIZE, calibrated) / k_trace's time / 8 TB/s: requests leaving the L2s, Infinity-Cache (MALL) hits "
+                           "INCLUDED — an upper bound on what HBM served; the guide's gfx950 caveat (FETCH_SIZE may count 64-byte requests as 32) would at most double it; "
+                           "null when the committed counters are of another kernel source or configuration",
+            "byte_rate_fractions": fracs, "largest_byte_rate_fraction": largest,
             "requested": req, "l2": l2, "fabric": fabric,
             "traffic": (fabric or {}).get("bytes_per_launch"),
             "traffic_is": "fabric-side bytes per launch (see fabric.note); null when the committed counters are of another kernel source or configuration",
             "compulsory": footprint, "refetch_ratio": refetch,
             "refetch_ratio_is": "fabric-side bytes / the bytes of every buffer the launch reads once: how many times the L2s fetched the working set",
             "algorithmic_GBps": round(algorithmic, 1), "algorithmic_frac": round(algorithmic / HBM_PEAK_GBS, 4),
-            "algorithmic_frac_is": "SURVEY §8(d): 64 B x node visits of the oracle's walk from the root + 40 / spp per ray, against HBM peak — a cache-oblivious demand "
-                                   "figure that may exceed 1; not a roofline fraction",
+            "algorithmic_frac_is": "SURVEY §8(d): 64 B x node visits of the oracle's walk from the root + 40 / spp per ray, x EVERY ray of the bake, / k_trace's time / HBM peak — "
+                                   "a cache-oblivious demand figure that may exceed 1 (the kernel starts below tile cuts, and with horizon tables does not walk most rays at all); "
+                                   "not a roofline fraction",
             "bytes_per_ray_algorithmic": round(b_ray, 1),
             "node_visits_per_ray_from_the_root": round(n_inner + n_leaf, 3), "inner_visits_per_ray_from_the_root": round(n_inner, 3), "leaf_visits_per_ray_from_the_root": round(n_leaf, 3),
             # the two instruction-rate roofs from the committed measurements of THIS kernel source (profiles/k_trace_counters.json): which unit,
@@ -646,7 +708,7 @@ def roofline_record(opts, args, W, H, world, visits, my_rays, kernel_ms, request
             "valu_wave_instr_per_ray": (rec or {}).get("valu_wave_instr_per_ray"), "vmem_wave_instr_per_ray": (rec or {}).get("vmem_wave_instr_per_ray"),
             "counters": (rec or {}).get("provenance") or why,
             "kernel": "k_trace", "kernel_ms": round(kernel_ms, 3), "kernel_source_sha256_16": kernel_source_hash(),
-            "rays_per_launch": my_rays, "counter_key": counter_key(opts, args, W, H, world)}
+            "rays_per_launch": my_rays, "rays_walked_per_launch": walked, "counter_key": counter_key(opts, args, W, H, world)}
 
 
 def host_cores():

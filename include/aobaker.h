@@ -397,6 +397,10 @@ int aob_bake_copy_horizon(AobBake* bake, int32_t material, uint8_t* dst, uint64_
 /* Diagnostics of the horizon-table kernel since the bake was created (or last cleared), summed over its tiles: out16[0..8] = walk rounds, child
  * boxes measured, near triangles, middle-distance leaves, tiles that got no tables (lists full), tiles, clock ticks of the kernel's three phases. */
 int aob_bake_horizon_counters(AobBake* bake, unsigned long long* out16, int clear);
+/* HIP-event times of the handle's most recent stages, in ms (-1: the stage has not run through its staged entry point): out6[0] the tree's build,
+ * [1] the rasterisation (aob_bake_rasterize / _rows: host read-backs included), [2] the trace (everything aob_bake_trace enqueued), and of the
+ * trace's most recent LAUNCH [3] its tile cuts, [4] its horizon tables, [5] its walk (k_trace).  Waits for the stream. */
+int aob_bake_last_stage_ms(AobBake* bake, float* out6);
 int aob_bake_surfel_count(AobBake* bake, int32_t material, uint64_t* count);
 int aob_bake_copy_surfels(AobBake* bake, int32_t material, AobSurfel* dst, uint64_t capacity);
 int aob_bake_copy_results(AobBake* bake, int32_t material, AobResult* dst, uint64_t capacity);

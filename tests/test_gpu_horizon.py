@@ -88,7 +88,7 @@ def test_open_sky_is_skipped_and_a_closed_room_is_not(engine, orc):
 
 def test_the_default_uses_tables_from_128_samples_on(engine, orc):
     flat = FlatScene(scenes.terrain_scene(grid=96, atlas=128))
-    for spp, want in ((64, 0), (100, 0), (144, 1), (256, 1), (257, 0)):
+    for spp, want in ((64, 0), (100, 0), (144, 0), (256, 1), (257, 0), (1024, 1)):      # (144 = 12 x 12: three rows a part do not fit a table word)
         _, st, _, _ = bake_cells(flat, options(orc, spp, use_any_hit=1, accumulate=capi.ACCUMULATE_FLOAT), 0)
         assert st.trace_horizon == want, (spp, st.trace_horizon)
     o = options(orc, 256, use_any_hit=1)
