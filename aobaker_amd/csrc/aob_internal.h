@@ -128,6 +128,7 @@ struct AobBake {
     bool      any_mesh_flags = false;
     int cu_count = 256;
     uint64_t gstack_words = 0;
+    bool horizon_diag = false;          // k_horizon adds its diagnostics to horizon_counters (off by default: the atomics are slow)
     unsigned long long* horizon_counters = nullptr;   // k_horizon's diagnostics [0..8] (rounds, box tests, near triangles, middle leaves, tiles given up, tiles, clock ticks of its three phases), then from [16] one word per material: the samples k_trace cast under horizon tables
     unsigned long long* acc_cells = nullptr;   // 2 x 64-bit exact sums per result cell of the largest material: where the sample parts of a tile
     uint64_t acc_cells_count = 0;              // add up when the cells are floats that hold fractions (trace.hip; sized at creation, kept zero)

@@ -832,6 +832,7 @@ int aob_bake_horizon_counters(AobBake* b, unsigned long long* out16, int clear)
     if (!out16) { set_error("out is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
     AOB_HIP(hipMemcpyAsync(out16, b->horizon_counters, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, b->stream));
     if (clear) AOB_HIP(hipMemsetAsync(b->horizon_counters, 0, sizeof(unsigned long long) * 16, b->stream));
+    if (clear == 2) b->horizon_diag = true;               // from here on k_horizon counts (it does not by default: the atomics cost more than the kernel)
     AOB_HIP(hipStreamSynchronize(b->stream));
     return AOB_OK;
 }

@@ -8,6 +8,7 @@
 namespace aob {
 
 static constexpr int kHzWave = 64;
+static constexpr int kHzGroups = 8;              // groups of 64 / kHzGroups consecutive origins a middle-distance leaf is measured against (16: tighter, twice the work)
 static constexpr int kHzSectors = 32;            // sectors of the tile's horizon H
 static constexpr int kHzOpenCap = 512;           // open nodes of the walk (LDS); a node that does not fit raises H by its own box instead
 static constexpr int kHzNearCap = 384;           // near triangles per tile; more: the tile gets no culling (every cell blocked)
@@ -25,6 +26,9 @@ typedef const float* hz_const_floats;
 #define HZ_CLOCK() ((unsigned long long)__builtin_readcyclecounter())
 #define HZ_SCALAR_POINTER(p) asm volatile("" : "+s"(p))
 typedef const __attribute__((address_space(4))) float* hz_const_floats;
+#endif
+#ifndef AOB_HZ_SKIP
+#define AOB_HZ_SKIP 0                        // measurement builds (tools/build_variants.py): bit 0 no near phase, bit 1 no arcs, bit 2 no middle-leaf measuring, bit 3 no walk at all
 #endif
 #define HZ_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 
@@ -123,12 +127,13 @@ void k_horizon(HorizonParams p)
     float (* const arcs)[12] = scratch.arcs;         // phase C: b, n, n x a, b x n of every arc (a = the arc before's b)
     __shared__ uint32_t near_tri[kHzNearCap];
     __shared__ uint32_t H[kHzSectors];               // bits of (sin E + 2): positive floats order like integers
-    __shared__ float grp[16][8];                     // the boxes of 16 groups of four origins, in the tile's frame: lo xyz, hi xyz, valid
+    __shared__ float grp[kHzGroups][8];              // the boxes of the tile's groups of consecutive origins, in the tile's frame: lo xyz, hi xyz, valid
     __shared__ uint32_t table[CMAX * kHzWave / (T16 ? 2 : 1)];    // local tables: [column][lane] = rows blocked FROM that column (cumulated at the end); T16: 16 rows, two lanes a word
 
     const uint32_t lane = threadIdx.x;
     const uint64_t k = p.begin + (uint64_t)blockIdx.x * kHzWave + lane;
     const int K = p.K, C = p.C;
+    if (AOB_HZ_SKIP & 16) return;
 
     // ---- the surfel and its frame's dual basis ----
     f3 P = make_f3(0.f, 0.f, 0.f), Xd = P, Nd = P, Zd = P, Nw = P;
@@ -155,6 +160,7 @@ void k_horizon(HorizonParams p)
         }
     }
     const uint64_t framed_m = __ballot(framed);
+    if (AOB_HZ_SKIP & 32) { if (framed && k == 0xffffffffffull) p.out[0] = 1; return; }
     auto write_out = [&](const uint32_t* fr) {          // fr: stride / 4 words of free counts
         if (k < p.end) {
             uint32_t* dst = (uint32_t*)(p.out + k * (uint64_t)p.stride);
@@ -201,13 +207,13 @@ void k_horizon(HorizonParams p)
         float ghi[3] = { framed ? fP.x + slack : -big, framed ? fP.y + slack : -big, framed ? fP.z + slack : -big };
 #pragma unroll
         for (int q = 0; q < 3; q++) {
-            glo[q] = fminf(glo[q], __shfl_xor(glo[q], 1)); glo[q] = fminf(glo[q], __shfl_xor(glo[q], 2));
-            ghi[q] = fmaxf(ghi[q], __shfl_xor(ghi[q], 1)); ghi[q] = fmaxf(ghi[q], __shfl_xor(ghi[q], 2));
+            for (int off = 1; off < kHzWave / kHzGroups; off <<= 1) { glo[q] = fminf(glo[q], __shfl_xor(glo[q], off)); ghi[q] = fmaxf(ghi[q], __shfl_xor(ghi[q], off)); }
         }
-        if ((lane & 3u) == 0u) {
-            float* g = grp[lane >> 2];
+        constexpr uint32_t per = kHzWave / kHzGroups;
+        if ((lane & (per - 1u)) == 0u) {
+            float* g = grp[lane / per];
             g[0] = glo[0]; g[1] = glo[1]; g[2] = glo[2]; g[3] = ghi[0]; g[4] = ghi[1]; g[5] = ghi[2];
-            g[6] = ((framed_m >> lane) & 0xfull) ? 1.0f : 0.0f; g[7] = 0.0f;
+            g[6] = ((framed_m >> lane) & ((1ull << per) - 1ull)) ? 1.0f : 0.0f; g[7] = 0.0f;
         }
     }
     const f3 fc = make_f3(0.5f * (flo.x + fhi.x), 0.5f * (flo.y + fhi.y), 0.5f * (flo.z + fhi.z));
@@ -218,6 +224,7 @@ void k_horizon(HorizonParams p)
     const float reach2 = p.reach * p.reach;                    // (inf * inf = inf)
     const f3 qo = make_f3(p.quant_frame[0], p.quant_frame[1], p.quant_frame[2]), qs = make_f3(p.quant_frame[3], p.quant_frame[4], p.quant_frame[5]);
 
+    if (AOB_HZ_SKIP & 64) { if (r_near2 + r_mid2 + fc.x + te.x + aXt.x + qo.x + qs.x == 12345.678f) p.out[0] = 1; return; }
     if (lane < (uint32_t)kHzSectors) H[lane] = __float_as_uint(1.0f);          // sin E = -1: nothing blocked
     for (int c = 0; c < C; c++) { if (!T16 || lane < 32u) table[c * (kHzWave / (T16 ? 2 : 1)) + (int)lane] = 0u; }
     if (lane == 0) { open_ref[0] = 0x80000000u; open_key[0] = 0xffffffffu; }       // the root, as a near node: opened whatever the horizon
@@ -255,7 +262,7 @@ void k_horizon(HorizonParams p)
             if (lane < 32u && ((lane - f) & 31u) < n) atomicMax(&H[lane], t);
         }
     };
-    while (open_n > 0) {
+    while (open_n > 0 && !(AOB_HZ_SKIP & 8)) {
         if (++rounds > kHzMaxRounds) break;
         {
             uint32_t hv = H[lane & 31u];
@@ -373,12 +380,12 @@ void k_horizon(HorizonParams p)
             }
         }
         if (give_up) break;
-        // ---- the round's middle-distance leaves, 16 at a time: four lanes a leaf, each lane its vertices against four of the 16 groups' boxes ----
+        // ---- the round's middle-distance leaves, 16 at a time: four lanes a leaf, each lane its vertices against a quarter of the groups' boxes ----
         n_leaves += (unsigned long long)n_leafq;
-        if (n_leafq) {
+        if (n_leafq && !(AOB_HZ_SKIP & 4)) {
             HZ_SYNC();
             for (int base = 0; base < n_leafq; base += 16) {
-                const int j = base + (int)(lane >> 2), g0i = (int)(lane & 3u) * 4;
+                const int j = base + (int)(lane >> 2), g0i = (int)(lane & 3u) * (kHzGroups / 4);
                 const bool on = j < n_leafq;
                 float el = -2.0f;
                 HzLeaf q; q.ref = 0u; q.key = 0u;
@@ -391,7 +398,7 @@ void k_horizon(HorizonParams p)
                         const f3 f = make_f3(dot(Xt, make_f3(w.x, w.y, w.z)), dot(Nt, make_f3(w.x, w.y, w.z)), dot(Zt, make_f3(w.x, w.y, w.z)));
                         const float sl = 2e-6f * (fabsf(f.x) + fabsf(f.y) + fabsf(f.z));
 #pragma unroll
-                        for (int gi = 0; gi < 4; gi++) {
+                        for (int gi = 0; gi < kHzGroups / 4; gi++) {
                             const float* gb = grp[g0i + gi];
                             const float lx = f.x - gb[3] - sl, hx = f.x - gb[0] + sl, lz = f.z - gb[5] - sl, hz = f.z - gb[2] + sl;
                             const float bh = f.y - gb[1] + sl;               // the highest the vertex stands over an origin of the group
@@ -451,7 +458,7 @@ void k_horizon(HorizonParams p)
     };
 
     // ---- phase B: the near triangles, every surfel in its own frame ----
-    for (int i = 0; i < near_n; i++) {
+    for (int i = 0; i < ((AOB_HZ_SKIP & 1) ? 0 : near_n); i++) {
         // (a wave-uniform address through the constant address space: the vertices come in by scalar loads)
         const uint32_t tri = (uint32_t)__builtin_amdgcn_readfirstlane((int)near_tri[i]);
         const float4* tp = p.leaf_tris + 3ull * tri;
@@ -558,7 +565,7 @@ void k_horizon(HorizonParams p)
             const float* L = arcs[kHzWave - 1];
             local(make_f3(L[0], L[1], L[2]), cs_a, th_a);            // arc 0 starts where arc 63 ends
         }
-        for (int i = 0; i < kHzWave; i++) {
+        for (int i = 0; i < ((AOB_HZ_SKIP & 2) ? 0 : kHzWave); i++) {
             const float* L = arcs[i];
             const f3 bb = make_f3(L[0], L[1], L[2]), nn = make_f3(L[3], L[4], L[5]);
             float cs_b, th_b;

@@ -606,26 +606,42 @@ void k_trace(TraceParams p)
     // is used, behind an empty asm, so that no per-lane address is kept, and spilt, across the walk)
     const __amdgpu_buffer_rsrc_t hz_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.horizon, 0, 0xffffffff, 0x00020000);
     const uint32_t hz_unit = (uint32_t)(wave_first * (uint64_t)p.horizon_words + (hz_cy0 >> 2)) * 4u;
-    auto hz_cum = [&](uint32_t& skipped) -> uint32_t {
+    // (up to eight rows: two words of the table.  cum_lo / cum_hi: byte r = cells cast in rows 0 .. r (rows 0 - 3 / 4 - 7); the list's length is the last byte of cum_hi)
+    auto hz_cum = [&](uint32_t& skipped, uint32_t& cum_hi) -> uint32_t {
         uint32_t lo = lane;
         asm volatile("" : "+v"(lo));
-        uint32_t w = __builtin_amdgcn_raw_buffer_load_b32(hz_rsrc, lo * (p.horizon_words * 4u), hz_unit, 0) >> ((hz_cy0 & 3u) << 3);
         const uint32_t sx = (uint32_t)p.grid.sx;
+        uint32_t w0 = __builtin_amdgcn_raw_buffer_load_b32(hz_rsrc, lo * (p.horizon_words * 4u), hz_unit, 0) >> ((hz_cy0 & 3u) << 3);
+        uint32_t w1 = 0u;
+        if (hz_rows > 4u) w1 = __builtin_amdgcn_raw_buffer_load_b32(hz_rsrc, lo * (p.horizon_words * 4u) + 4u, hz_unit, 0);      // (wave-uniform: eight-row units start on a word)
         uint32_t cum = 0u, run = 0u;
         skipped = 0u;
 #pragma unroll
         for (uint32_t r = 0; r < 4u; r++) {
-            const uint32_t f = r < hz_rows ? min((w >> (8u * r)) & 0xffu, sx) : sx;
+            const uint32_t f = r < hz_rows ? min((w0 >> (8u * r)) & 0xffu, sx) : sx;
             if (r < hz_rows) skipped += f;
             run += sx - f;
             cum |= run << (8u * r);
+        }
+        cum_hi = run * 0x01010101u;
+        if (hz_rows > 4u) {
+            cum_hi = 0u;
+#pragma unroll
+            for (uint32_t r = 0; r < 4u; r++) {
+                const uint32_t f = r + 4u < hz_rows ? min((w1 >> (8u * r)) & 0xffu, sx) : sx;
+                if (r + 4u < hz_rows) skipped += f;
+                run += sx - f;
+                cum_hi |= run << (8u * r);
+            }
         }
         return cum;
     };
     int32_t hz_passes = 0;
     if (hz_on) {
         uint32_t sk;
-        int32_t len = valid ? (int32_t)(hz_cum(sk) >> 24) : 0;
+        uint32_t ch = 0u;
+        if (valid) (void)hz_cum(sk, ch);
+        int32_t len = valid ? (int32_t)(ch >> 24) : 0;
         for (int off = 32; off > 0; off >>= 1) len = max(len, __shfl_xor(len, off));
         hz_passes = __builtin_amdgcn_readfirstlane(len);
     }
@@ -866,11 +882,19 @@ void k_trace(TraceParams p)
                     // entry j of this surfel's list: the row the cumulated counts put it in, that row's cells from the last one down
                     const uint32_t j = (uint32_t)(gen_next - gen_begin);
                     uint32_t sk;
-                    const uint32_t cum = valid ? hz_cum(sk) : 0u;
-                    make = j < (cum >> 24);
-                    const uint32_t c0 = cum & 0xffu, c1 = (cum >> 8) & 0xffu, c2 = (cum >> 16) & 0xffu;
-                    const uint32_t r = (j >= c0 ? 1u : 0u) + (j >= c1 ? 1u : 0u) + (j >= c2 ? 1u : 0u);
-                    const uint32_t before = r == 0u ? 0u : (r == 1u ? c0 : (r == 2u ? c1 : c2));
+                    uint32_t ch = 0u;
+                    const uint32_t cum = valid ? hz_cum(sk, ch) : 0u;
+                    make = j < (ch >> 24);
+                    // the row: how many of the seven cumulated counts the entry's number has reached
+                    const uint32_t c0 = cum & 0xffu, c1 = (cum >> 8) & 0xffu, c2 = (cum >> 16) & 0xffu, c3 = cum >> 24;
+                    uint32_t r = (j >= c0 ? 1u : 0u) + (j >= c1 ? 1u : 0u) + (j >= c2 ? 1u : 0u);
+                    uint32_t before = r == 0u ? 0u : (r == 1u ? c0 : (r == 2u ? c1 : c2));
+                    if (hz_rows > 4u && j >= c3) {          // (wave-uniform test first: four-row units never come here)
+                        const uint32_t d0 = ch & 0xffu, d1 = (ch >> 8) & 0xffu, d2 = (ch >> 16) & 0xffu;
+                        const uint32_t r2 = (j >= d0 ? 1u : 0u) + (j >= d1 ? 1u : 0u) + (j >= d2 ? 1u : 0u);
+                        r = 4u + r2;
+                        before = r2 == 0u ? c3 : (r2 == 1u ? d0 : (r2 == 2u ? d1 : d2));
+                    }
                     cell_y = (int32_t)(hz_cy0 + r);
                     cell_x = p.grid.sx - 1 - (int32_t)(j - before);
                     i = cell_y * p.grid.sx + cell_x;
@@ -1222,7 +1246,7 @@ void k_trace(TraceParams p)
         const float4 d = p.frames[4ull * (wave_first + lane) + 3];
         long long sT = COUNT32 ? (long long)(CUT ? (miss_count[lane >> 1] >> ((lane & 1u) << 4)) & 0xffffu : miss_count[lane]) * kUnit : (long long)acc[lane][0];
         // (the samples the horizon table resolved: unoccluded, weight 1 — what finish() adds for a ray that ends without a hit)
-        if (hz_on) { uint32_t sk; (void)hz_cum(sk); sT += (long long)sk * kUnit; }
+        if (hz_on) { uint32_t sk, ch; (void)hz_cum(sk, ch); sT += (long long)sk * kUnit; }
         const long long sW = UNITW ? (long long)(gen_end - gen_begin) * kUnit : (long long)acc[lane][TOTAL_ONLY ? 0 : 1];
         AobResult* cell = p.results + __float_as_uint(d.x);
         if (p.parts > 1u) {
@@ -1406,7 +1430,8 @@ static uint32_t schedule_parts(const AobOptions& o)
     if (horizon_applies(o)) {
         CosineGrid g;
         cosine_grid(o.sample_count, g);
-        if ((uint32_t)g.sy % parts == 0u && (uint32_t)g.sy / parts > 4u && g.sy % 4 == 0 && g.sy / 4 <= kCutWedges) parts = (uint32_t)g.sy / 4u;
+        const uint32_t most = g.sx <= 16 ? 8u : 4u;          // rows a unit's list may span (trace.hip hz_cum)
+        if ((uint32_t)g.sy % parts == 0u && (uint32_t)g.sy / parts > most && g.sy % 4 == 0 && g.sy / 4 <= kCutWedges) parts = (uint32_t)g.sy / 4u;
     }
     return parts;
 }
@@ -1603,7 +1628,8 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
             if (horizon_applies(b) && quant == 2 && b->node_count > 0) {
                 const uint32_t per = (uint32_t)o.sample_count / p.parts, sx = (uint32_t)p.grid.sx;
                 const uint32_t rows = per / sx;
-                const bool whole = per * p.parts == (uint32_t)o.sample_count && rows * sx == per && (rows == 1u || rows == 2u || rows == 4u) && !(fine_tiles && rows == 1u);
+                // (whole rows, 1 / 2 / 4 of them inside one word of the table, or 8 — two words — where a list of 8 rows still fits its byte counts: <= 16 columns)
+                const bool whole = per * p.parts == (uint32_t)o.sample_count && rows * sx == per && (rows == 1u || rows == 2u || rows == 4u || (rows == 8u && sx <= 16u)) && !(fine_tiles && rows == 1u);
                 if (whole) {
                     if (horizon_build(b, m, sb, se, p.tmax)) {
                         p.horizon = (const uint32_t*)m.horizon; p.horizon_words = horizon_stride(b) / 4u;

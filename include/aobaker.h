@@ -395,7 +395,8 @@ int aob_bake_copy_tile_cuts(AobBake* bake, int32_t material, uint32_t* dst, uint
  * cell must be unoccluded for the oracle. */
 int aob_bake_copy_horizon(AobBake* bake, int32_t material, uint8_t* dst, uint64_t capacity_bytes, uint32_t* stride, uint64_t* surfels);
 /* Diagnostics of the horizon-table kernel since the bake was created (or last cleared), summed over its tiles: out16[0..8] = walk rounds, child
- * boxes measured, near triangles, middle-distance leaves, tiles that got no tables (lists full), tiles, clock ticks of the kernel's three phases. */
+ * boxes measured, near triangles, middle-distance leaves, tiles that got no tables (lists full), tiles, clock ticks of the kernel's three phases.
+ * The kernel counts only after a call with clear = 2 (nine contended atomics per tile cost more than the kernel itself); clear = 1 zeroes the counters. */
 int aob_bake_horizon_counters(AobBake* bake, unsigned long long* out16, int clear);
 /* HIP-event times of the handle's most recent stages, in ms (-1: the stage has not run through its staged entry point): out6[0] the tree's build,
  * [1] the rasterisation (aob_bake_rasterize / _rows: host read-backs included), [2] the trace (everything aob_bake_trace enqueued), and of the

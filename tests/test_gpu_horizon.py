@@ -137,3 +137,16 @@ def test_sections_with_visibility_flags_and_a_material_range(engine, orc):
             for i in range(gpu_scene.GetMaterialCount()):
                 assert np.array_equal(gpu_scene.GetMaterial(i).GetAOTexture().GetData(), cpu_scene.GetMaterial(i).GetAOTexture().GetData())
     engine.Options = None
+
+
+@pytest.mark.parametrize("parts,want", [(1, 1), (2, 1), (4, 1), (8, 1), (16, 1)])
+def test_units_of_one_to_eight_rows(engine, orc, parts, want):
+    """256 spp = 16 rows: two parts are units of eight rows (two words of a surfel's table), sixteen parts of one row; one part would be sixteen rows: the schedule makes it four parts (schedule_parts)"""
+    flat = FlatScene(scenes.terrain_scene(grid=96, atlas=128))
+    opt = options(orc, 256, use_any_hit=1, accumulate=capi.ACCUMULATE_FLOAT, trace_parts=parts, trace_part_min=1)
+    with_t, st, _, _ = bake_cells(flat, opt, 2)
+    without, _, _, _ = bake_cells(flat, opt, 1)
+    assert st.trace_horizon == want
+    assert np.array_equal(with_t["total_bits"], without["total_bits"]) and np.array_equal(with_t["weight_bits"], without["weight_bits"])
+    if want:
+        assert st.rays_cast < st.ray_count

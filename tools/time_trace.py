@@ -112,7 +112,7 @@ def child(modes, reps, knobs):
             if hasattr(b.lib, "aob_bake_horizon_counters") and st.trace_horizon == 1:
                 import ctypes
                 hb = (ctypes.c_ulonglong * 16)()
-                b.lib.aob_bake_horizon_counters(b.handle, hb, 1)
+                b.lib.aob_bake_horizon_counters(b.handle, hb, 2)
                 b.clear_results(0); b.trace(0); b.sync()
                 b.lib.aob_bake_horizon_counters(b.handle, hb, 1)
                 tl = max(1, int(hb[5]))
