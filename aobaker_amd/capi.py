@@ -178,7 +178,7 @@ EXPORTED_SYMBOLS = [
     "aob_bake_node_count", "aob_bake_copy_nodes", "aob_bake_surfel_count",
     "aob_bake_copy_surfels", "aob_bake_copy_results", "aob_bake_results_device_ptr",
     "aob_bake_image_device_ptr", "aob_bake_stream", "aob_bake_last_trace_ms",
-    "aob_bake_shard_bounds", "aob_bake_node4_count", "aob_bake_copy_nodes4", "aob_bake_copy_leaf_tris", "aob_bake_add_results", "aob_bake_add_results_from", "aob_bake_copy_tile_cuts", "aob_bake_copy_horizon", "aob_bake_horizon_counters", "aob_bake_last_stage_ms",
+    "aob_bake_shard_bounds", "aob_bake_node4_count", "aob_bake_copy_nodes4", "aob_bake_copy_leaf_tris", "aob_bake_add_results", "aob_bake_add_results_from", "aob_bake_copy_tile_cuts", "aob_bake_copy_horizon", "aob_bake_horizon_counters", "aob_bake_last_stage_ms", "aob_debug_fail_tile_cuts",
     "aob_bake_copy_nodes2q", "aob_bake_quant_frame", "aob_bake_copy_nodes4q", "aob_bake_node4q_count", "aob_bake_rasterize_rows",
 ]
 
@@ -261,6 +261,7 @@ def load() -> C.CDLL:
         "aob_bake_copy_horizon": (C.c_int, [vp, C.c_int32, vp, u64, P(C.c_uint32), P(C.c_uint64)]),
         "aob_bake_horizon_counters": (C.c_int, [vp, vp, C.c_int]),
         "aob_bake_last_stage_ms": (C.c_int, [vp, vp]),
+        "aob_debug_fail_tile_cuts": (None, [C.c_int]),
         "aob_bake_copy_nodes2q": (C.c_int, [vp, vp, u64]),
         "aob_bake_quant_frame": (C.c_int, [vp, vp]),
         "aob_bake_copy_nodes4q": (C.c_int, [vp, vp, u64]),

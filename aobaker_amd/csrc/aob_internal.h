@@ -60,6 +60,8 @@ struct DeviceMaterial {
     uint32_t* perm = nullptr;             // trace order -> row-major rank (per section)
     uint32_t* tile_cuts = nullptr;        // 128 words per 64-surfel tile and sample part of a trace launch: the tile's cut of the tree (trace.hip k_tile_cuts)
     uint64_t  tile_cut_capacity = 0;      // ... in words
+    uint64_t  tile_cut_failed = 0;        // ... the smallest request that could not be allocated since the last rasterisation (0: none): not tried again
+    uint32_t  cuts_state = 0, horizon_state = 0;   // this material's launches since its last rasterisation: AobStats::trace_cuts / trace_horizon (the stats carry the maximum over the materials)
     uint32_t  tile_cut_tiles = 0, tile_cut_records = 0;   // ... of the most recent launch (0 tiles: it walked from the root)
     uint8_t*  horizon = nullptr;          // horizon tables of the surfels (horizon.hip): per surfel, in trace order, the free columns of every azimuth row of the COSINE sampler's grid
     uint64_t  horizon_capacity = 0;       // ... in bytes

@@ -721,6 +721,9 @@ int aob_bake_get_stats(AobBake* b, AobStats* stats)
     b->stats.surfel_count = surfels;
     b->stats.ray_count = surfels * (uint64_t)b->opt.sample_count;
     b->stats.ms_total_device = b->stats.ms_bvh_build + b->stats.ms_rasterize + b->stats.ms_trace + b->stats.ms_resolve;
+    // tile cuts / horizon tables: what the materials' launches reported, the worst of them (2: wanted and could not be had)
+    b->stats.trace_cuts = 0u; b->stats.trace_horizon = 0u;
+    for (auto& m : b->materials) { b->stats.trace_cuts = std::max(b->stats.trace_cuts, m.cuts_state); b->stats.trace_horizon = std::max(b->stats.trace_horizon, m.horizon_state); }
     // the samples the trace launches cast: all of them, less what the horizon tables resolved (launches since each material's last rasterisation)
     b->stats.rays_cast = b->stats.ray_count;
     {
@@ -843,7 +846,7 @@ int aob_bake_copy_horizon(AobBake* b, int32_t material, uint8_t* dst, uint64_t c
     DeviceMaterial& m = b->materials[material];
     if (!stride || !surfels) { set_error("stride / surfels is NULL"); return AOB_ERR_INVALID_ARGUMENT; }
     *stride = 0; *surfels = 0;
-    if (!m.horizon || b->stats.trace_horizon != 1u || m.surfel_count == 0) return AOB_OK;
+    if (!m.horizon || m.horizon_state != 1u || m.surfel_count == 0) return AOB_OK;
     const uint32_t st = horizon_stride(b);
     *stride = st; *surfels = m.surfel_count;
     const uint64_t bytes = (uint64_t)st * m.surfel_count;

@@ -551,8 +551,7 @@ int rasterize_material(AobBake* b, int32_t material, int32_t row_begin, int32_t 
     m.rasterized = true;
     // the tile cuts of this material's trace launches, sized by what was covered (a strip of rows: a strip's worth) — here, so that no trace
     // launch carries an allocation; without the memory the launches walk from the root and the bake says so (trace.hip ensure_tile_cuts)
-    b->stats.trace_cuts = 0u;
-    b->stats.trace_horizon = 0u;
+    m.cuts_state = 0u; m.horizon_state = 0u; m.tile_cut_failed = 0;      // (per material: another material's rasterisation does not erase what this one's launches reported)
     m.horizon_asked = 0;
     (void)hipMemsetAsync(b->horizon_counters + 16 + material, 0, sizeof(unsigned long long), b->stream);
     reserve_tile_cuts(b, material);

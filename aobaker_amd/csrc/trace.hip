@@ -442,8 +442,13 @@ __device__ __forceinline__ long long f2fix(float v)
 #define AOB_TRACE_WAVES 8          // waves per SIMD the register allocator must leave room for (<= 64 VGPRs): the walk
                                    // lives on latency hiding — 27 instead of 32 wavefronts per CU cost 11 %
 #endif
-template <int SAMPLER, int ANYHIT, int ACCUM, int LDS_N, int QUANT, int MASKED, int CUTMODE>
-__global__ __launch_bounds__(kWave, AOB_TRACE_WAVES)
+#ifndef AOB_TRACE_WAVES_HZ
+#define AOB_TRACE_WAVES_HZ 7       // ... and for the launches under horizon tables: their rays are the long walks near the horizon, fewer and heavier — 72 registers and
+                                   // 7 wavefronts per SIMD beat 64 and 8 there (BASELINE configs[2]: 36.1 -> 33.6 ms, 6 wavefronts 34.9; closest-hit terrain 65.2 -> 62.7;
+                                   // the launches without tables are even at 7 and lose at 6: profiles/r06/horizon/waves_per_simd.jsonl)
+#endif
+template <int SAMPLER, int ANYHIT, int ACCUM, int LDS_N, int QUANT, int MASKED, int CUTMODE, int HZMODE>
+__global__ __launch_bounds__(kWave, (HZMODE ? AOB_TRACE_WAVES_HZ : AOB_TRACE_WAVES))
 void k_trace(TraceParams p)
 {
     // 5 KB per wavefront: 32 wavefronts per CU fill its 160 KB
@@ -597,8 +602,11 @@ void k_trace(TraceParams p)
     // unoccluded whatever their jitter and are NOT cast — they go into the sums in the epilogue.  What is left of the rows is a list per surfel,
     // and pass j of the generator makes entry j of every list that has one: row after row, each from its last cell (the most grazing) down to
     // the first blocked one.  The word is fetched again in every pass (L1) rather than held across the walk: this kernel lives at the register cap.
-    constexpr bool HZ = SAMPLER == AOB_SAMPLER_COSINE && QUANT == 2;
-    const bool hz_on = HZ && p.horizon != nullptr;
+    // (an instantiation of its own — HZMODE — so that the launches without tables compile to the kernel they were before: as a run-time switch the
+    // tables' code cost those launches 6 % — 43.8 -> 46.6 ms on BASELINE configs[2] with trace_horizon 1, profiles/r06/horizon/)
+    constexpr bool HZ = HZMODE != 0;
+    static_assert(!HZ || (SAMPLER == AOB_SAMPLER_COSINE && QUANT == 2), "horizon tables: the COSINE sampler on the quantised 4-ary nodes");
+    constexpr bool hz_on = HZ;
     const uint32_t hz_cy0 = (uint32_t)gen_begin / (uint32_t)p.grid.sx;
     const uint32_t hz_rows = (uint32_t)(gen_end - gen_begin) / (uint32_t)p.grid.sx;
     // a surfel's row word -> the rows' remaining cells, cumulated: byte r = cells cast in rows 0 .. r (byte 3: the list's length)
@@ -637,10 +645,16 @@ void k_trace(TraceParams p)
         return cum;
     };
     int32_t hz_passes = 0;
+    // (a unit of up to four rows — every unit of the default schedules — keeps its list's cumulated counts in ONE register across the walk; the
+    // wider units fetch and make them again in every pass.  AOB_HZ_HOLD 0: every unit does — for A/B runs.)
+#ifndef AOB_HZ_HOLD
+#define AOB_HZ_HOLD 1
+#endif
+    uint32_t hz_held = 0u;
     if (hz_on) {
         uint32_t sk;
         uint32_t ch = 0u;
-        if (valid) (void)hz_cum(sk, ch);
+        if (valid) hz_held = hz_cum(sk, ch);
         int32_t len = valid ? (int32_t)(ch >> 24) : 0;
         for (int off = 32; off > 0; off >>= 1) len = max(len, __shfl_xor(len, off));
         hz_passes = __builtin_amdgcn_readfirstlane(len);
@@ -883,7 +897,9 @@ void k_trace(TraceParams p)
                     const uint32_t j = (uint32_t)(gen_next - gen_begin);
                     uint32_t sk;
                     uint32_t ch = 0u;
-                    const uint32_t cum = valid ? hz_cum(sk, ch) : 0u;
+                    uint32_t cum = hz_held;
+                    ch = (hz_held >> 24) * 0x01000000u;
+                    if (!AOB_HZ_HOLD || hz_rows > 4u) cum = valid ? hz_cum(sk, ch) : 0u;
                     make = j < (ch >> 24);
                     // the row: how many of the seven cumulated counts the entry's number has reached
                     const uint32_t c0 = cum & 0xffu, c1 = (cum >> 8) & 0xffu, c2 = (cum >> 16) & 0xffu, c3 = cum >> 24;
@@ -905,9 +921,6 @@ void k_trace(TraceParams p)
                 else if (++gen_cx == p.grid.sx) { gen_cx = 0; gen_cy++; }
                 const uint64_t make_m = hz_on ? __ballot(make) : valid_m;
                 if (HZ) cast_acc += (uint32_t)__popcll(make_m);
-                // (the cut's planes are fetched by scalar loads: their address is made here, where control flow is wave-uniform)
-                const uint32_t* cut_planes = cut_on ? tile_cut + kCutMax : nullptr;
-                asm volatile("" : "+s"(cut_planes));
                 if (make) {
                     const float4* fr = p.frames + 4ull * (wave_first + lane);
                     const float4 a = fr[0], b = fr[1], c = fr[2];
@@ -952,7 +965,7 @@ void k_trace(TraceParams p)
                             // four entries per pass (the list is padded to a multiple of four with empty slots, which no ray enters), the
                             // next four fetched (scalar loads) while these are tested; the fetch past the list's end reads the next record
                             typedef const __attribute__((address_space(4))) uint32_t* const_words;
-                            const uint32_t* eg = cut_planes;
+                            const uint32_t* eg = tile_cut + kCutMax;
                             asm volatile("" : "+s"(eg));
                             const_words ew = (const_words)eg;
                             uint32_t w0 = ew[0], w1 = ew[1], w2 = ew[2], w3 = ew[3], w4 = ew[4], w5 = ew[5], w6 = ew[6], w7 = ew[7], w8 = ew[8], w9 = ew[9], w10 = ew[10], w11 = ew[11];
@@ -1278,7 +1291,7 @@ void k_trace(TraceParams p)
         }
     }
   }   // next unit
-    if (SAMPLER == AOB_SAMPLER_COSINE && QUANT == 2 && p.cast_total && lane == 0) atomicAdd(p.cast_total, (unsigned long long)cast_acc);
+    if (HZMODE != 0 && p.cast_total && lane == 0) atomicAdd(p.cast_total, (unsigned long long)cast_acc);
 }
 
 // After a launch whose parts met in acc_cells: every surfel of the launch owns one cell (sections in one launch share no texel);
@@ -1315,10 +1328,19 @@ static void launch_stack(int quant, dim3 grid, hipStream_t s, const TraceParams&
     constexpr bool CAN_CUT = AOB_TRACE_CUT != 0;
     // (a cut's 32 refs: with unit weights and any-hit scoring the 16-bit miss counters make their room, otherwise a stack entry does)
     constexpr int NC = (SAMPLER == AOB_SAMPLER_COSINE && ANYHIT) ? N : N - 1;
-    if (quant == 2 && CAN_CUT && p.tile_cuts) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, NC, 2, MASKED, CAN_CUT ? 1 : 0>), grid, dim3(kWave), 0, s, p);
-    else if (quant == 2) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 2, MASKED, 0>), grid, dim3(kWave), 0, s, p);
-    else if (quant == 1) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 1, MASKED, 0>), grid, dim3(kWave), 0, s, p);
-    else hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 0, MASKED, 0>), grid, dim3(kWave), 0, s, p);
+    // (horizon tables — p.horizon — are the COSINE sampler's, on the quantised 4-ary nodes: instantiations of their own)
+    constexpr int HZ = SAMPLER == AOB_SAMPLER_COSINE ? 1 : 0;
+    // (28 instead of 32 wavefronts per CU would leave each 5.7 KB of LDS — two more stack entries per lane, AOB_HZ_STACK_MORE 2: measured slower, 33.5 -> 34.2 ms)
+#ifndef AOB_HZ_STACK_MORE
+#define AOB_HZ_STACK_MORE 0
+#endif
+    constexpr int NH = HZ ? AOB_HZ_STACK_MORE : 0;
+    if (quant == 2 && CAN_CUT && p.tile_cuts && p.horizon) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, NC + NH, 2, MASKED, CAN_CUT ? 1 : 0, HZ>), grid, dim3(kWave), 0, s, p);
+    else if (quant == 2 && CAN_CUT && p.tile_cuts) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, NC, 2, MASKED, CAN_CUT ? 1 : 0, 0>), grid, dim3(kWave), 0, s, p);
+    else if (quant == 2 && p.horizon) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N + NH, 2, MASKED, 0, HZ>), grid, dim3(kWave), 0, s, p);
+    else if (quant == 2) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 2, MASKED, 0, 0>), grid, dim3(kWave), 0, s, p);
+    else if (quant == 1) hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 1, MASKED, 0, 0>), grid, dim3(kWave), 0, s, p);
+    else hipLaunchKernelGGL((k_trace<SAMPLER, ANYHIT, ACCUM, N, 0, MASKED, 0, 0>), grid, dim3(kWave), 0, s, p);
 }
 template <int SAMPLER, int ANYHIT, int MASKED>
 static void launch_acc(int accum, int quant, dim3 grid, hipStream_t s, const TraceParams& p)
@@ -1400,16 +1422,22 @@ static int knob(int32_t value, int fallback) { return value > 0 ? value : fallba
 // rasterisation ends (rasterize_material -> reserve_tile_cuts) — so a rank that rasterised a strip holds a strip's worth — and again by a
 // launch whose schedule wants more.  Without the memory the launch walks from the root: same cells, slower — and NOT silently:
 // AobStats::trace_cuts becomes 2 and aob_last_error() holds a warning.
+// (tests: aob_debug_fail_tile_cuts(1) makes every allocation of tile cuts fail from then on — the fallback must bake the same cells and say so)
+static bool g_fail_tile_cuts = false;
 static bool ensure_tile_cuts(AobBake* b, DeviceMaterial& m, uint64_t words)
 {
-    if (words <= m.tile_cut_capacity) return true;
+    if (words <= m.tile_cut_capacity && !g_fail_tile_cuts) return true;
+    // (a request that failed is not tried again launch after launch — each try is a stream synchronisation and a multi-GB allocation that fails again —
+    // until the material is rasterised anew or a launch asks for less)
+    if (m.tile_cut_failed && words >= m.tile_cut_failed) return false;
     (void)hipStreamSynchronize(b->stream);
     release_device(b, m.tile_cuts);
     m.tile_cuts = nullptr; m.tile_cut_capacity = 0;
-    if (hipMalloc((void**)&m.tile_cuts, sizeof(uint32_t) * words) == hipSuccess) { m.tile_cut_capacity = words; return true; }
+    if (!g_fail_tile_cuts && hipMalloc((void**)&m.tile_cuts, sizeof(uint32_t) * words) == hipSuccess) { m.tile_cut_capacity = words; return true; }
     (void)hipGetLastError();
     m.tile_cuts = nullptr;
-    b->stats.trace_cuts = 2u;
+    m.tile_cut_failed = words;
+    m.cuts_state = 2u;
     set_error("warning: %.1f MiB for the tile cuts of a %dx%d material could not be allocated: its rays walk from the root (same results, slower; AobStats::trace_cuts = 2)",
               (double)(sizeof(uint32_t) * words) / 1048576.0, m.width, m.height);
     return false;
@@ -1493,7 +1521,7 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
     if (begin < end) {
         const bool cut = cuts_apply(b) && b->node_count > 0;
         const int cut_entries = o.trace_cut >= 4 ? min(o.trace_cut, kCutMax) : kCutMax;
-        if (!cut && b->stats.trace_cuts != 2u) b->stats.trace_cuts = 0u;
+        if (!cut && m.cuts_state != 2u) m.cuts_state = 0u;
         TraceParams p;
         if (!o.bvh_quantised) AOB_TRY(ensure_nodes(b));
         else if (o.bvh_width != 4) AOB_TRY(ensure_nodes2q(b));
@@ -1593,9 +1621,6 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
             p.coarse_tiles = queue_tiles - fine_tiles;
             p.coarse_units = p.coarse_tiles * p.parts;
             p.units_per_xcd = p.coarse_units + fine_tiles * p.parts_fine;
-            // as many wavefronts as the chip holds (5 KB of LDS and <= 64 VGPRs each: 32 per CU), fewer for small jobs
-            const uint32_t resident = 32u * (uint32_t)b->cu_count;
-            dim3 grid(min(resident, (p.units_per_xcd * 8u + 7u) / 8u * 8u));
             AOB_HIP(hipMemsetAsync(b->trace_unit_next, 0, 8 * sizeof(uint32_t), s));
             p.unit_next = b->trace_unit_next;
             p.tile_cuts = nullptr; p.cut_records = 1u;
@@ -1619,7 +1644,7 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
                                        (float)AOB_CUT_SHRINK_PCT * 0.01f, cut_entries, reach * reach, wedges, m.tile_cuts);
                     p.tile_cuts = m.tile_cuts;
                     m.tile_cut_tiles = p.ntiles; m.tile_cut_records = p.cut_records;
-                    if (b->stats.trace_cuts != 2u) b->stats.trace_cuts = 1u;
+                    if (m.cuts_state != 2u) m.cuts_state = 1u;
                 } else p.cut_records = 1u;
             }
             AOB_HIP(hipEventRecord(b->ev_part[1], s));
@@ -1635,14 +1660,17 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
                         p.horizon = (const uint32_t*)m.horizon; p.horizon_words = horizon_stride(b) / 4u;
                         p.cast_total = b->horizon_counters + 16 + material;
                         m.horizon_asked += (se - sb) * (uint64_t)o.sample_count;
-                        if (b->stats.trace_horizon != 2u) b->stats.trace_horizon = 1u;
+                        if (m.horizon_state != 2u) m.horizon_state = 1u;
                     } else {
-                        b->stats.trace_horizon = 2u;
+                        m.horizon_state = 2u;
                         set_error("warning: the horizon tables of a %dx%d material could not be allocated: every sample is cast (same results, slower; AobStats::trace_horizon = 2)", m.width, m.height);
                     }
                 }
             }
             AOB_HIP(hipEventRecord(b->ev_part[2], s));
+            // as many wavefronts as the chip holds (5 KB of LDS and <= 64 VGPRs each: 32 per CU; under horizon tables 72 registers: 28), fewer for small jobs
+            const uint32_t resident = (p.horizon ? 4u * (uint32_t)AOB_TRACE_WAVES_HZ : 32u) * (uint32_t)b->cu_count;
+            dim3 grid(min(resident, (p.units_per_xcd * 8u + 7u) / 8u * 8u));
             // the HBM overflow stack (reserved when the tree was built; a launch whose schedule or mode was set later re-sizes it here)
             const uint32_t overflow = stack_overflow_entries(b, p.tile_cuts != nullptr);
             if (overflow) AOB_TRY(reserve_gstack(b, (uint64_t)grid.x * kWave * overflow));
@@ -1664,6 +1692,8 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
 }
 
 } // namespace aob
+
+extern "C" void aob_debug_fail_tile_cuts(int on) { aob::g_fail_tile_cuts = on != 0; }
 
 #if AOB_TRACE_STATS
 // diagnostic builds only: read and clear the loop counters

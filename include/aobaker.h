@@ -216,7 +216,7 @@ typedef struct AobStats {
     uint64_t surfel_count;        /* covered texels summed over sections and materials */
     uint64_t ray_count;           /* surfel_count * sample_count */
     uint32_t bvh_depth;
-    uint32_t trace_cuts;          /* the trace launches since the last rasterisation — 0: walked from the root by design (a mode without tile
+    uint32_t trace_cuts;          /* the worst over the materials of what each one's trace launches since ITS last rasterisation reported — 0: walked from the root by design (a mode without tile
                                      cuts, trace_cut 1); 1: started their rays below tile cuts (AobOptions::trace_cut); 2: at least one wanted
                                      cuts and walked from the root because their memory could not be allocated — the same cells, slower;
                                      aob_last_error() then holds a line that starts with "warning:" (ABI 6; was reserved0)           */
@@ -402,6 +402,9 @@ int aob_bake_horizon_counters(AobBake* bake, unsigned long long* out16, int clea
  * [1] the rasterisation (aob_bake_rasterize / _rows: host read-backs included), [2] the trace (everything aob_bake_trace enqueued), and of the
  * trace's most recent LAUNCH [3] its tile cuts, [4] its horizon tables, [5] its walk (k_trace).  Waits for the stream. */
 int aob_bake_last_stage_ms(AobBake* bake, float* out6);
+/* Tests only: from a call with on != 0 every allocation of tile cuts fails (process-wide), as on a device without memory for them — the bakes walk
+ * from the root, write the same cells and report AobStats::trace_cuts = 2 with a "warning:" in aob_last_error(). */
+void aob_debug_fail_tile_cuts(int on);
 int aob_bake_surfel_count(AobBake* bake, int32_t material, uint64_t* count);
 int aob_bake_copy_surfels(AobBake* bake, int32_t material, AobSurfel* dst, uint64_t capacity);
 int aob_bake_copy_results(AobBake* bake, int32_t material, AobResult* dst, uint64_t capacity);

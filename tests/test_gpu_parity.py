@@ -1016,3 +1016,27 @@ def test_closest_hit_below_tile_cuts_is_the_oracles_walk_of_the_same_cuts(engine
     nodes, _ = orc.bvh_build(orc.scene_triangles(flat.desc), 1)
     ref, _ = orc.trace(nodes, o_surfels, sidx, opt, m.width, m.height, hemi, threads=4)
     assert np.array_equal(got, ref), name
+
+
+def test_tile_cuts_that_cannot_be_allocated_are_reported_for_every_material(engine, orc):
+    """ADVICE r5: a bake of TWO materials whose tile cuts cannot be allocated walks from the root — the same cells — and says so: AobStats::trace_cuts
+    stays 2 whatever the second material's rasterisation does, aob_last_error() holds the warning, and the allocation is not tried launch after launch."""
+    import ctypes
+    lib = capi.load()
+    opt = make_options(orc, sample_count=16, sampler=capi.SAMPLER_COSINE, accumulate=capi.ACCUMULATE_FLOAT, use_any_hit=1, seed=2)
+    gpu_scene, cpu_scene = _flagged_scene(4), _flagged_scene(4)
+    lib.aob_debug_fail_tile_cuts(1)
+    try:
+        engine.Options = opt
+        engine.Bake(gpu_scene)
+        st = engine.LastStats
+        assert st.trace_cuts == 2
+        assert b"warning:" in (lib.aob_last_error() or b"")
+    finally:
+        lib.aob_debug_fail_tile_cuts(0)
+    orc.bake(FlatScene(cpu_scene).desc, opt, threads=4)
+    for i in range(2):
+        assert np.array_equal(gpu_scene.GetMaterial(i).GetAOTexture().GetData(), cpu_scene.GetMaterial(i).GetAOTexture().GetData())
+    engine.Bake(gpu_scene)                      # and with the memory back the next bake has its cuts again
+    assert engine.LastStats.trace_cuts == 1
+    engine.Options = None

@@ -25,7 +25,7 @@ def main():
     # AOB_VARIANT_ALSO="bvh_build.hip ...": sources compiled with the variant's flags besides trace.hip (a flag that both sides of a
     # data structure must see, e.g. -DAOB_FAN=1)
     also = os.environ.get("AOB_VARIANT_ALSO", "").split()
-    src_name = os.environ.get("AOB_VARIANT_SOURCE", "trace.hip")
+    src_name = os.environ.get("AOB_VARIANT_REPLACES", os.environ.get("AOB_VARIANT_SOURCE", "trace.hip"))      # the product object the variant's source stands in for
     others = [os.path.join(CSRC, o) for o in ("api.o", "bvh_build.o", "raster.o", "trace.o", "horizon.o", "resolve.o") if o.replace(".o", ".hip") not in also + [src_name]]
     procs = []
     for arg in sys.argv[1:]:

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
-    want = sys.argv[1] if len(sys.argv) > 1 else "_ZN3aob7k_traceILi1ELi1ELi1ELi11ELi2ELi0ELi1EEEvNS_11TraceParamsE"
+    want = sys.argv[1] if len(sys.argv) > 1 else "_ZN3aob7k_traceILi1ELi1ELi1ELi11ELi2ELi0ELi1ELi1EEEvNS_11TraceParamsE"
     flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize"]
     with tempfile.TemporaryDirectory() as tmp:
         subprocess.run(["/opt/rocm/bin/hipcc"] + flags + ["-I", os.path.join(ROOT, "include"), "--save-temps", "-c", os.path.join(ROOT, "aobaker_amd", "csrc", "trace.hip"), "-o",
