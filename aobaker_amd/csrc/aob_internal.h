@@ -65,6 +65,9 @@ struct DeviceMaterial {
     uint32_t  tile_cut_tiles = 0, tile_cut_records = 0;   // ... of the most recent launch (0 tiles: it walked from the root)
     uint8_t*  horizon = nullptr;          // horizon tables of the surfels (horizon.hip): per surfel, in trace order, the free columns of every azimuth row of the COSINE sampler's grid
     uint64_t  horizon_capacity = 0;       // ... in bytes
+    uint32_t  horizon_verdict = 0;        // trace_horizon 0 on a large launch: 0 not sampled yet, 1 the sample said worth it, 2 not worth it (kept for the handle)
+    float     horizon_sampled = 0.0f;     // ... samples per surfel the sample's tables resolved
+    bool      horizon_declined = false;   // the last horizon_build returned false because of that verdict (not for lack of memory)
     uint64_t  horizon_asked = 0;          // samples of the launches that had tables, since the last rasterisation (AobStats::rays_cast)
     uint32_t* tile_sums = nullptr;        // scan partials of the tile-order pass
     uint32_t* tile_row_prefix = nullptr;  // covered texels before each 8-texel tile row (first section)
@@ -168,7 +171,7 @@ int reserve_trace_stack(AobBake* b);                         // trace.hip: the w
 bool horizon_applies(const AobOptions& o);                   // horizon.hip: the options ask for horizon tables (COSINE sampler on a full grid, quantised 4-ary nodes, trace_horizon)
 bool horizon_applies(const AobBake* b);
 uint32_t horizon_stride(const AobBake* b);                   // ... bytes per surfel
-bool horizon_build(AobBake* b, DeviceMaterial& m, uint64_t begin, uint64_t end, float tmax);   // ... the tables of a launch's surfels (false: no memory)
+bool horizon_build(AobBake* b, DeviceMaterial& m, uint64_t begin, uint64_t end, float tmax, bool verdict_only = false);   // ... the tables of a launch's surfels (false: no memory)
 int resolve_material(AobBake* b, int32_t material);          // resolve.hip
 uint64_t chunk_texel_max(const AobOptions& opt);             // trace.hip (BakeEngine.cpp:359-364)
 }

@@ -51,8 +51,9 @@ uint32_t horizon_stride(const AobBake* b)
     return g.sy <= 16 ? 16u : 32u;
 }
 
-// The tables of the surfels [begin, end) of a material (a trace launch's range), into m.horizon.  false: no memory — the launch traces every sample.
-bool horizon_build(AobBake* b, DeviceMaterial& m, uint64_t begin, uint64_t end, float tmax)
+// The tables of the surfels [begin, end) of a material (a trace launch's range), into m.horizon.  false: no memory, or — horizon_declined — not worth
+// building here: the launch traces every sample.  verdict_only: allocate, and settle whether they are worth building (below), nothing more.
+bool horizon_build(AobBake* b, DeviceMaterial& m, uint64_t begin, uint64_t end, float tmax, bool verdict_only)
 {
     const AobOptions& o = b->opt;
     const uint32_t stride = horizon_stride(b);
@@ -76,11 +77,35 @@ bool horizon_build(AobBake* b, DeviceMaterial& m, uint64_t begin, uint64_t end, 
     p.reach = tmax < 1e30f ? (tmax + fabsf(o.ray_bias)) * 1.01f : INFINITY;
     p.near_factor = 0.5f; p.mid_factor = 3.0f; p.small2 = 0.14f * 0.14f; p.big2 = 0.6f;
     p.out = m.horizon; p.stride = stride;
+    p.tile_stride = 1u;
     // (diagnostics only on request — aob_bake_horizon_counters(.., 2): nine contended global atomics per tile cost more than the kernel itself, 5.6 of 7.2 ms)
     p.counters = b->horizon_diag ? b->horizon_counters : nullptr;
     const uint32_t tiles = (uint32_t)((end - begin + kHzWave - 1) / kHzWave);
-    if (g.sx <= 16 && g.sy <= 16) hipLaunchKernelGGL((k_horizon<16, true>), dim3(tiles), dim3(kHzWave), 0, b->stream, p);
-    else hipLaunchKernelGGL((k_horizon<32, false>), dim3(tiles), dim3(kHzWave), 0, b->stream, p);
+    auto launch = [&](uint32_t blocks) {
+        if (g.sx <= 16 && g.sy <= 16) hipLaunchKernelGGL((k_horizon<16, true>), dim3(blocks), dim3(kHzWave), 0, b->stream, p);
+        else hipLaunchKernelGGL((k_horizon<32, false>), dim3(blocks), dim3(kHzWave), 0, b->stream, p);
+    };
+    // ---- are they worth it HERE?  The tables cost time per surfel and save time per sample they resolve: on BASELINE configs[2] they resolve 58 % of the
+    // samples and the trace gains 8 %; on configs[4]'s rocks — every surfel hemmed in by its neighbours within the rays' 1.25 — they resolve 0.4 % and
+    // cost 3 %.  With trace_horizon 0 a large launch (4096 tiles and more) measures a sample of its tiles first — every 64th — and goes on only if the
+    // sample promises at least kHzWorth samples resolved per surfel; the verdict is kept for the handle (its scene and options do not change).
+    // trace_horizon 2 builds them unasked.
+    constexpr double kHzWorth = 80.0;
+    if (o.trace_horizon == 0 && m.horizon_verdict == 0 && tiles >= 4096u) {
+        unsigned long long* cnt = b->horizon_counters + 12;          // [12] free cells, [13] surfels of the sample
+        if (hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned long long), b->stream) != hipSuccess) return false;
+        p.tile_stride = 64u; p.skipped = cnt;
+        launch(tiles / 64u);
+        unsigned long long got[2] = { 0, 0 };
+        if (hipMemcpyAsync(got, cnt, sizeof got, hipMemcpyDeviceToHost, b->stream) != hipSuccess || hipStreamSynchronize(b->stream) != hipSuccess) return false;
+        p.tile_stride = 1u; p.skipped = nullptr;
+        const double per_surfel = got[1] ? (double)got[0] / (double)got[1] : 0.0;      // samples resolved per surfel
+        m.horizon_verdict = per_surfel >= kHzWorth ? 1u : 2u;
+        m.horizon_sampled = (float)per_surfel;
+    }
+    if (o.trace_horizon == 0 && m.horizon_verdict == 2u) { m.horizon_declined = true; return false; }
+    if (verdict_only) return true;          // (trace_range asks before it makes its schedule; the tables themselves when it launches)
+    launch(tiles);
     return hipGetLastError() == hipSuccess;
 }
 

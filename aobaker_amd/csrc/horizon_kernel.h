@@ -46,6 +46,8 @@ struct HorizonParams {
     float big2;                    // a leaf whose box diagonal squared exceeds this times its squared gap to the tile is a near leaf
     uint8_t* out;                  // stride bytes per surfel: free columns of row cy in byte cy
     uint32_t stride;
+    uint32_t tile_stride;          // the launch's block i measures tile i * tile_stride (1: every tile; more: a sample of them)
+    unsigned long long* skipped;   // (or null) += the free cells of the launch's tables, += 64 per tile at [1]: what a sample of tiles promises
     unsigned long long* counters;  // diagnostics (or null): rounds, box tests, near triangles, mid leaves, tiles given up, tiles, clock ticks of phases A / B / C
 #ifdef AOB_HORIZON_EMU
     float* dbg;                    // per tile 32 floats: the tile's horizon after phase A; then per tile 64 x 32 words: the local tables after phase B
@@ -131,7 +133,7 @@ void k_horizon(HorizonParams p)
     __shared__ uint32_t table[CMAX * kHzWave / (T16 ? 2 : 1)];    // local tables: [column][lane] = rows blocked FROM that column (cumulated at the end); T16: 16 rows, two lanes a word
 
     const uint32_t lane = threadIdx.x;
-    const uint64_t k = p.begin + (uint64_t)blockIdx.x * kHzWave + lane;
+    const uint64_t k = p.begin + (uint64_t)blockIdx.x * p.tile_stride * kHzWave + lane;
     const int K = p.K, C = p.C;
     if (AOB_HZ_SKIP & 16) return;
 
@@ -608,6 +610,12 @@ void k_horizon(HorizonParams p)
         for (int r = 0; r < 32; r++) fr[r >> 2] |= cnt[r] << ((r & 3) * 8);
     }
     write_out(fr);
+    if (p.skipped) {
+        float tot = 0.0f;
+        for (int r = 0; r < 32; r++) tot += (float)((fr[r >> 2] >> ((r & 3) * 8)) & 0xffu);
+        tot = hz_wave_sum(tot);
+        if (lane == 0) { atomicAdd(&p.skipped[0], (unsigned long long)tot); atomicAdd(&p.skipped[1], 64ull); }
+    }
     if (p.counters && lane == 0) {
         // (clock ticks per phase, summed over the tiles: A, B, C + the epilogue)
         const unsigned long long clk3 = HZ_CLOCK();

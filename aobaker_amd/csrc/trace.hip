@@ -1450,12 +1450,12 @@ static bool cuts_apply(const AobBake* b)
 }
 
 // the sample parts per tile of a launch (and whether the last tiles of a queue are cut finer): trace_range's schedule
-static uint32_t schedule_parts(const AobOptions& o)
+static uint32_t schedule_parts(const AobOptions& o, bool tables = true)
 {
     uint32_t parts = (uint32_t)max(1, min(o.trace_parts > 0 ? o.trace_parts : 4, o.sample_count / (o.trace_part_min > 0 ? o.trace_part_min : 16)));
     // horizon tables (horizon.hip): a unit's samples are at most four whole rows of the sampler's grid — one word of a surfel's table.  A 32 x 32 grid
     // (1024 spp) in four parts would be eight rows each: eight parts then.
-    if (horizon_applies(o)) {
+    if (tables && horizon_applies(o)) {
         CosineGrid g;
         cosine_grid(o.sample_count, g);
         const uint32_t most = g.sx <= 16 ? 8u : 4u;          // rows a unit's list may span (trace.hip hz_cum)
@@ -1469,9 +1469,13 @@ void reserve_tile_cuts(AobBake* b, int32_t material)
     if (!cuts_apply(b)) return;
     DeviceMaterial& m = b->materials[material];
     if (m.surfel_count == 0) return;
-    const uint32_t parts = schedule_parts(b->opt);
-    const bool fine = parts > 1u && (uint32_t)b->opt.sample_count / (2u * parts) >= 16u && 3u * parts <= (uint32_t)kCutWedges;
-    const uint64_t records = b->opt.sampler == AOB_SAMPLER_COSINE ? (fine ? 3ull : 1ull) * parts : 1ull;       // coarse parts + twice as many fine ones
+    // (the records of the schedule with horizon tables and of the one without — a launch may turn the tables down, horizon.hip — whichever needs more)
+    uint64_t records = 1;
+    for (int with = 0; with < 2; with++) {
+        const uint32_t parts = schedule_parts(b->opt, with != 0);
+        const bool fine = parts > 1u && (uint32_t)b->opt.sample_count / (2u * parts) >= 16u && 3u * parts <= (uint32_t)kCutWedges;
+        records = std::max<uint64_t>(records, b->opt.sampler == AOB_SAMPLER_COSINE ? (fine ? 3ull : 1ull) * parts : 1ull);       // coarse parts + twice as many fine ones
+    }
     const uint64_t tiles = m.surfel_count / 64 + m.section_offsets.size() + 1;
     (void)ensure_tile_cuts(b, m, (tiles * records + 1) * (uint64_t)kCutWords);
 }
@@ -1587,7 +1591,9 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
             // Adding the parts is exact with integer cells and with float cells that hold whole numbers (unit weights, any hit); float
             // cells that hold fractions go through 64-bit accumulators and are rounded once after the launch (k_acc_to_cells).
             const bool split_direct = o.accumulate == AOB_ACCUMULATE_QUANTISED || (o.sampler == AOB_SAMPLER_COSINE && o.use_any_hit);
-            p.parts = schedule_parts(o);
+            // (horizon tables under trace_horizon 0: a large launch first asks a sample of its tiles whether they pay — before the schedule, which depends on the answer)
+            if (horizon_applies(b) && quant == 2 && b->node_count > 0 && o.trace_horizon == 0 && m.horizon_verdict == 0u) { (void)horizon_build(b, m, sb, se, p.tmax, true); m.horizon_declined = false; }
+            p.parts = schedule_parts(o, m.horizon_verdict != 2u);          // (a material whose sampled tiles turned the tables down keeps the schedule without them)
             const bool through_acc = !split_direct && p.parts > 1u;
             if (through_acc) {
                 const uint64_t cells = (uint64_t)m.width * m.height;
@@ -1650,7 +1656,7 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
             AOB_HIP(hipEventRecord(b->ev_part[1], s));
             // ---- horizon tables (horizon.hip): where the unit's samples are whole rows of the sampler's grid, at most four of them in one word of the table ----
             p.horizon = nullptr; p.horizon_words = 0u; p.cast_total = nullptr;
-            if (horizon_applies(b) && quant == 2 && b->node_count > 0) {
+            if (horizon_applies(b) && quant == 2 && b->node_count > 0 && !(o.trace_horizon == 0 && m.horizon_verdict == 2u)) {
                 const uint32_t per = (uint32_t)o.sample_count / p.parts, sx = (uint32_t)p.grid.sx;
                 const uint32_t rows = per / sx;
                 // (whole rows, 1 / 2 / 4 of them inside one word of the table, or 8 — two words — where a list of 8 rows still fits its byte counts: <= 16 columns)
@@ -1661,6 +1667,8 @@ int trace_range(AobBake* b, int32_t material, uint64_t begin, uint64_t end)
                         p.cast_total = b->horizon_counters + 16 + material;
                         m.horizon_asked += (se - sb) * (uint64_t)o.sample_count;
                         if (m.horizon_state != 2u) m.horizon_state = 1u;
+                    } else if (m.horizon_declined) {
+                        m.horizon_declined = false;               // (a sample of the tiles said the tables would not pay here: no tables, by design)
                     } else {
                         m.horizon_state = 2u;
                         set_error("warning: the horizon tables of a %dx%d material could not be allocated: every sample is cast (same results, slower; AobStats::trace_horizon = 2)", m.width, m.height);

@@ -22,7 +22,7 @@ extern "C" int emu_horizon(const float* frames, uint64_t begin, uint64_t end, co
     std::memset(&p, 0, sizeof p);
     p.frames = (const float4*)frames; p.begin = begin; p.end = end; p.nodes4q = (const uint4*)nodes4q; p.leaf_tris = (const float4*)leaf_tris;
     p.quant_frame = quant_frame; p.node_count = node_count; p.K = K; p.C = C; p.bias = bias; p.reach = reach;
-    p.near_factor = near_factor; p.mid_factor = mid_factor; p.small2 = small2; p.big2 = big2; p.out = out; p.stride = stride; p.counters = counters; p.dbg = dbg; p.dbg_tables = dbg_tables;
+    p.near_factor = near_factor; p.mid_factor = mid_factor; p.small2 = small2; p.big2 = big2; p.out = out; p.stride = stride; p.tile_stride = 1u; p.counters = counters; p.dbg = dbg; p.dbg_tables = dbg_tables;
     std::barrier<> b(emu::kLanes);
     emu::bar = &b;
     std::vector<std::thread> th;
