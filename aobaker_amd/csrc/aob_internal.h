@@ -152,6 +152,13 @@ struct AobBake {
 };
 
 namespace aob {
+// The large device buffers of a handle — its arena, a material's tile cuts and horizon tables — come from and go back to a small per-device pool
+// (api.hip): a process that bakes one scene after another (BakeEngine::Bake from the UI, the one-shot aob_bake) pays their hipMalloc / hipFree — a
+// device synchronisation each, 4 ms per bake of BASELINE configs[2] — once.  What the reference's Init does with its ~3 GB of fixed buffers
+// (BakeEngine.cpp:163-212), sized by the scenes actually baked; aob_shutdown of the last thread releases it.
+hipError_t pool_alloc(void** p, size_t bytes, int device);
+void pool_free(void* p, size_t bytes, int device);
+void pool_clear();
 // hipFree for a buffer that may be a slice of the bake's arena (then it is not freed on its own)
 inline void release_device(const AobBake* b, void* p)
 {

@@ -140,12 +140,61 @@ struct ArenaPlan {
     void want_bytes(void** p, size_t bytes) { *p = nullptr; wants.push_back({ p, bytes ? bytes : 1 }); }
 };
 
+// ---- the pool of released device buffers (aob_internal.h) ----
+struct PoolEntry { int device; void* p; size_t bytes; };
+static std::mutex g_pool_mutex;
+static std::vector<PoolEntry> g_pool;
+static constexpr size_t kPoolEntries = 12;                 // buffers kept per process
+static constexpr size_t kPoolBytes = 64ull << 30;          // ... and their total size (an MI355X has 288 GB)
+
+hipError_t pool_alloc(void** p, size_t bytes, int device)
+{
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        // the smallest kept buffer that is large enough and not more than twice (+ 1 MB) what is asked for
+        int best = -1;
+        for (size_t i = 0; i < g_pool.size(); i++)
+            if (g_pool[i].device == device && g_pool[i].bytes >= bytes && g_pool[i].bytes <= 2 * bytes + (1u << 20) && (best < 0 || g_pool[i].bytes < g_pool[(size_t)best].bytes)) best = (int)i;
+        if (best >= 0) { *p = g_pool[(size_t)best].p; g_pool.erase(g_pool.begin() + best); return hipSuccess; }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {
+        // out of memory with buffers kept aside: give them back and try once more
+        (void)hipGetLastError();
+        pool_clear();
+        e = hipMalloc(p, bytes);
+    }
+    return e;
+}
+
+void pool_free(void* p, size_t bytes, int device)
+{
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        size_t total = bytes;
+        for (const auto& e : g_pool) total += e.bytes;
+        if (g_process_inits.load() > 0 && g_pool.size() < kPoolEntries && total <= kPoolBytes && bytes >= (1u << 20)) { g_pool.push_back({ device, p, bytes }); return; }
+    }
+    hipFree(p);
+}
+
+void pool_clear()
+{
+    std::vector<PoolEntry> drop;
+    { std::lock_guard<std::mutex> lock(g_pool_mutex); drop.swap(g_pool); }
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    for (const auto& e : drop) { (void)hipSetDevice(e.device); hipFree(e.p); }
+    if (prev >= 0) (void)hipSetDevice(prev);
+}
+
 static int carve(AobBake* b, const ArenaPlan& plan)
 {
     size_t total = 0;
     for (const auto& w : plan.wants) total += (w.bytes + 255) & ~(size_t)255;
-    AOB_HIP(hipMalloc((void**)&b->arena, total ? total : 256));
-    b->arena_bytes = total;
+    AOB_HIP(pool_alloc((void**)&b->arena, total ? total : 256, b->device));
+    b->arena_bytes = total ? total : 256;
     size_t at = 0;
     for (const auto& w : plan.wants) { *w.slot = b->arena + at; at += (w.bytes + 255) & ~(size_t)255; }
     return AOB_OK;
@@ -157,13 +206,13 @@ static void free_bake(AobBake* b)
     // buffers that were allocated (or re-allocated: the surfel lists of overlapping sections can outgrow W*H) on their own
     for (auto& m : b->materials) {
         release_device(b, m.prev_layer); release_device(b, m.surfels); release_device(b, m.section_index); release_device(b, m.frames); release_device(b, m.perm);
-        release_device(b, m.tile_cuts);
-        if (m.horizon) hipFree(m.horizon);
+        if (m.tile_cuts) pool_free(m.tile_cuts, sizeof(uint32_t) * m.tile_cut_capacity, b->device);
+        pool_free(m.horizon, m.horizon_capacity, b->device);
         if (m.tile_row_prefix_host) hipHostFree(m.tile_row_prefix_host);
     }
     release_device(b, b->gstack);
     release_device(b, b->acc_cells);
-    if (b->arena) hipFree(b->arena);
+    if (b->arena) pool_free(b->arena, b->arena_bytes, b->device);
     if (b->pinned) hipHostFree(b->pinned);
     for (auto& e : b->ev) if (e) hipEventDestroy(e);
     for (auto& e : b->ev_trace) if (e) hipEventDestroy(e);
@@ -337,8 +386,11 @@ void aob_shutdown(void)
         g_process_device.store(-1);
         // the last thread out: the process-wide hemisphere table (REFERENCE_COMPAT bakes: up to 200 MB of host memory) goes too; a bake that
         // is still uploading from it keeps its own reference
-        std::lock_guard<std::mutex> lock(g_table_mutex);
-        g_table.reset();
+        {
+            std::lock_guard<std::mutex> lock(g_table_mutex);
+            g_table.reset();
+        }
+        pool_clear();          // ... and the device buffers kept for the next bake
     }
 }
 

@@ -60,10 +60,10 @@ bool horizon_build(AobBake* b, DeviceMaterial& m, uint64_t begin, uint64_t end, 
     const uint64_t bytes = (uint64_t)stride * m.surfel_count;
     if (bytes > m.horizon_capacity) {
         (void)hipStreamSynchronize(b->stream);
-        if (m.horizon) hipFree(m.horizon);
+        pool_free(m.horizon, m.horizon_capacity, b->device);
         m.horizon = nullptr; m.horizon_capacity = 0;
         const uint64_t want = (uint64_t)stride * (m.surfel_capacity > m.surfel_count ? m.surfel_capacity : m.surfel_count);
-        if (hipMalloc((void**)&m.horizon, want) != hipSuccess) { (void)hipGetLastError(); m.horizon = nullptr; return false; }
+        if (pool_alloc((void**)&m.horizon, want, b->device) != hipSuccess) { (void)hipGetLastError(); m.horizon = nullptr; return false; }
         m.horizon_capacity = want;
     }
     HorizonParams p;

@@ -1431,9 +1431,9 @@ static bool ensure_tile_cuts(AobBake* b, DeviceMaterial& m, uint64_t words)
     // until the material is rasterised anew or a launch asks for less)
     if (m.tile_cut_failed && words >= m.tile_cut_failed) return false;
     (void)hipStreamSynchronize(b->stream);
-    release_device(b, m.tile_cuts);
+    if (m.tile_cuts) pool_free(m.tile_cuts, sizeof(uint32_t) * m.tile_cut_capacity, b->device);
     m.tile_cuts = nullptr; m.tile_cut_capacity = 0;
-    if (!g_fail_tile_cuts && hipMalloc((void**)&m.tile_cuts, sizeof(uint32_t) * words) == hipSuccess) { m.tile_cut_capacity = words; return true; }
+    if (!g_fail_tile_cuts && pool_alloc((void**)&m.tile_cuts, sizeof(uint32_t) * words, b->device) == hipSuccess) { m.tile_cut_capacity = words; return true; }
     (void)hipGetLastError();
     m.tile_cuts = nullptr;
     m.tile_cut_failed = words;
