@@ -326,9 +326,11 @@ int AobMultiGpuBake::Step(AobMultiStepStats* stats)
 		const bool reduce = !d.by_rows && overlapping[0] != 0;
 		// phase 2a: every rank ENQUEUES its side of the one exchange step (nothing waits here)
 		d.giving_up = false;
+		std::vector<double> posted((size_t)n, 0.0);          // when each rank began to post its side of the exchange (its gather time starts there)
 		rc = d.on_all([&, i, reduce](int r) -> int {
 			uint8_t* mine = d.results[(size_t)r][i];
 			hipStream_t stream = d.streams[(size_t)r];
+			posted[(size_t)r] = now_ms();
 			if (n > 1 && d.use_rccl)
 			{
 				ncclResult_t e = ncclSuccess;
@@ -411,7 +413,13 @@ int AobMultiGpuBake::Step(AobMultiStepStats* stats)
 					}
 					std::this_thread::sleep_for(std::chrono::microseconds(20));
 				}
-				gather_ms[(size_t)r] += now_ms() - t;
+				gather_ms[(size_t)r] += now_ms() - posted[(size_t)r];
+			}
+			else if (n > 1 && r == 0)
+			{
+				// ranks sharing a device: the strips were copied (or summed) on device 0's stream — its gather ends when that stream has drained
+				if (hipStreamSynchronize(d.streams[0]) != hipSuccess) { d.errors[0] = "hipStreamSynchronize after the strips' copies failed"; return AOB_ERR_DEVICE; }
+				gather_ms[0] += now_ms() - posted[0];
 			}
 			int s = AOB_OK;
 			if (r == 0) s = aob_bake_resolve(b, (int32_t)i);

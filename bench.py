@@ -421,7 +421,8 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     if rank == 0 and not args.no_cpp_host:
-        cpp = cpp_host_leg(scene, world, args)
+        # (a rehearsal's ranks share the visible devices: the C++ host is told the same, rank r on device r % visible)
+        cpp = cpp_host_leg(scene, world, args, [r % max(1, torch.cuda.device_count()) for r in range(world)] if (world > 1 and rehearsal) else None)
     if world > 1:
         dist.barrier(group=host_group)      # gloo: the peers wait on the host, their GPUs stay idle meanwhile
 
@@ -488,13 +489,32 @@ def main():
                 # what one GPU needed for each rank's strip of this atlas cut N ways, before any re-cut (tools/run_shapes.py ranks, the
                 # same kernel source): the first real N-GPU run's rank_build_raster_trace is to be read against these
                 line["expected_rank_ms"] = ((base or {}).get("rank_strip_ms") or {}).get(str(world))
+        if world > 1:
+            # with more than one GPU the headline is the C++ host's — ONE process, a host thread and an RCCL rank per device
+            # (aobaker_amd/host/MultiGpu.cpp: SURVEY 8(e)'s process model, the north star's "the repo's own C++") — timed by itself over the same K
+            # steps (barrier on all threads + stream drains on both sides, the slowest rank's time); the python ranks' figures stay beside it.
+            # Only a C++ run that printed the expected image counts; otherwise the python ranks' value stands and the line says why.
+            py = {"value": value, "ms_per_step": round(ms_per_step, 3), "host": line["config"]["host"]}
+            expected = line["config"]["image_crc32_expected"]
+            crcs = (cpp or {}).get("image_crc32") or []
+            cpp_ok = bool(cpp) and "error" not in cpp and cpp.get("value") and (expected is None or (len(crcs) > 0 and all(c == expected for c in crcs)))
+            if cpp_ok:
+                line["value"] = cpp["value"]; line["ms_per_step"] = cpp["ms_per_step"]; line["steps"] = cpp.get("steps", args.steps); line["warmup"] = cpp.get("warmup", args.warmup)
+                line["config"]["host"] = "C++: aobake_mgpu, one process, one host thread + one RCCL rank per device (ncclCommInitAll), strips gathered to rank 0 with grouped ncclSend / ncclRecv"
+                line["config"]["image_crc32"] = crcs[0]; line["config"]["image_crc32_ok"] = None if expected is None else True
+                line["stage_ms"]["rank_build_raster_trace"] = cpp.get("rank_ms"); line["stage_ms"]["rank_bvh_build"] = cpp.get("rank_bvh_build_ms")
+                line["stage_ms"]["rank_trace_kernel"] = cpp.get("rank_trace_kernel_ms"); line["stage_ms"]["gather_ms"] = cpp.get("gather_ms"); line["stage_ms"]["rank_gather_ms"] = cpp.get("rank_gather_ms")
+                line["value_from"] = "cpp_host"
+            else:
+                line["value_from"] = "python_ranks: " + ("the C++ host leg was skipped" if cpp is None else str((cpp or {}).get("error") or "the C++ host's image CRC is not the expected one"))
+            line["python_ranks"] = py
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpp_host_leg(scene, world, args):
+def cpp_host_leg(scene, world, args, devices=None):
     """`aobake_mgpu` on the same scene: one process, one host thread + one RCCL rank per device (MultiGpu.cpp)."""
     import tempfile
     from aobaker_amd import scenefile
@@ -505,11 +525,16 @@ def cpp_host_leg(scene, world, args):
         with tempfile.TemporaryDirectory() as tmp:
             path = os.path.join(tmp, "scene.aobs")
             scenefile.write_scene(scene, path)
-            cmd = [exe, "--scene", path, "--gpus", str(world), "--steps", str(max(1, min(args.steps, 5))), "--warmup", str(max(2, min(args.warmup, 3))),
+            # (N > 1: this run carries the line's `value` — exactly the K steps after W warm-ups the contract names; N = 1: a side-leg, bounded)
+            k_steps = args.steps if world > 1 else max(1, min(args.steps, 5))
+            k_warm = max(2, args.warmup) if world > 1 else max(2, min(args.warmup, 3))
+            cmd = [exe, "--scene", path, "--gpus", str(world), "--steps", str(k_steps), "--warmup", str(k_warm),
                    "--spp", str(args.spp), "--sampler", "1", "--accumulate", "1", "--seed", "3", "--any-hit", "1", "--normal-fp16", "0", "--builder", str(args.bvh_builder_resolved)]
             if args.no_balance:
                 cmd.append("--no-balance")
-            out = subprocess.run(cmd, capture_output=True, text=True, timeout=180)
+            if devices:
+                cmd += ["--devices", ",".join(str(d) for d in devices)]
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=180 if world == 1 else 420)
         if out.returncode != 0:
             return {"error": f"rc {out.returncode}: {out.stderr.strip()[-300:]}"}
         return json.loads(out.stdout.strip().splitlines()[-1])

@@ -154,7 +154,7 @@ def test_cpp_multi_gpu_host_config4_shape(engine, tmp_path):
     assert rec["image_crc32"] == [bench.CONFIG3_IMAGE_CRC32]
     # the step's anatomy is in the record: every rank's redundant tree build, its trace kernel, and what the gather cost rank 0
     assert len(rec["rank_bvh_build_ms"]) == 8 and all(0.0 < v < 50.0 for v in rec["rank_bvh_build_ms"]) and len(rec["rank_trace_kernel_ms"]) == 8
-    assert rec["gather_ms"] >= 0.0 and len(rec["rank_gather_ms"]) == 8
+    assert rec["gather_ms"] > 0.0 and len(rec["rank_gather_ms"]) == 8
     print("aobake_mgpu 8 ranks on one device:", json.dumps({k: rec[k] for k in ("ms_per_step", "rank_ms", "rows")}))
 
 

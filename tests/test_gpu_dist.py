@@ -78,6 +78,19 @@ def test_bench_rank_processes_rehearsed_on_one_gpu(ranks):  # eight ranks are re
     assert many["config"]["image_crc32"] == one["config"]["image_crc32"]
 
 
+def test_the_cpp_host_carries_the_headline_of_a_multi_gpu_line():
+    """with N > 1 `value` is the C++ host's (aobake_mgpu: one process, a thread + RCCL rank per device) — here rehearsed with two
+    ranks on the one device — the python ranks' figures beside it, both with the one-rank image."""
+    common = ["--atlas", 256, "--grid", 96, "--spp", 32, "--steps", 2, "--warmup", 2, "--no-cpu-baseline", "--no-wallclock"]
+    one = _bench("--gpus", 1, "--no-cpp-host", *common)
+    two = _bench("--gpus", 2, "--backend", "gloo", "--oversubscribe", *common)
+    assert two["value_from"] == "cpp_host", two.get("value_from")
+    assert two["value"] == two["cpp_host"]["value"] and two["ms_per_step"] == two["cpp_host"]["ms_per_step"]
+    assert two["python_ranks"]["value"] > 0 and "C++" in two["config"]["host"]
+    assert two["config"]["image_crc32"] == one["config"]["image_crc32"] == two["cpp_host"]["image_crc32"][0]
+    assert len(two["stage_ms"]["rank_build_raster_trace"]) == 2
+
+
 def test_bench_rank_failure_ends_the_run_with_an_error_line():
     """A rank that dies before the first gather (fault injected: AOB_BENCH_FAIL_RANK) ends the whole N-rank run in seconds —
     one JSON line with value null and the failing rank named, exit code non-zero — instead of the peers waiting in the
