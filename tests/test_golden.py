@@ -169,3 +169,21 @@ def test_gpu_reproduces_feature_golden(engine, name):
     engine.Bake(sc)
     assert np.array_equal(sc.GetMaterial(0).GetAOTexture().GetData(), FEATURES_GOLD[f"{name}_image"])
     assert engine.LastStats.ray_count == int(FEATURES_GOLD[f"{name}_counts"][1])
+
+
+def test_the_headline_images_are_pinned_by_a_complete_oracle_bake():
+    """tests/golden/fullsize_crc.json is written by tests/golden/make_fullsize_golden.py — the oracle baking BASELINE configs[2] and configs[3] completely,
+    every texel — and bench.py's expected image CRCs ARE its numbers (they used to be constants the GPU path had produced)."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    g = json.load(open(os.path.join(root, "tests", "golden", "fullsize_crc.json")))
+    assert g["2"]["image_crc32"] == bench.CONFIG2_IMAGE_CRC32 and g["2"]["rays"] == 2048 * 2048 * 256
+    assert g["3"]["image_crc32"] == bench.CONFIG3_IMAGE_CRC32 and g["3"]["rays"] == 4096 * 4096 * 256
+    for c, n in (("2", 2048), ("3", 4096)):
+        assert "every texel" in g[c]["made_by"] and g[c]["surfels"] == n * n
+        sub = __import__("numpy").load(os.path.join(root, "tests", "golden", f"fullsize_cells_{c}.npz"))
+        assert len(sub["cell_index"]) == (n // 16) ** 2

@@ -7,6 +7,7 @@ count bit for bit; at the full 256 spp the GPU image is checked through size-ind
 """
 import os
 
+
 import numpy as np
 import pytest
 
@@ -113,6 +114,14 @@ def test_config3_full_spp_properties(engine, orc, terrain, builder):
         img = np.zeros(2048 * 2048 * 4, dtype=np.uint8)
         b.download(0, img)
     assert zlib.crc32(img.tobytes()) == bench.CONFIG2_IMAGE_CRC32
+    # ... which, since round 6, is the ORACLE's number: tests/golden/make_fullsize_golden.py bakes this atlas completely on the CPU (1.07 G rays) and
+    # writes the CRC bench.py reads, the CRC of the cells, and the cells of every 16th texel in x and y — compared here without running the oracle
+    import json
+    golden = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fullsize_crc.json")))["2"]
+    assert golden["image_crc32"] == bench.CONFIG2_IMAGE_CRC32 and golden["surfels"] == 2048 * 2048
+    assert zlib.crc32(np.ascontiguousarray(first).tobytes()) == golden["cells_crc32"]
+    sub = np.load(os.path.join(os.path.dirname(__file__), "golden", "fullsize_cells_2.npz"))
+    assert np.array_equal(first["total_bits"][sub["cell_index"]], sub["total_bits"]) and np.array_equal(first["weight_bits"][sub["cell_index"]], sub["weight_bits"])
     ao = img.view(np.float32).reshape(2048, 2048)
     t = first["total_bits"].view(np.float32).reshape(2048, 2048)
     w = first["weight_bits"].view(np.float32).reshape(2048, 2048)

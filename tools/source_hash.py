@@ -26,7 +26,8 @@ def digest(blobs):
     for name in sorted(per):
         h.update(name.encode() + b"\0" + per[name].encode() + b"\n")
     k = hashlib.sha256()
-    for rel in ("aobaker_amd/csrc/trace.hip", "aobaker_amd/csrc/aob_math.h", "aobaker_amd/csrc/aob_internal.h", "aobaker_amd/csrc/bvh_build.hip"):      # bench.py KERNEL_SOURCES
+    for rel in ("aobaker_amd/csrc/trace.hip", "aobaker_amd/csrc/aob_math.h", "aobaker_amd/csrc/aob_internal.h", "aobaker_amd/csrc/bvh_build.hip",
+                "aobaker_amd/csrc/horizon_kernel.h", "aobaker_amd/csrc/horizon.hip"):      # bench.py KERNEL_SOURCES
         k.update(dict(blobs).get(rel, b""))
     return {"kernel_source_sha": h.hexdigest()[:16], "source_sha256_16": k.hexdigest()[:16], "files": per}
 

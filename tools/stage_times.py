@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""tools/stage_times.py — HIP-event times of the stages of one BASELINE configs[2] bake (aob_bake_last_stage_ms): the tree's build, the rasterisation, the
+trace stage and, inside it, the tile cuts, the horizon tables and k_trace; best of four traces.  AOBAKER_HIP_LIBRARY picks an A/B build
+(tools/build_variants.py).  Product code only."""
+import sys, os, json
+sys.path.insert(0, os.getcwd())
+from aobaker_amd import Baker, capi, scenes, BakeEngine
+from aobaker_amd.scene import FlatScene
+BakeEngine.Init(0)
+flat = FlatScene(scenes.terrain_scene(grid=708, atlas=2048, seed=3, bpc=4))
+o = capi.default_options(); o.sample_count=256; o.sampler=capi.SAMPLER_COSINE; o.seed=3; o.accumulate=capi.ACCUMULATE_FLOAT; o.normal_fp16=capi.FP16_OFF
+with Baker(flat, o) as b:
+    b.build_bvh(); b.rasterize(0)
+    best=None
+    for _ in range(4):
+        b.clear_results(0); b.trace(0); b.sync(); s=b.last_stage_ms()
+        if best is None or s["horizon"] < best["horizon"]: best=s
+    st=b.stats()
+    print(json.dumps({"lib": os.environ.get("AOBAKER_HIP_LIBRARY","in-tree").split("/")[-1], **{k: round(v,3) for k,v in best.items() if v is not None}, "cast_share": round(st.rays_cast/ max(1,st.ray_count),4)}), flush=True)

@@ -21,7 +21,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 enum Kind { FMA, PK_FMA, PERM, MAX3, MIN3_CLAMP, XOR, CNDMASK, ALIGNBIT, FMA_MIX, MUL, CMP, ADD_U32, LSHL_OR, RCP, MOV,
             FMA_SGPR, PERM_SGPR, BOX_PERM_PK, BOX_ALIGN_MIX, BOX_PERM_FMA, SALU_AND,
-            MAX_F32, CNDMASK_VCC, AND_B32, LSHLREV, CVT_UBYTE, CVT_F16, BFE, AND_OR, SUB_F32, MIX_1S1F, MIX_1S2F, MIX_2S1F, MIX_1S3F, BOX_PERM_PK2, KIND_COUNT };
+            MAX_F32, CNDMASK_VCC, AND_B32, LSHLREV, CVT_UBYTE, CVT_F16, BFE, AND_OR, SUB_F32, MIX_1S1F, MIX_1S2F, MIX_2S1F, MIX_1S3F, BOX_PERM_PK2, PK_FMA_F16, PK_MIN_F16, PK_MAX_F16, PK_ADD_F16, PK_MAX3_F16, BOXPAIR_F16, KIND_COUNT };
 static const char* kind_name[KIND_COUNT] = {
     "v_fma_f32", "v_pk_fma_f32", "v_perm_b32", "v_max3_f32", "v_min3_f32", "v_xor_b32", "v_cndmask_b32", "v_alignbit_b32",
     "v_fma_mix_f32", "v_mul_f32", "v_cmp_le_f32", "v_add_u32", "v_lshl_or_b32", "v_rcp_f32", "v_mov_b32",
@@ -30,13 +30,17 @@ static const char* kind_name[KIND_COUNT] = {
     "box: 6 v_perm_b32 + 6 v_fma_f32 + max3 + min3 + cmp", "s_and_b64",
     "v_max_f32", "v_cndmask_b32 (vcc, VOP2)", "v_and_b32", "v_lshlrev_b32", "v_cvt_f32_ubyte1", "v_cvt_f32_f16", "v_bfe_u32", "v_and_or_b32", "v_sub_f32",
     "mix: 1 v_perm_b32 + 1 v_fma_f32", "mix: 1 v_perm_b32 + 2 v_fma_f32", "mix: 2 v_perm_b32 + 1 v_fma_f32", "mix: 1 v_perm_b32 + 3 v_fma_f32",
-    "box: 6 v_perm_b32 + 3 v_pk_fma_f32 + max3 + min3 + cmp, no register copies" };
+    "box: 6 v_perm_b32 + 3 v_pk_fma_f32 + max3 + min3 + cmp, no register copies",
+    // round 6: the packed-fp16 opcodes the reference's fp16 walk tests TWO child boxes per instruction with (kernels/CL/intersect_bvh2_lds_fp16.cl:42-92)
+    "v_pk_fma_f16", "v_pk_min_f16", "v_pk_max_f16", "v_pk_add_f16", "v_pk_maximum3_f16",
+    "box PAIR in packed fp16: 6 v_pk_fma_f16 + 3 v_pk_min_f16 + 3 v_pk_max_f16 + v_pk_maximum3_f16 + v_pk_minimum3_f16 + v_pk_add_f16 (17 instructions for two boxes)" };
 // vector instructions per loop iteration
 static int kind_instr(int k)
 {
     switch (k) {
     case BOX_PERM_PK: case BOX_ALIGN_MIX: case BOX_PERM_PK2: return 16 * 12;
     case BOX_PERM_FMA: return 16 * 15;
+    case BOXPAIR_F16: return 16 * 17;
     case MIX_1S1F: return 16 * 4; case MIX_1S2F: return 16 * 6; case MIX_2S1F: return 16 * 6; case MIX_1S3F: return 16 * 8;
     default: return 64;
     }
@@ -190,6 +194,33 @@ __global__ __launch_bounds__(64) void k_probe(uint64_t* stamps, float* out, int 
                 : [n0] "=&v"(a0), [f0] "=&v"(a1), [n1] "=&v"(a2), [f1] "=&v"(a3), [n2] "=&v"(p3.x), [f2] "=&v"(p3.y), [q0] "+v"(p0), [q1] "+v"(p1), [q2] "+v"(p2)
                 : [nx] "v"(nx), [ny] "v"(ny), [nz] "v"(nz), [sn] "v"(sel), [sf] "v"(sel2),
                   [pix] "v"(pix), [piy] "v"(piy), [piz] "v"(piz), [pox] "v"(pox), [poy] "v"(poy), [poz] "v"(poz) : "vcc");)
+        } else if (KIND == PK_FMA_F16) {
+            REP16(asm volatile("v_pk_fma_f16 %0, %0, %4, %5\n v_pk_fma_f16 %1, %1, %4, %5\n v_pk_fma_f16 %2, %2, %4, %5\n v_pk_fma_f16 %3, %3, %4, %5"
+                               : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(sel), "v"(sel2));)
+        } else if (KIND == PK_MIN_F16) {
+            REP16(asm volatile("v_pk_min_f16 %0, %0, %4\n v_pk_min_f16 %1, %1, %4\n v_pk_min_f16 %2, %2, %4\n v_pk_min_f16 %3, %3, %4"
+                               : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(sel));)
+        } else if (KIND == PK_MAX_F16) {
+            REP16(asm volatile("v_pk_max_f16 %0, %0, %4\n v_pk_max_f16 %1, %1, %4\n v_pk_max_f16 %2, %2, %4\n v_pk_max_f16 %3, %3, %4"
+                               : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(sel));)
+        } else if (KIND == PK_ADD_F16) {
+            REP16(asm volatile("v_pk_add_f16 %0, %0, %4\n v_pk_add_f16 %1, %1, %4\n v_pk_add_f16 %2, %2, %4\n v_pk_add_f16 %3, %3, %4"
+                               : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(sel));)
+        } else if (KIND == PK_MAX3_F16) {
+            REP16(asm volatile("v_pk_maximum3_f16 %0, %0, %4, %5\n v_pk_maximum3_f16 %1, %1, %4, %5\n v_pk_maximum3_f16 %2, %2, %4, %5\n v_pk_maximum3_f16 %3, %3, %4, %5"
+                               : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(sel), "v"(sel2));)
+        } else if (KIND == BOXPAIR_F16) {
+            // two child boxes at once: planes as half2 {box A, box B} per axis and side, t = plane * invdir + oxinvdir (6), near / far per axis (3 + 3),
+            // the three nears' maximum and the three fars' minimum (2), far - near: both sign bits (1)
+            REP16(asm volatile(
+                "v_pk_fma_f16 %[a0], %[nx], %[ix], %[ox]\n v_pk_fma_f16 %[a1], %[ny], %[ix], %[ox]\n v_pk_fma_f16 %[a2], %[nz], %[iy], %[oy]\n"
+                "v_pk_fma_f16 %[a3], %[nx], %[iy], %[oy]\n v_pk_fma_f16 %[b0], %[ny], %[iz], %[oz]\n v_pk_fma_f16 %[b1], %[nz], %[iz], %[oz]\n"
+                "v_pk_min_f16 %[b2], %[a0], %[a1]\n v_pk_max_f16 %[a0], %[a0], %[a1]\n v_pk_min_f16 %[a1], %[a2], %[a3]\n v_pk_max_f16 %[a2], %[a2], %[a3]\n"
+                "v_pk_min_f16 %[a3], %[b0], %[b1]\n v_pk_max_f16 %[b0], %[b0], %[b1]\n"
+                "v_pk_maximum3_f16 %[b2], %[b2], %[a1], %[a3]\n v_pk_minimum3_f16 %[a0], %[a0], %[a2], %[b0]\n v_pk_add_f16 %[a0], %[a0], %[b2] neg_lo:[0,1] neg_hi:[0,1]\n"
+                "v_pk_max_f16 %[b2], %[b2], %[b2]\n v_pk_min_f16 %[a0], %[a0], %[a0]"
+                : [a0] "=&v"(u0), [a1] "=&v"(u1), [a2] "=&v"(u2), [a3] "=&v"(u3), [b0] "=&v"(sb), [b1] "=&v"(rot), [b2] "=&v"(sel2)
+                : [nx] "v"(nx), [ny] "v"(ny), [nz] "v"(nz), [ix] "v"(sel), [iy] "v"(nx), [iz] "v"(ny), [ox] "v"(nz), [oy] "v"(nx), [oz] "v"(ny));)
         } else if (KIND == SALU_AND) {
             REP16(asm volatile("s_and_b64 %0, %0, %1\n s_and_b64 %0, %0, %1\n s_and_b64 %0, %0, %1\n s_and_b64 %0, %0, %1" : "+s"(sm) : "s"(sn) : "scc");)
         }
