@@ -23,7 +23,7 @@ FAST = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_f
 
 def main():
     src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "aobaker_amd", "csrc", "trace.hip")
-    want = sys.argv[2] if len(sys.argv) > 2 else "_ZN3aob7k_traceILi1ELi1ELi1ELi11ELi2ELi0ELi1EEEvNS_11TraceParamsE"
+    want = sys.argv[2] if len(sys.argv) > 2 else "_ZN3aob7k_traceILi1ELi1ELi1ELi11ELi2ELi0ELi1ELi1EEEvNS_11TraceParamsE"
     flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
              "-fno-slp-vectorize"]                                     # aobaker_amd/csrc/Makefile
     with tempfile.TemporaryDirectory() as tmp:
