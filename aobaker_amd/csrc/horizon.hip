@@ -82,8 +82,11 @@ bool horizon_build(AobBake* b, DeviceMaterial& m, uint64_t begin, uint64_t end, 
     p.counters = b->horizon_diag ? b->horizon_counters : nullptr;
     const uint32_t tiles = (uint32_t)((end - begin + kHzWave - 1) / kHzWave);
     auto launch = [&](uint32_t blocks) {
-        if (g.sx <= 16 && g.sy <= 16) hipLaunchKernelGGL((k_horizon<16, true>), dim3(blocks), dim3(kHzWave), 0, b->stream, p);
-        else hipLaunchKernelGGL((k_horizon<32, false>), dim3(blocks), dim3(kHzWave), 0, b->stream, p);
+#ifndef AOB_HZ_DYN_LDS
+#define AOB_HZ_DYN_LDS 0             // measurement builds: unused dynamic LDS per workgroup, to lower the wavefronts a CU holds
+#endif
+        if (g.sx <= 16 && g.sy <= 16) hipLaunchKernelGGL((k_horizon<16, true>), dim3(blocks), dim3(kHzWave), AOB_HZ_DYN_LDS, b->stream, p);
+        else hipLaunchKernelGGL((k_horizon<32, false>), dim3(blocks), dim3(kHzWave), AOB_HZ_DYN_LDS, b->stream, p);
     };
     // ---- are they worth it HERE?  The tables cost time per surfel and save time per sample they resolve: on BASELINE configs[2] they resolve 58 % of the
     // samples and the trace gains 8 %; on configs[4]'s rocks — every surfel hemmed in by its neighbours within the rays' 1.25 — they resolve 0.4 % and

@@ -10,8 +10,33 @@ namespace aob {
 static constexpr int kHzWave = 64;
 static constexpr int kHzGroups = 8;              // groups of 64 / kHzGroups consecutive origins a middle-distance leaf is measured against (16: tighter, twice the work)
 static constexpr int kHzSectors = 32;            // sectors of the tile's horizon H
-static constexpr int kHzOpenCap = 512;           // open nodes of the walk (LDS); a node that does not fit raises H by its own box instead
-static constexpr int kHzNearCap = 384;           // near triangles per tile; more: the tile gets no culling (every cell blocked)
+#ifndef AOB_HZ_OPEN_CAP
+#define AOB_HZ_OPEN_CAP 512
+#endif
+#ifndef AOB_HZ_NEAR_CAP
+#define AOB_HZ_NEAR_CAP 384
+#endif
+// (nothing here is part of the arithmetic contract of DESIGN.md §4 — the tables are bounds with margins, not results — so multiply-adds may fuse: a tenth of the kernel's instructions)
+#if defined(__clang__) && !defined(AOB_HZ_NO_CONTRACT)
+#pragma clang fp contract(fast)
+#endif
+#ifndef AOB_HZ_LANE_CHILD
+#define AOB_HZ_LANE_CHILD 1        // phase A: 1 a lane a child box (16 nodes a round), 0 a lane a node (64 a round, its children one after the other)
+#endif
+#ifndef AOB_HZ_LEAFQ
+#define AOB_HZ_LEAFQ (AOB_HZ_LANE_CHILD ? 128 : 512)
+#endif
+#ifndef AOB_HZ_WAVES
+#define AOB_HZ_WAVES 0
+#endif
+#if AOB_HZ_WAVES
+#define AOB_HZ_BOUNDS __launch_bounds__(kHzWave, AOB_HZ_WAVES)
+#else
+#define AOB_HZ_BOUNDS __launch_bounds__(kHzWave)
+#endif
+static constexpr int kHzLeafQ = AOB_HZ_LEAFQ;        // middle-distance leaves a round can put aside (LDS); one more raises H by its box, as a far leaf does
+static constexpr int kHzOpenCap = AOB_HZ_OPEN_CAP;   // open nodes of the walk (LDS); a node that does not fit raises H by its own box instead
+static constexpr int kHzNearCap = AOB_HZ_NEAR_CAP;           // near triangles per tile; more: the tile gets no culling (every cell blocked)
 static constexpr int kHzMaxRounds = 1024;
 static constexpr uint32_t kHzEmptyPlanes = 0x8000ffffu;
 static constexpr float kMarginU = 2e-3f;         // on u1 (a column of a 32-column grid is 0.031 wide)
@@ -58,6 +83,9 @@ struct HorizonParams {
 __device__ __forceinline__ float hz_uni(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
 __device__ __forceinline__ float hz_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
 __device__ __forceinline__ float hz_rsq(float v) { return __builtin_amdgcn_rsqf(v); }
+// sqrt from above / from below (v_sqrt_f32 is good to 1 ulp; the file's correctly rounded sqrtf is a dozen instructions)
+__device__ __forceinline__ float hz_sqrt_up(float v) { return __builtin_amdgcn_sqrtf(v) * 1.0000004f; }
+__device__ __forceinline__ float hz_sqrt_down(float v) { return __builtin_amdgcn_sqrtf(v) * 0.9999996f; }
 
 // atan2(y, x) in turns, (-0.5, 0.5]; |error| < 4e-6 turns (Abramowitz & Stegun 4.4.49 on the octant's ratio)
 __device__ __forceinline__ float hz_atan2_turns(float y, float x)
@@ -110,27 +138,31 @@ __device__ __forceinline__ uint32_t hz_sector_range32(float lo, float hi, bool f
     return (uint32_t)(a & 31) | ((uint32_t)cnt << 8);
 }
 
+__device__ __forceinline__ float hz_dot(const f3& a, const f3& b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }   // (aob_math.h's dot() keeps the contract's unfused products)
 __device__ __forceinline__ float hz_wave_min(float v) { for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off)); return v; }
 __device__ __forceinline__ float hz_wave_max(float v) { for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off)); return v; }
 __device__ __forceinline__ float hz_wave_sum(float v) { for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off); return v; }
 
 struct HzLeaf { uint32_t ref, key; };                 // key: first sector | sectors << 5 | margin (sin, 1 / 16384ths, rounded up) << 11
-struct HzWalk { uint32_t open_ref[kHzOpenCap]; uint32_t open_key[kHzOpenCap]; HzLeaf leafq[4 * kHzWave]; };
-union HzScratch { HzWalk walk; float arcs[kHzWave][12]; };
+struct HzWalk { uint32_t open_ref[kHzOpenCap]; uint32_t open_key[kHzOpenCap]; HzLeaf leafq[kHzLeafQ]; };
+// phase A's lists are dead when phases B and C start: the local tables and phase C's arcs live in their storage (10.1 -> 8.1 KB of LDS per tile for 16-row
+// tables: five wavefronts per SIMD instead of four — the kernel waits on its own round trips, and its time follows the wavefronts a SIMD holds: 9.9 / 7.7 / 6.0 ms at 2 / 3 / 4)
+template <int CMAX, bool T16> struct HzLate { float arcs[kHzWave][12]; uint32_t table[CMAX * kHzWave / (T16 ? 2 : 1)]; };
+template <int CMAX, bool T16> union HzScratch { HzWalk walk; HzLate<CMAX, T16> late; };
 
 template <int CMAX, bool T16>
-__global__ __launch_bounds__(kHzWave)
+__global__ AOB_HZ_BOUNDS
 void k_horizon(HorizonParams p)
 {
-    __shared__ HzScratch scratch;                    // phase A's lists, then phase C's arcs
+    __shared__ HzScratch<CMAX, T16> scratch;         // phase A's lists, then the local tables and phase C's arcs
     uint32_t* const open_ref = scratch.walk.open_ref;   // phase A: the nodes to open (bit 31: a near node), last in first out
     uint32_t* const open_key = scratch.walk.open_key;   // ... and what the box they came from measured: top (16 bits, rounded up) | first sector << 16 | sectors << 21
     HzLeaf* const leafq = scratch.walk.leafq;        // a round's middle-distance leaves
-    float (* const arcs)[12] = scratch.arcs;         // phase C: b, n, n x a, b x n of every arc (a = the arc before's b)
+    float (* const arcs)[12] = scratch.late.arcs;         // phase C: b, n, n x a, b x n of every arc (a = the arc before's b)
     __shared__ uint32_t near_tri[kHzNearCap];
     __shared__ uint32_t H[kHzSectors];               // bits of (sin E + 2): positive floats order like integers
     __shared__ float grp[kHzGroups][8];              // the boxes of the tile's groups of consecutive origins, in the tile's frame: lo xyz, hi xyz, valid
-    __shared__ uint32_t table[CMAX * kHzWave / (T16 ? 2 : 1)];    // local tables: [column][lane] = rows blocked FROM that column (cumulated at the end); T16: 16 rows, two lanes a word
+    uint32_t* const table = scratch.late.table;      // (phases B and C) local tables: [column][lane] = rows blocked FROM that column (cumulated at the end); T16: 16 rows, two lanes a word
 
     const uint32_t lane = threadIdx.x;
     const uint64_t k = p.begin + (uint64_t)blockIdx.x * p.tile_stride * kHzWave + lane;
@@ -146,8 +178,8 @@ void k_horizon(HorizonParams p)
         P = make_f3(a.x, a.y, a.z);
         const f3 N = make_f3(a.w, b.x, b.y), X = make_f3(b.z, b.w, c.x), Z = make_f3(c.y, c.z, c.w);
         const f3 nz = cross(N, Z), zx = cross(Z, X), xn = cross(X, N);
-        const float det = dot(X, nz);
-        const float nn = dot(N, N);
+        const float det = hz_dot(X, nz);
+        const float nn = hz_dot(N, N);
         if (valid && fabsf(det) > 1e-12f && det == det && nn > 1e-20f) {
             const float id = 1.0f / det;
             Xd = make_f3(nz.x * id, nz.y * id, nz.z * id);
@@ -157,7 +189,7 @@ void k_horizon(HorizonParams p)
             Nw = make_f3(N.x * il, N.y * il, N.z * il);
             // (the bounds below want the duals of a frame that is orthonormal up to rounding and to the 0.0001 by which an axis frame's normal may lean:
             // anything else — a frame the sampler itself would make garbage of — gets no culling)
-            const float lx = dot(Xd, Xd), lz = dot(Zd, Zd), ln = dot(Nd, Nd) * nn;
+            const float lx = hz_dot(Xd, Xd), lz = hz_dot(Zd, Zd), ln = hz_dot(Nd, Nd) * nn;
             framed = finite3(Xd) && finite3(Nd) && finite3(Zd) && lx > 0.9f && lx < 1.1f && lz > 0.9f && lz < 1.1f && ln > 0.9f && ln < 1.1f;
         }
     }
@@ -182,7 +214,7 @@ void k_horizon(HorizonParams p)
     f3 thi = make_f3(hz_wave_max(framed ? P.x : -big), hz_wave_max(framed ? P.y : -big), hz_wave_max(framed ? P.z : -big));
     f3 Nt = make_f3(hz_wave_sum(framed ? Nw.x : 0.f), hz_wave_sum(framed ? Nw.y : 0.f), hz_wave_sum(framed ? Nw.z : 0.f));
     {
-        const float l2 = dot(Nt, Nt);
+        const float l2 = hz_dot(Nt, Nt);
         if (l2 > 1e-12f) { const float il = 1.0f / sqrtf(l2); Nt = make_f3(Nt.x * il, Nt.y * il, Nt.z * il); }
         else Nt = make_f3(0.f, 1.f, 0.f);
     }
@@ -197,7 +229,7 @@ void k_horizon(HorizonParams p)
     }
     tlo = make_f3(hz_uni(tlo.x), hz_uni(tlo.y), hz_uni(tlo.z)); thi = make_f3(hz_uni(thi.x), hz_uni(thi.y), hz_uni(thi.z));
     Xt = make_f3(hz_uni(Xt.x), hz_uni(Xt.y), hz_uni(Xt.z)); Nt = make_f3(hz_uni(Nt.x), hz_uni(Nt.y), hz_uni(Nt.z)); Zt = make_f3(hz_uni(Zt.x), hz_uni(Zt.y), hz_uni(Zt.z));
-    const f3 fP = make_f3(dot(Xt, P), dot(Nt, P), dot(Zt, P));          // the origin in the tile's frame
+    const f3 fP = make_f3(hz_dot(Xt, P), hz_dot(Nt, P), hz_dot(Zt, P));          // the origin in the tile's frame
     f3 flo = make_f3(hz_wave_min(framed ? fP.x : big), hz_wave_min(framed ? fP.y : big), hz_wave_min(framed ? fP.z : big));
     f3 fhi = make_f3(hz_wave_max(framed ? fP.x : -big), hz_wave_max(framed ? fP.y : -big), hz_wave_max(framed ? fP.z : -big));
     {
@@ -228,7 +260,6 @@ void k_horizon(HorizonParams p)
 
     if (AOB_HZ_SKIP & 64) { if (r_near2 + r_mid2 + fc.x + te.x + aXt.x + qo.x + qs.x == 12345.678f) p.out[0] = 1; return; }
     if (lane < (uint32_t)kHzSectors) H[lane] = __float_as_uint(1.0f);          // sin E = -1: nothing blocked
-    for (int c = 0; c < C; c++) { if (!T16 || lane < 32u) table[c * (kHzWave / (T16 ? 2 : 1)) + (int)lane] = 0u; }
     if (lane == 0) { open_ref[0] = 0x80000000u; open_key[0] = 0xffffffffu; }       // the root, as a near node: opened whatever the horizon
     HZ_SYNC();
 
@@ -264,6 +295,9 @@ void k_horizon(HorizonParams p)
             if (lane < 32u && ((lane - f) & 31u) < n) atomicMax(&H[lane], t);
         }
     };
+    int n_leafq = 0;                 // middle-distance leaves put aside: measured when a wavefront's worth has come together (or the walk is over)
+    constexpr int kLeafFlush = kHzLeafQ - kHzWave * (AOB_HZ_LANE_CHILD ? 1 : 4);      // (a round adds at most a leaf a child)
+    static_assert(kLeafFlush >= 0, "AOB_HZ_LEAFQ: room for a round's leaves");
     while (open_n > 0 && !(AOB_HZ_SKIP & 8)) {
         if (++rounds > kHzMaxRounds) break;
         {
@@ -271,12 +305,16 @@ void k_horizon(HorizonParams p)
             for (int off = 16; off > 0; off >>= 1) hv = min(hv, (uint32_t)__shfl_xor((int)hv, off));
             h_low = (uint32_t)__builtin_amdgcn_readfirstlane((int)hv);
         }
-        // ---- a round: every lane opens one node of the list's top (up to 64), its four children one after the other ----
+        // ---- a round: the nodes of the list's top, up to 16, four lanes a node, every lane one child box ----
+        // (the walk's list is short at its start and at its end: with a lane a NODE and its children one after the other — 64 nodes a round — 36 lanes of 64 had
+        // one on the terrain, and every lane went through the ~450 instructions of a box four times a round; a lane a CHILD fills the wavefront from 16 nodes)
         // (as many as the list can take the children of: a node leaves the list and up to four enter it)
-        const int take = min(min(kHzWave, open_n), max(1, (kHzOpenCap - open_n) / 3));
-        bool have = (int)lane < take;
+        constexpr int kPer = AOB_HZ_LANE_CHILD ? 4 : 1;          // lanes a node
+        const int slot = (int)lane / kPer;
+        const int take = min(min(kHzWave / kPer, open_n), max(1, (kHzOpenCap - open_n) / 3));
+        bool have = slot < take;
         uint32_t node = 0u, key = 0u;
-        if (have) { node = open_ref[open_n - 1 - (int)lane]; key = open_key[open_n - 1 - (int)lane]; }
+        if (have) { node = open_ref[open_n - 1 - slot]; key = open_key[open_n - 1 - slot]; }
         open_n -= take;
         const bool near_node = (node >> 31) != 0u;
         node &= 0x7fffffffu;
@@ -287,9 +325,8 @@ void k_horizon(HorizonParams p)
         }
         uint4 kid[4];
 #pragma unroll
-        for (int ci = 0; ci < 4; ci++) kid[ci] = have ? p.nodes4q[4ull * node + ci] : make_uint4(kHzEmptyPlanes, kHzEmptyPlanes, kHzEmptyPlanes, 0u);
-        int n_leafq = 0;
-        for (int ci = 0; ci < 4; ci++) {
+        for (int ci = 0; ci < 4 / kPer; ci++) kid[ci] = have ? p.nodes4q[4ull * node + (kPer == 4 ? (lane & 3u) : (uint32_t)ci)] : make_uint4(kHzEmptyPlanes, kHzEmptyPlanes, kHzEmptyPlanes, 0u);
+        for (int ci = 0; ci < 4 / kPer; ci++) {
             const uint4 c = kid[ci];
             bool live = have && !(c.x == kHzEmptyPlanes && c.y == kHzEmptyPlanes && c.z == kHzEmptyPlanes);
             if (__ballot(live) == 0ull) continue;
@@ -308,9 +345,9 @@ void k_horizon(HorizonParams p)
             const bool far = live && !near;
             // ---- far boxes: top and arc in the tile's frame, the box grown by the tile's extent ----
             const f3 cw = make_f3(0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)), ew = make_f3(0.5f * (hi.x - lo.x), 0.5f * (hi.y - lo.y), 0.5f * (hi.z - lo.z));
-            const f3 v = make_f3(dot(Xt, cw) - fc.x, dot(Nt, cw) - fc.y, dot(Zt, cw) - fc.z);
+            const f3 v = make_f3(hz_dot(Xt, cw) - fc.x, hz_dot(Nt, cw) - fc.y, hz_dot(Zt, cw) - fc.z);
             const float slack = 2e-6f * (fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(fc.x) + fabsf(fc.y) + fabsf(fc.z));
-            const f3 e = make_f3(dot(aXt, ew) + te.x + slack, dot(aNt, ew) + te.y + slack, dot(aZt, ew) + te.z + slack);
+            const f3 e = make_f3(hz_dot(aXt, ew) + te.x + slack, hz_dot(aNt, ew) + te.y + slack, hz_dot(aZt, ew) + te.z + slack);
             const float a0 = v.x - e.x, a1 = v.x + e.x, b1 = v.y + e.y, g0 = v.z - e.z, g1 = v.z + e.z;
             const float rx = fmaxf(fmaxf(a0, -a1), 0.0f), rz = fmaxf(fmaxf(g0, -g1), 0.0f);
             const float rmin2 = rx * rx + rz * rz;
@@ -323,10 +360,10 @@ void k_horizon(HorizonParams p)
             // the arc of azimuths: the grown rectangle's bounding circle about its centre (cheaper than its four corners, and the rectangle is nearly a square)
             const float rc2 = v.x * v.x + v.z * v.z, R2c = e.x * e.x + e.z * e.z;
             const float thc = hz_atan2_turns(v.z, v.x);
-            const float alpha = (around || rc2 <= R2c) ? 0.5f : hz_asin_turns_up(sqrtf(R2c * hz_rcp(rc2)) * 1.0001f);
+            const float alpha = (around || rc2 <= R2c) ? 0.5f : hz_asin_turns_up(hz_sqrt_up(R2c * hz_rcp(rc2)) * 1.0001f);
             uint32_t rng = hz_sector_range32(thc - alpha, thc + alpha, around || alpha >= 0.25f);
             const bool over = over_horizon(top, rng, far);
-            const float ang2 = dot(e, e) * hz_rcp(fmaxf(dot(v, v), 1e-30f));
+            const float ang2 = hz_dot(e, e) * hz_rcp(fmaxf(hz_dot(v, v), 1e-30f));
             const bool relevant = far && over;
             // (a leaf whose grown box stands over the tile may hold the pole of some origin in its INTERIOR, where no vertex or edge sees it: its box's top, 1, it is)
             const bool mid_leaf = relevant && leaf && gap2 <= r_mid2 && gap2 > 0.0f && !around;
@@ -373,18 +410,25 @@ void k_horizon(HorizonParams p)
                 if (mid_leaf) {
                     // the arc's bulge over its ends: an edge of angular length w rises at most w^2 / 7 (in sine) over the higher end; w <= box diagonal / gap
                     // (1 / cos(w / 2) - 1 <= w^2 / 7 up to w = 1.2)
-                    const float w2 = 4.0f * dot(ew, ew) * hz_rcp(gap2) * 1.001f;
+                    const float w2 = 4.0f * hz_dot(ew, ew) * hz_rcp(gap2) * 1.001f;
                     const float mg = (w2 <= 1.0f ? w2 * (1.0f / 7.0f) : 2.0f) + kMarginF;
                     HzLeaf lf; lf.ref = c.w; lf.key = (rng & 31u) | ((rng >> 8) << 5) | ((uint32_t)fminf(ceilf(mg * 16384.0f), 32768.0f) << 11);
-                    leafq[n_leafq + __popcll(ml & below)] = lf;
+                    if (n_leafq + __popcll(ml & below) < kHzLeafQ) leafq[n_leafq + __popcll(ml & below)] = lf;
                 }
-                n_leafq += __popcll(ml);
+                if (n_leafq + __popcll(ml) > kHzLeafQ) {
+                    const bool spill_leaf = mid_leaf && n_leafq + __popcll(ml & below) >= kHzLeafQ;
+                    raise(top, rng, spill_leaf);
+                }
+                n_leafq = min(n_leafq + __popcll(ml), kHzLeafQ);
             }
         }
         if (give_up) break;
-        // ---- the round's middle-distance leaves, 16 at a time: four lanes a leaf, each lane its vertices against a quarter of the groups' boxes ----
-        n_leaves += (unsigned long long)n_leafq;
-        if (n_leafq && !(AOB_HZ_SKIP & 4)) {
+        // ---- the middle-distance leaves put aside, 16 at a time: four lanes a leaf, each lane its vertices against a quarter of the groups' boxes ----
+        // (not round by round — five leaves a round on the terrain, a third of a batch — but when 64 and more wait, or nothing is left to open: until then the horizon
+        // is the lower for it and keeps a box or two more; the bounds hold whenever they are applied)
+        const bool flush = n_leafq > kLeafFlush || open_n == 0 || rounds == kHzMaxRounds;
+        if (flush) n_leaves += (unsigned long long)n_leafq;
+        if (n_leafq && flush && !(AOB_HZ_SKIP & 4)) {
             HZ_SYNC();
             for (int base = 0; base < n_leafq; base += 16) {
                 const int j = base + (int)(lane >> 2), g0i = (int)(lane & 3u) * (kHzGroups / 4);
@@ -397,7 +441,7 @@ void k_horizon(HorizonParams p)
                     const int nv = (q.ref & 0x40000000u) ? 6 : 3;
                     for (int vi = 0; vi < nv; vi++) {
                         const float4 w = p.leaf_tris[3ull * tri + vi];
-                        const f3 f = make_f3(dot(Xt, make_f3(w.x, w.y, w.z)), dot(Nt, make_f3(w.x, w.y, w.z)), dot(Zt, make_f3(w.x, w.y, w.z)));
+                        const f3 f = make_f3(hz_dot(Xt, make_f3(w.x, w.y, w.z)), hz_dot(Nt, make_f3(w.x, w.y, w.z)), hz_dot(Zt, make_f3(w.x, w.y, w.z)));
                         const float sl = 2e-6f * (fabsf(f.x) + fabsf(f.y) + fabsf(f.z));
 #pragma unroll
                         for (int gi = 0; gi < kHzGroups / 4; gi++) {
@@ -418,6 +462,7 @@ void k_horizon(HorizonParams p)
                 if (__ballot(lead) != 0ull) raise(fminf(el + (float)(q.key >> 11) * (1.0f / 16384.0f), 1.0f), (q.key & 31u) | (((q.key >> 5) & 63u) << 8), lead);
             }
         }
+        if (flush) n_leafq = 0;
         HZ_SYNC();
     }
     if (!give_up && open_n > 0) {
@@ -438,6 +483,8 @@ void k_horizon(HorizonParams p)
         atomicAdd(&p.counters[3], n_leaves); atomicAdd(&p.counters[4], give_up ? 1ull : 0ull); atomicAdd(&p.counters[5], 1ull);
     }
     if (give_up) { write_out(zero8); return; }
+    HZ_SYNC();
+    for (int c = 0; c < C; c++) { if (!T16 || lane < 32u) table[c * (kHzWave / (T16 ? 2 : 1)) + (int)lane] = 0u; }      // (in the walk's storage: it is done with)
     HZ_SYNC();
 #ifdef AOB_HORIZON_EMU
     if (p.dbg && lane < 32u) p.dbg[blockIdx.x * 32u + lane] = __uint_as_float(H[lane]) - 2.0f;
@@ -470,7 +517,7 @@ void k_horizon(HorizonParams p)
 #pragma unroll
         for (int vi = 0; vi < 3; vi++) {
             const f3 d = make_f3(tw[4 * vi] - P.x, tw[4 * vi + 1] - P.y, tw[4 * vi + 2] - P.z);
-            al[vi] = dot(Xd, d); be[vi] = dot(Nd, d); ga[vi] = dot(Zd, d);
+            al[vi] = hz_dot(Xd, d); be[vi] = hz_dot(Nd, d); ga[vi] = hz_dot(Zd, d);
         }
         const float bmax = fmaxf(fmaxf(be[0], be[1]), be[2]);
         const bool want = framed && bmax > -1e-7f;
@@ -487,7 +534,7 @@ void k_horizon(HorizonParams p)
         const float mnx = fminf(fminf(al[0], al[1]), al[2]), mxx = fmaxf(fmaxf(al[0], al[1]), al[2]);
         const float mnz = fminf(fminf(ga[0], ga[1]), ga[2]), mxz = fmaxf(fmaxf(ga[0], ga[1]), ga[2]);
         const float bx = fmaxf(fmaxf(mnx, -mxx), 0.0f), bz = fmaxf(fmaxf(mnz, -mxz), 0.0f);
-        const float R = sqrtf(R2), rc = sqrtf(rc2);
+        const float R = hz_sqrt_up(R2), rc = hz_sqrt_down(rc2);
         const float cd = fmaxf(rc - R, 0.0f);
         const float d2 = fmaxf(bx * bx + bz * bz, cd * cd) * 0.9999f;
         const float ua = d2 * hz_rcp(d2 + bm * bm) * 0.99999f;
@@ -535,7 +582,7 @@ void k_horizon(HorizonParams p)
         const f3 a = (lane & 1u) ? point(s, az1) : point(s, az0);
         const f3 b = (lane & 1u) ? point(sn, az1) : point(s, az1);
         f3 n = cross(a, b);
-        const float nl2 = dot(n, n);
+        const float nl2 = hz_dot(n, n);
         float ok = 0.0f;
         if (nl2 > 1e-14f) { const float il = hz_rsq(nl2); n = make_f3(n.x * il, n.y * il, n.z * il); ok = 1.0f; }
         const f3 na = cross(n, a), bn = cross(b, n);
@@ -545,7 +592,7 @@ void k_horizon(HorizonParams p)
         HZ_SYNC();
         // cos(theta) and azimuth of a world direction in the surfel's frame
         auto local = [&](const f3& d, float& cs, float& th) {
-            const float x = dot(Xd, d), y = dot(Nd, d), z = dot(Zd, d);
+            const float x = hz_dot(Xd, d), y = hz_dot(Nd, d), z = hz_dot(Zd, d);
             const float l2 = x * x + y * y + z * z;
             cs = l2 > 0.0f ? y * hz_rsq(l2) : 1.0f;
             th = hz_atan2_turns(z, x);
@@ -553,7 +600,7 @@ void k_horizon(HorizonParams p)
         // The surfel's own pole first: if the normal itself points into the blocked set, no walk along a meridian ever leaves it — every row is
         // blocked from its first column.  (Its sector's horizon and both neighbours'; next to the tile's pole, where sectors meet, every sector's.)
         {
-            const float sN = dot(Nt, Nw), xN = dot(Xt, Nw), zN = dot(Zt, Nw);
+            const float sN = hz_dot(Nt, Nw), xN = hz_dot(Xt, Nw), zN = hz_dot(Zt, Nw);
             float th = hz_atan2_turns(zN, xN);
             th -= floorf(th);
             const int sk = (int)(th * 32.0f) & 31;
@@ -576,10 +623,10 @@ void k_horizon(HorizonParams p)
             const bool arc = nn.x != 0.0f || nn.y != 0.0f || nn.z != 0.0f;
             if (arc) {
                 // the arc's point nearest the surfel's pole: the pole's foot on the arc's plane, if it falls between the ends
-                const float dn = dot(Nw, nn);
+                const float dn = hz_dot(Nw, nn);
                 const f3 q = make_f3(Nw.x - dn * nn.x, Nw.y - dn * nn.y, Nw.z - dn * nn.z);
-                const float ql2 = dot(q, q);
-                const bool inside = ql2 > 1e-12f && dot(q, make_f3(L[6], L[7], L[8])) >= 0.0f && dot(q, make_f3(L[9], L[10], L[11])) >= 0.0f;
+                const float ql2 = hz_dot(q, q);
+                const bool inside = ql2 > 1e-12f && hz_dot(q, make_f3(L[6], L[7], L[8])) >= 0.0f && hz_dot(q, make_f3(L[9], L[10], L[11])) >= 0.0f;
                 if (inside) { float cs_q, th_q; local(q, cs_q, th_q); f = fmaxf(f, cs_q); }
             }
             f = fminf(f + kMarginF, 1.0f);
@@ -625,3 +672,6 @@ void k_horizon(HorizonParams p)
 
 
 } // namespace aob
+#if defined(__clang__) && !defined(AOB_HZ_NO_CONTRACT)
+#pragma clang fp contract(off)
+#endif

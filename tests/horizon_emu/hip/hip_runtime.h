@@ -62,6 +62,7 @@ static inline int __builtin_amdgcn_readfirstlane(int v) { return emu::from_lane(
 static inline int __builtin_amdgcn_readlane(int v, int l) { return emu::from_lane(v, (unsigned)l); }
 static inline float __builtin_amdgcn_rcpf(float v) { return 1.0f / v; }
 static inline float __builtin_amdgcn_rsqf(float v) { return 1.0f / std::sqrt(v); }
+static inline float __builtin_amdgcn_sqrtf(float v) { return std::sqrt(v); }
 #define __builtin_amdgcn_fence(...) ((void)0)
 static inline void __builtin_amdgcn_wave_barrier() { std::atomic_thread_fence(std::memory_order_seq_cst); emu::sync(); }
 static inline int __popcll(uint64_t v) { return __builtin_popcountll(v); }
