@@ -12,13 +12,13 @@
 // (kMarginU, kMarginPhi, kMarginF), and the parity suite bakes with it by default.
 //
 // One wavefront per tile of 64 surfels (the trace order's 8x8-texel tiles), three phases:
-//   A  lane = child box: a walk of the quantised 4-ary tree from the tile (depth first, the children of 16 nodes per round).  A box nearer
-//      than r_near is opened down to its triangles (the NEAR list).  Every other box is measured against the tile in the tile's own frame
-//      (pole = the surfels' mean normal): its top — the largest sin(elevation) any point of it can have over any origin of the tile, the box
-//      grown by the tile's extent — and its arc of azimuths.  H[32] is the tile's horizon: the sin(elevation) below which a direction may be
-//      blocked for SOME origin of the tile.  A box wholly under H is dropped (what it could block is blocked already); a leaf in the middle
-//      distance is measured exactly (its vertices against the boxes of 16 groups of four origins) and raises H; a small box or a far leaf
-//      raises H by its own top; anything else is opened.
+//   A  lane = child box: a walk of the quantised 4-ary tree from the tile (depth first, the four children of up to 16 nodes per round).  A box nearer
+//      than r_near — or a leaf that looks big from the tile — is opened down to its triangles (the NEAR list).  Every other box is measured against the
+//      tile in the tile's own frame (pole = the surfels' mean normal): its top — the largest sin(elevation) any point of it can have over any origin of
+//      the tile, the box grown by the tile's extent — and its arc of azimuths.  H[32] is the tile's horizon: the sin(elevation) below which a direction
+//      may be blocked for SOME origin of the tile.  A box wholly under H is dropped (what it could block is blocked already); a leaf in the middle
+//      distance is put aside and measured exactly, a wavefront's worth at a time (its vertices against the boxes of 8 groups of 8 origins), and raises H;
+//      a small box or a far leaf raises H by its own top; anything else is opened.
 //   B  lane = surfel: the near triangles against each surfel's own tangent frame, into its local table (LDS).
 //   C  lane = surfel: the boundary of {sin E <= H[az]} as a closed polyline of great-circle arcs (a latitude's chord lies poleward of it:
 //      southern latitudes are raised so that the chord stays above), each arc into the local table: from a blocked direction the way to
@@ -31,8 +31,8 @@ namespace aob {
 
 // ---- host ----
 
-// The tables cost a fixed time per surfel (k_horizon: ~1.7 us per tile of 64 on the 1 M-triangle terrain) and save time per SAMPLE: measured on
-// MI355X, BASELINE configs[2] (256 spp) traces 6 % faster with them, the terrain with closest-hit scoring 11 %, configs[1] (64 spp) 39 % SLOWER
+// The tables cost a fixed time per surfel (k_horizon: 4.7 ms for the 65 536 tiles of a 2048^2 atlas over the 1 M-triangle terrain) and save time per SAMPLE: measured on
+// MI355X, BASELINE configs[2] (256 spp) traces 12 % faster with them, the terrain with closest-hit scoring likewise, configs[1] (64 spp) a third SLOWER
 // (profiles/r06/horizon/).  trace_horizon 0 — the default — therefore means: from 128 samples per surfel on.
 bool horizon_applies(const AobOptions& o)
 {
@@ -75,7 +75,13 @@ bool horizon_build(AobBake* b, DeviceMaterial& m, uint64_t begin, uint64_t end, 
     p.K = g.sy; p.C = g.sx;
     p.bias = o.ray_bias > 0.0f ? o.ray_bias : 0.0f;
     p.reach = tmax < 1e30f ? (tmax + fabsf(o.ray_bias)) * 1.01f : INFINITY;
-    p.near_factor = 0.5f; p.mid_factor = 3.0f; p.small2 = 0.14f * 0.14f; p.big2 = 0.6f;
+    #ifndef AOB_HZ_MID
+#define AOB_HZ_NEAR 0.5f
+#define AOB_HZ_MID 3.0f
+#define AOB_HZ_SMALL 0.14f
+#define AOB_HZ_BIG 0.6f
+#endif
+    p.near_factor = AOB_HZ_NEAR; p.mid_factor = AOB_HZ_MID; p.small2 = AOB_HZ_SMALL * AOB_HZ_SMALL; p.big2 = AOB_HZ_BIG;
     p.out = m.horizon; p.stride = stride;
     p.tile_stride = 1u;
     // (diagnostics only on request — aob_bake_horizon_counters(.., 2): nine contended global atomics per tile cost more than the kernel itself, 5.6 of 7.2 ms)

@@ -8,7 +8,10 @@
 namespace aob {
 
 static constexpr int kHzWave = 64;
-static constexpr int kHzGroups = 8;              // groups of 64 / kHzGroups consecutive origins a middle-distance leaf is measured against (16: tighter, twice the work)
+#ifndef AOB_HZ_GROUPS
+#define AOB_HZ_GROUPS 8
+#endif
+static constexpr int kHzGroups = AOB_HZ_GROUPS;              // groups of 64 / kHzGroups consecutive origins a middle-distance leaf is measured against (16: tighter, twice the work)
 static constexpr int kHzSectors = 32;            // sectors of the tile's horizon H
 #ifndef AOB_HZ_OPEN_CAP
 #define AOB_HZ_OPEN_CAP 512

@@ -38,16 +38,15 @@ def main():
         for k, v in zip(names, combo):
             setattr(o, k, v)
         with Baker(flat, o) as b:
-            b.build_bvh(); b.rasterize(0)
             best = None
             for _ in range(a.reps + 1):
-                b.clear_results(0); b.trace(0); b.sync()
+                b.build_bvh(); b.rasterize(0); b.trace(0); b.sync()
                 s = b.last_stage_ms()
                 if best is None or s["trace"] < best["trace"]:
                     best = s
             st = b.stats()
             crc = zlib.crc32(np.ascontiguousarray(b.results(0)).tobytes())
-        print(json.dumps({"knobs": dict(zip(names, combo)), "trace": round(best["trace"], 3), "tile_cuts": round(best["tile_cuts"] or 0, 3),
+        print(json.dumps({"knobs": dict(zip(names, combo)), "bvh_build": round(best["bvh_build"] or 0, 3), "rasterize": round(best["rasterize"] or 0, 3), "trace": round(best["trace"], 3), "tile_cuts": round(best["tile_cuts"] or 0, 3),
                           "horizon": round(best["horizon"] or 0, 3), "walk": round(best["walk"] or 0, 3), "cast_share": round(st.rays_cast / max(1, st.ray_count), 4), "cells_crc32": crc}), flush=True)
 
 
