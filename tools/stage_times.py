@@ -23,6 +23,6 @@ with Baker(flat, o) as b:
     best=None
     for _ in range(4):
         b.clear_results(0); b.trace(0); b.sync(); s=b.last_stage_ms()
-        if best is None or s["horizon"] < best["horizon"]: best=s
+        if best is None or s["trace"] < best["trace"]: best=s
     st=b.stats()
     print(json.dumps({"lib": os.environ.get("AOBAKER_HIP_LIBRARY","in-tree").split("/")[-1], **{k: round(v,3) for k,v in best.items() if v is not None}, "cast_share": round(st.rays_cast/ max(1,st.ray_count),4)}), flush=True)
