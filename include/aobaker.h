@@ -87,13 +87,14 @@ typedef struct AobOptions {
     int32_t  normal_fp16;         /* AOB_FP16_*: the RGBA16F NormalV target, :446         */
     int32_t  ray_chunk_size;      /* reference rayChunkSize; bounds the compat table      */
     int32_t  clamp_tmax_to_falloff; /* falloff mode: cast with tmax=min(tmax,falloff)     */
-    int32_t  bvh_width;           /* traversal structure: 2 = the reference's BVH2 nodes, one lane
-                                     per ray; 4 = BVH2 collapsed to 4-ary nodes, four lanes per ray
-                                     (quantised: one lane per ray); 0 = 2.  Default 4             */
-    int32_t  bvh_quantised;       /* default 1.  With bvh_width 4: 1 = lane-per-ray walk of AobBvh4QNode,
-                                     0 = quad-per-ray walk of the fp32 AobBvh4Node.  With bvh_width 2:  0: 64-byte fp32 nodes (the reference layout);
-                                     1: 32-byte nodes, child boxes as 15-bit fixed point on the scene
-                                     box, rounded outward (AobBvh2QNode)                            */
+    int32_t  bvh_width;           /* traversal structure: 2 = the reference's BVH2 nodes; 4 = BVH2 collapsed to
+                                     4-ary nodes (quantised only: bvh_quantised must be 1); 0 = 2.  One lane per
+                                     ray either way.  Default 4                                                    */
+    int32_t  bvh_quantised;       /* default 1.  With bvh_width 4: 1 = the walk of AobBvh4QNode; 0 is REFUSED with
+                                     AOB_ERR_UNSUPPORTED since ABI 6 (the quad-per-ray walk of the fp32 AobBvh4Node was an
+                                     experiment 2.7x slower, retired to tools/experiments/).  With bvh_width 2:  0: 64-byte
+                                     fp32 nodes (the reference layout); 1: 32-byte nodes, child boxes as 15-bit fixed point
+                                     on the scene box, rounded outward (AobBvh2QNode)                               */
     int32_t  bvh_builder;         /* -1 (AOB_BVH_BUILDER_AUTO, the default): 1 or 2 by workload, see aob_resolve_bvh_builder;
                                      0: LBVH, the reference stack's GPU builder (kernels/CL/build_hlbvh.cl);
                                      1: PLOC (locally-ordered agglomerative clustering over the same Morton
@@ -136,7 +137,8 @@ typedef struct AobOptions {
                                      0 (default) = 32 entries, 4..32 = that many, 1 = off (the walk from the root).  Like the knobs above
                                      it moves work and never changes a result cell.  The cuts take 512 B per tile and record of device
                                      memory (up to 96 B per covered texel), allocated when a material is rasterised; a bake that cannot
-                                     have them walks from the root and says so (AobStats::trace_cuts).  (ABI 5)                        */
+                                     have them walks from the root and says so (AobStats::trace_cuts).  (the field: ABI 5; closest-hit
+                                     rays below cuts and AobStats::trace_cuts: ABI 6)                                                  */
     int32_t  trace_horizon;       /* COSINE sampler on a full sx x sy grid (sample_count = sx * sy, both 4..32), quantised 4-ary nodes: every surfel
                                      gets a HORIZON TABLE — for each azimuth row of the sampler's grid the number of leading columns (the
                                      directions nearest the normal) that no triangle of the scene can reach, proven from the tree with
