@@ -367,7 +367,8 @@ def main():
         capi.check(baker.lib.aob_bake_node4q_count(baker.handle, C.byref(n4q)))
         baker.lib.aob_bake_copy_tile_cuts(baker.handle, 0, None, 0, C.byref(tiles_c), C.byref(recs_c))
         parts = {"nodes4q": int(n4q.value) * 64, "leaf_tris": int(stats.triangle_count) * 48, "frames": int(counts["mine"]) * 64,
-                 "tile_cuts": int(tiles_c.value) * int(recs_c.value) * 512, "result_cells": int(counts["mine"]) * 8}
+                 "tile_cuts": int(tiles_c.value) * int(recs_c.value) * 512, "result_cells": int(counts["mine"]) * 8,
+                 "horizon_tables": int(counts["mine"]) * (16 if args.spp <= 256 else 32) if int(stats.trace_horizon) == 1 else 0}
         footprint = {"bytes": sum(parts.values()), "of_which": parts}
     except Exception as e:
         print(f"bench: footprint failed: {e!r}", file=sys.stderr)
