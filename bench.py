@@ -68,8 +68,8 @@ KERNEL_SOURCES = ("aobaker_amd/csrc/trace.hip", "aobaker_amd/csrc/aob_math.h", "
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)      # (the default line is the driver's: 20 timed steps after 5 — a second of GPU time; with 3 after 1 the clocks had not settled: 43.0 ms a step against 40.9)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--atlas", type=int, default=0, help="0 = the BASELINE config of --gpus (2048 at N=1, 4096 at N>1)")
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--grid", type=int, default=708, help="terrain grid (708 -> 999 698 triangles)")
